@@ -1,0 +1,489 @@
+#!/usr/bin/env python3
+"""Generate the golden input/output vectors under tests/golden/*.npz by IMPORTING THE
+REFERENCE (read-only, /root/reference) in the build container, CPU, float32.
+
+Run:  python tests/golden/make_golden.py          (needs /root/reference; never runs on the GPU box)
+
+Each .npz holds seeded inputs plus the outputs the reference's own code produced for
+them.  The fixtures are data only; no reference source is stored.  The oracle
+(oracle/pita_oracle.py) and the HIP path are both checked against them.
+"""
+import os
+import sys
+from functools import partial
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _ref_shims  # noqa: E402
+
+_ref_shims.install()
+
+from src.energies import base_prior, gmm_energy, lennardjones_energy  # noqa: E402
+from src.models.components import (annealing_factor_schedules, egnn, egnn_temp_conditioned, energy_net,  # noqa: E402
+                                   mlp, noise_schedules, score_net, sde_integration, sdes, utils)
+from src.utils import data_utils  # noqa: E402
+
+torch.set_num_threads(8)
+F32 = np.float32
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB  ({len(arrs)} arrays)")
+
+
+def sd_np(module):
+    return {k: v.detach().numpy().copy() for k, v in module.state_dict().items()}
+
+
+class LJ(lennardjones_energy.LennardJonesEnergy):
+    """The reference class with only its dataset loading (absent .npy files) disabled."""
+
+    def setup_test_set(self):
+        return None
+
+    def setup_val_set(self):
+        return None
+
+
+def lattice_cluster(n, d, B, gen, spacing=1.08, jitter=0.07):
+    """Compact, physically reasonable n-particle clusters (min distance ~0.8)."""
+    r = 3
+    grid = np.stack(np.meshgrid(*[np.arange(-r, r + 1)] * d, indexing="ij"), -1).reshape(-1, d).astype(np.float64)
+    # fcc-like offset for 3D to get ~12 neighbours
+    order = np.argsort((grid**2).sum(-1), kind="stable")
+    pts = grid[order[:n]] * spacing
+    x = torch.tensor(pts, dtype=torch.float32)[None].repeat(B, 1, 1)
+    x = x + jitter * torch.randn(B, n, d, generator=gen)
+    x = x - x.mean(dim=1, keepdim=True)
+    return x.reshape(B, n * d)
+
+
+# ----------------------------------------------------------------------------- schedules
+def gen_schedules():
+    t = torch.linspace(0, 1, 1001)
+    out = {"t": t.numpy()}
+    for smin in (0.002, 0.01, 0.05):
+        s = noise_schedules.ElucidatingNoiseSchedule(sigma_min=smin, sigma_max=80.0, rho=7)
+        h = s.h(t)
+        out[f"h_{smin}"] = h.numpy()
+        out[f"g_{smin}"] = s.g(t).numpy()
+        out[f"dhdt_{smin}"] = s.dh_dt(t).numpy()
+        out[f"tinv_{smin}"] = s.t(h).numpy()
+    geo = noise_schedules.GeometricNoiseSchedule(0.01, 10.0)
+    out["geo_h"] = geo.h(t).numpy()
+    out["geo_g"] = geo.g(t).numpy()
+    c = annealing_factor_schedules.ConstantAnnealingFactorSchedule(4 / 3)
+    l = annealing_factor_schedules.LinearAnnealingFactorSchedule(1.5, 1.0, t_start=0.9, t_end=0.1)
+    s = annealing_factor_schedules.SigmoidAnnealingFactorSchedule(1.5, 1.0, t_start=0.9, t_end=0.1, sharpness=10.0)
+    tt = torch.linspace(-0.1, 1.1, 241)
+    out["tt"] = tt.numpy()
+    for nm, sch in (("const", c), ("lin", l), ("sig", s)):
+        out[f"gamma_{nm}"] = sch.gamma(tt).numpy()
+        out[f"dgamma_{nm}"] = sch.dgamma_dt(tt).numpy()
+    save("schedules.npz", **out)
+
+
+# ----------------------------------------------------------------------------- LJ target
+def gen_lj():
+    for n in (13, 55):
+        gen = torch.Generator().manual_seed(1000 + n)
+        D = 3 * n
+        cold = lattice_cluster(n, 3, 48, gen)
+        warm = lattice_cluster(n, 3, 8, gen, spacing=1.3, jitter=0.25)
+        hot = torch.randn(8, D, generator=gen) * 1.0  # adversarial: overlapping particles, |E| ~ 1e6+
+        hot = data_utils.remove_mean(hot, n, 3)
+        x = torch.cat([cold, warm, hot])
+        out = {"x": x.numpy(), "n_cold": 48, "n_warm": 8}
+        for T in (1.0, 2.0, 4.0):
+            e = LJ(D, n, 3, data_path="", temperature=T)
+            lp = e(x.clone())
+            lp2, f = e(x.clone(), return_force=True)
+            assert torch.equal(lp, lp2)
+            out[f"logp_T{T}"] = lp.numpy()
+            out[f"force_T{T}"] = f.numpy()
+        e = LJ(D, n, 3, data_path="", temperature=1.0, energy_factor=0.5)
+        lp, f = e(x.clone(), return_force=True)
+        out["logp_ef0.5"] = lp.numpy()
+        out["force_ef0.5"] = f.numpy()
+        save(f"lj{n}_logp_force.npz", **out)
+
+
+# ----------------------------------------------------------------------------- GMM target
+def gen_gmm():
+    out = {}
+    for T in (1.0, 2.0):
+        g = gmm_energy.GMM(temperature=T)
+        gen = torch.Generator().manual_seed(7)
+        x = (torch.rand(256, 2, generator=gen) - 0.5) * 112
+        if T == 1.0:
+            out["x"] = x.numpy()
+            out["means"] = g.gmm.locs.numpy()
+            out["scale_trils"] = g.gmm.scale_trils.numpy()
+            out["cat_probs"] = g.gmm.cat_probs.numpy()
+            xs = x.clone().requires_grad_(True)
+            (grad,) = torch.autograd.grad(g(xs).sum(), xs)
+            out["grad_T1.0"] = grad.numpy()
+        out[f"logp_T{T}"] = g(x).numpy()
+    save("gmm40.npz", **out)
+
+
+# ----------------------------------------------------------------------------- EGNN
+def make_egnn(n, d, temp=True):
+    torch.manual_seed(12345)
+    if temp:
+        return egnn_temp_conditioned.EGNN_dynamics(
+            n_particles=n, n_dimension=d, hidden_nf=32, n_layers=3, act_fn=torch.nn.SiLU(), recurrent=True,
+            tanh=True, attention=True, condition_time=True, condition_temperature=True, agg="sum")
+    return egnn.EGNN_dynamics(n_particles=n, n_dimension=d, hidden_nf=32, n_layers=3, act_fn=torch.nn.SiLU(),
+                              recurrent=True, tanh=True, attention=True, condition_time=True, agg="sum")
+
+
+def gen_egnn():
+    net13 = make_egnn(13, 3)
+    w = sd_np(net13)
+    save("egnn_weights_seed12345.npz", **w)
+    # a second, "trained-like" weight set: the xavier(gain=1e-3) coord head of the fresh
+    # init makes velocities ~1e-4; scale those heads up so every term matters numerically.
+    torch.manual_seed(777)
+    net_t = make_egnn(13, 3)
+    with torch.no_grad():
+        for l in range(3):
+            getattr(net_t.egnn, f"gcl_{l}").coord_mlp[2].weight.mul_(300.0)
+        for p in net_t.parameters():
+            p.add_(0.02 * torch.randn_like(p))
+    wt = sd_np(net_t)
+    save("egnn_weights_trainedlike.npz", **wt)
+
+    for name, n, d in (("lj13", 13, 3), ("dw4", 4, 2), ("lj55", 55, 3)):
+        B = 24 if n < 55 else 8
+        gen = torch.Generator().manual_seed(4242 + n)
+        base = lattice_cluster(n, d, B, gen, spacing=1.1 if d == 3 else 2.5, jitter=0.1)
+        hs = torch.tensor([1e-3, 0.0025, 0.1, 1.0, 10.0, 400.0, 6400.0, 3.0])[torch.arange(B) % 8]
+        x = base + hs.sqrt()[:, None] * torch.randn(B, n * d, generator=gen)
+        betas = torch.tensor([1.0, 1.33, 4.0])[torch.arange(B) % 3]
+        out = {"x": x.numpy(), "h": hs.numpy(), "beta": betas.numpy(), "n": n, "d": d}
+        for tag, state in (("init", w), ("trained", wt)):
+            net = make_egnn(n, d)
+            net.load_state_dict({k: torch.tensor(v) for k, v in state.items()})
+            sn = score_net.ScoreNet(net)
+            with torch.no_grad():
+                c_noise = (1 / 8) * torch.log(hs)
+                c_in = 1 / (1 + hs) ** 0.5
+                F = net(c_noise, c_in[:, None] * x, betas)
+                Dth = sn.denoiser(hs, x, betas)
+                sc = sn(hs, x, betas)
+            out[f"F_{tag}"] = F.numpy()
+            out[f"D_{tag}"] = Dth.numpy()
+            out[f"score_{tag}"] = sc.numpy()
+            # energy-net view of the same backbone (energy_net.py:14-49)
+            en = energy_net.EnergyNet(net)
+            with torch.no_grad():
+                out[f"E_{tag}"] = en.forward_energy(hs, x, betas).numpy()
+        # pin the t/beta interleave quirk: recompute the h0 matrix the way the reference does
+        t_ = c_noise.unsqueeze(-1)
+        b_ = betas.unsqueeze(-1)
+        h0 = torch.cat([torch.ones(B, n) * t_, torch.ones(B, n) * b_], dim=-1).reshape(B * n, 2)
+        out["h0"] = h0.numpy()
+        out["c_noise"] = c_noise.numpy()
+        save(f"egnn_{name}_fwd.npz", **out)
+
+    # non-temperature-conditioned egnn.py (in_node_nf=1)
+    net1 = make_egnn(13, 3, temp=False)
+    gen = torch.Generator().manual_seed(99)
+    x = lattice_cluster(13, 3, 8, gen) + 0.3 * torch.randn(8, 39, generator=gen)
+    t = torch.linspace(-0.8, 1.0, 8)
+    with torch.no_grad():
+        y = net1(t, x)
+    save("egnn_notemp_lj13_fwd.npz", x=x.numpy(), t=t.numpy(), out=y.numpy(), **{"w." + k: v for k, v in sd_np(net1).items()})
+
+
+# ----------------------------------------------------------------------------- MLP
+def gen_mlp():
+    torch.manual_seed(12345)
+    net = mlp.MyMLP(hidden_size=128, hidden_layers=3, emb_size=128, out_dim=2, input_dim=2)
+    gen = torch.Generator().manual_seed(5)
+    B = 64
+    hs = torch.exp(torch.rand(B, generator=gen) * (np.log(6400.0) - np.log(1e-4)) + np.log(1e-4))
+    x = (torch.rand(B, 2, generator=gen) - 0.5) * 100 + hs.sqrt()[:, None] * torch.randn(B, 2, generator=gen)
+    beta = torch.ones(B)
+    sn = score_net.ScoreNet(net)
+    with torch.no_grad():
+        c_noise = (1 / 8) * torch.log(hs)
+        c_in = 1 / (1 + hs) ** 0.5
+        F = net(c_noise, c_in[:, None] * x, beta)
+        sc = sn(hs, x, beta)
+    w = {"w." + k: v for k, v in sd_np(net).items()}
+    save("mlp_gmm_fwd.npz", x=x.numpy(), h=hs.numpy(), F=F.numpy(), score=sc.numpy(), **w)
+
+    torch.manual_seed(54321)
+    # NB the reference sizes the last Linear by emb_size (mlp.py:489-490), so hidden_size must equal emb_size
+    net2 = mlp.MyMLPTemperature(hidden_size=64, hidden_layers=2, emb_size=64, out_dim=3, input_dim=3)
+    x3 = torch.randn(32, 3, generator=gen) * 3
+    t3 = torch.randn(32, generator=gen)
+    b3 = torch.rand(32, generator=gen) * 3 + 0.5
+    with torch.no_grad():
+        y = net2(t3, x3, b3)
+    save("mlp_temp_fwd.npz", x=x3.numpy(), t=t3.numpy(), beta=b3.numpy(), out=y.numpy(),
+         **{"w." + k: v for k, v in sd_np(net2).items()})
+
+
+# ----------------------------------------------------------------------------- prior / remove_mean
+def gen_prior():
+    out = {}
+    for n, d in ((13, 3), (4, 2)):
+        torch.manual_seed(31 + n)
+        raw_state = torch.get_rng_state()
+        noise = torch.randn(16, n * d)
+        torch.set_rng_state(raw_state)
+        scale = 69.28203
+        p = base_prior.Prior(scale=scale, n_particles=n, spatial_dim=d)
+        s = p.sample(16)
+        out[f"noise_{n}"] = noise.numpy()
+        out[f"sample_{n}"] = s.numpy()
+        out[f"logprob_{n}"] = p.log_prob(s).numpy()
+        out["scale"] = scale
+        out[f"remove_mean_{n}"] = data_utils.remove_mean(noise, n, d).numpy()
+    save("prior.npz", **out)
+
+
+# ----------------------------------------------------------------------------- resampling
+def gen_resample():
+    out = {}
+    gen = torch.Generator().manual_seed(11)
+    cases = {
+        "normal": torch.randn(257, generator=gen) * 3,
+        "ties": torch.zeros(64),
+        "peaked": torch.cat([torch.full((99,), -50.0), torch.tensor([10.0])]),
+        "neginf": torch.cat([torch.randn(30, generator=gen), torch.full((2,), -float("inf"))]),
+        "huge": torch.randn(1000, generator=gen) * 200,
+        "big": torch.randn(5000, generator=gen) * 2,
+    }
+    real_rand = torch.rand
+    for k, logits in cases.items():
+        us = []
+
+        def rec_rand(*a, **kw):
+            r = real_rand(*a, **kw)
+            us.append(r.clone())
+            return r
+
+        torch.manual_seed(1234)
+        torch.rand = rec_rand
+        try:
+            ids, _ = utils.sample_cat_sys(logits.shape[0], logits)
+        finally:
+            torch.rand = real_rand
+        out[f"logits_{k}"] = logits.numpy()
+        out[f"u_{k}"] = us[0].numpy()
+        out[f"ids_{k}"] = np.asarray(ids, dtype=np.int64)
+        q = torch.quantile(logits[torch.isfinite(logits)], 0.9)
+        out[f"q90_{k}"] = q.numpy()
+    save("resample_sys.npz", **out)
+
+
+# ----------------------------------------------------------------------------- trajectories
+class FakeTrainer:
+    world_size = 1
+    global_rank = 0
+    num_nodes = 1
+
+
+class FakeLM:
+    """Single-rank stand-in for the LightningModule the integrator talks to
+    (sde_integration.py:227-229,248-251): all_gather adds the leading world dim."""
+
+    trainer = FakeTrainer()
+
+    def all_gather(self, obj):
+        if isinstance(obj, dict):
+            return {k: self.all_gather(v) for k, v in obj.items()}
+        if obj is None:
+            return None
+        return obj.unsqueeze(0)
+
+
+class Recorder:
+    """Record every randn_like / rand / rand_like draw made by the reference."""
+
+    def __init__(self):
+        self.randn, self.rand, self.rand_like = [], [], []
+        self._r = (torch.randn_like, torch.rand, torch.rand_like)
+
+    def __enter__(self):
+        rn, r, rl = self._r
+
+        def f_randn_like(x, *a, **k):
+            v = rn(x, *a, **k)
+            self.randn.append(v.detach().clone())
+            return v
+
+        def f_rand(*a, **k):
+            v = r(*a, **k)
+            self.rand.append(v.detach().clone())
+            return v
+
+        def f_rand_like(x, *a, **k):
+            v = rl(x, *a, **k)
+            self.rand_like.append(v.detach().clone())
+            return v
+
+        torch.randn_like, torch.rand, torch.rand_like = f_randn_like, f_rand, f_rand_like
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn_like, torch.rand, torch.rand_like = self._r
+
+
+def build_lj13_stack(weights, debias, sigma_min=0.05):
+    net = make_egnn(13, 3)
+    net.load_state_dict({k: torch.tensor(v) for k, v in weights.items()})
+    import copy
+
+    sn = score_net.ScoreNet(net)
+    en = energy_net.EnergyNet(copy.deepcopy(net))
+    sched = noise_schedules.ElucidatingNoiseSchedule(sigma_min=sigma_min, sigma_max=80.0, rho=7)
+    sde = sdes.VEReverseSDE(noise_schedule=sched, energy_net=en, score_net=sn,
+                            cdf=partial(utils.compute_divergence_exact, sn.forward), pin_energy=False,
+                            debias_inference=debias)
+    sde.trainer = FakeTrainer()
+    return sde, sched
+
+
+def gen_traj_nodebias():
+    wt = dict(np.load(os.path.join(HERE, "egnn_weights_trainedlike.npz")))
+    sde, sched = build_lj13_stack(wt, debias=False)
+    N, B = 20, 32
+    gamma = annealing_factor_schedules.ConstantAnnealingFactorSchedule(4 / 3)
+    integ = sde_integration.WeightedSDEIntegrator(
+        sde=sde, num_integration_steps=N, start_resampling_step=0, end_resampling_step=N, lightning_module=FakeLM(),
+        partial_annealing_factor_schedule=None, resampling_interval=-1, num_negative_time_steps=0, post_mcmc_steps=0,
+        batch_size=16, should_mean_free=True)
+    e = LJ(39, 13, 3, data_path="", temperature=1.0)
+    torch.manual_seed(2024)
+    scale = float((sched.h(torch.tensor(1.0)) / gamma.gamma(torch.tensor(1.0))) ** 0.5)
+    x1 = base_prior.Prior(scale=scale, n_particles=13, spatial_dim=3).sample(B)
+    xs = []
+    real_rm = data_utils.remove_mean
+    with Recorder() as rec:
+        x, logw, uniq, terms, acc = integ.integrate_sde(x1.clone(), e, gamma, inverse_temperature=1.0)
+    drift = np.stack([t.drift_X.reshape(B, 39).numpy() for t in terms])
+    diffusion = np.stack([t.diffusion.reshape(B, 39).numpy() for t in terms])
+    noise = np.stack([torch.cat(rec.randn[2 * k:2 * k + 2]).numpy() for k in range(N)])  # 2 chunks of 16 per step
+    save("em_traj_lj13_nodebias.npz", x1=x1.numpy(), x_final=x.detach().numpy(), noise=noise, drift_X=drift,
+         diffusion=diffusion, logweights=logw.numpy(), prior_scale=scale, N=N, chunk=16, gamma=4 / 3, beta=1.0,
+         sigma_min=0.05)
+
+
+def gen_traj_debias():
+    wt = dict(np.load(os.path.join(HERE, "egnn_weights_trainedlike.npz")))
+    sde, sched = build_lj13_stack(wt, debias=True)
+    N, B = 8, 12
+    gamma = annealing_factor_schedules.ConstantAnnealingFactorSchedule(4 / 3)
+    integ = sde_integration.WeightedSDEIntegrator(
+        sde=sde, num_integration_steps=N, start_resampling_step=1, end_resampling_step=7, lightning_module=FakeLM(),
+        partial_annealing_factor_schedule=None, resampling_interval=2, num_negative_time_steps=0, post_mcmc_steps=0,
+        batch_size=12, no_grad=True, should_mean_free=True)
+    e = LJ(39, 13, 3, data_path="", temperature=1.0)
+    torch.manual_seed(77)
+    scale = 3.0
+    x1 = base_prior.Prior(scale=scale, n_particles=13, spatial_dim=3).sample(B)
+    with Recorder() as rec:
+        x, logw, uniq, terms, acc = integ.integrate_sde(x1.clone(), e, gamma, inverse_temperature=1.0)
+    out = dict(x1=x1.numpy(), x_final=x.detach().numpy(), logweights=logw.detach().numpy(),
+               num_unique=np.asarray(uniq), N=N, gamma=4 / 3, beta=1.0, sigma_min=0.05,
+               noise=np.stack([r.numpy() for r in rec.randn]),
+               u=np.stack([r.numpy() for r in rec.rand]) if rec.rand else np.zeros((0, 1)))
+    for nm in ("drift_X", "drift_A", "divergence_score", "cross_term", "dUt_dt"):
+        out[nm] = np.stack([getattr(t, nm).reshape(B, -1).squeeze(-1).detach().numpy() for t in terms])
+    save("em_traj_lj13_debias.npz", **out)
+
+
+def gen_post():
+    """negative-time descent + MALA on the LJ13 target (sde_integration.py:353-470)."""
+    e_raw = LJ(39, 13, 3, data_path="", temperature=1.0)
+
+    class Detached:
+        """torch>=2.10 refuses ``requires_grad = True`` on the non-leaf views the reference's MALA
+        passes to LennardJonesEnergy.__call__ (lennardjones_energy.py:216) -- the reference then
+        swallows the exception (sde_integration.py:401) and MALA silently does nothing.  Hand the
+        energy a detached alias of the same storage so the reference arithmetic runs unchanged."""
+
+        is_molecule, n_particles, n_spatial_dim = True, 13, 3
+
+        def __call__(self, x, return_force=False):
+            return e_raw(x.detach(), return_force=return_force)
+
+    e = Detached()
+    gen = torch.Generator().manual_seed(5150)
+    x0 = lattice_cluster(13, 3, 16, gen, spacing=1.12, jitter=0.1)
+
+    def mk(**kw):
+        d = dict(sde=None, num_integration_steps=1, start_resampling_step=0, end_resampling_step=1,
+                 lightning_module=FakeLM(), partial_annealing_factor_schedule=None)
+        d.update(kw)
+        return sde_integration.WeightedSDEIntegrator(**d)
+
+    out = {"x0": x0.numpy()}
+    integ = mk(num_negative_time_steps=25, dt_negative_time=1e-4, do_langevin=False)
+    out["x_descent"] = integ.negative_time_descent(x0.clone(), e).detach().numpy()
+    integ = mk(num_negative_time_steps=10, dt_negative_time=1e-4, do_langevin=True)
+    torch.manual_seed(3)
+    with Recorder() as rec:
+        out["x_langevin"] = integ.negative_time_descent(x0.clone(), e).detach().numpy()
+    out["langevin_noise"] = np.stack([r.numpy() for r in rec.randn])
+    # plain MALA, 6 steps, dt chosen so acceptance is mixed
+    integ = mk(post_mcmc_steps=6, dt_negative_time=4e-4, adaptive_mcmc=False)
+    torch.manual_seed(4)
+    with Recorder() as rec:
+        xm, accs = integ.metropolis_hastings_mala(x0.clone(), e, return_acceptance_rate=True)
+    out["x_mala"] = xm.detach().numpy()
+    out["mala_acc"] = np.asarray(accs)
+    out["mala_noise"] = np.stack([r.numpy() for r in rec.randn])
+    out["mala_u"] = np.stack([r.numpy() for r in rec.rand_like])
+    # adaptive MALA
+    integ = mk(post_mcmc_steps=6, dt_negative_time=4e-4, adaptive_mcmc=True)
+    torch.manual_seed(5)
+    with Recorder() as rec:
+        xa, accs = integ.metropolis_hastings_mala_adaptive(x0.clone(), e, dt_init=4e-4, return_acceptance_rate=True)
+    out["x_mala_adaptive"] = xa.detach().numpy()
+    out["mala_adaptive_acc"] = np.asarray(accs)
+    out["mala_adaptive_noise"] = np.stack([r.numpy() for r in rec.randn])
+    out["mala_adaptive_u"] = np.stack([r.numpy() for r in rec.rand_like])
+    save("post_lj13.npz", **out)
+
+
+def gen_traj_gmm():
+    """Config C1 plumbing: 40-mode GMM target, MyMLP score net, 100 steps (B reduced to 64 here)."""
+    w = {k[2:]: v for k, v in np.load(os.path.join(HERE, "mlp_gmm_fwd.npz")).items() if k.startswith("w.")}
+    net = mlp.MyMLP(hidden_size=128, hidden_layers=3, emb_size=128, out_dim=2, input_dim=2)
+    net.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
+    sn = score_net.ScoreNet(net)
+    sched = noise_schedules.ElucidatingNoiseSchedule(sigma_min=0.01, sigma_max=80.0, rho=7)
+    sde = sdes.VEReverseSDE(noise_schedule=sched, energy_net=None, score_net=sn, cdf=lambda *a: None,
+                            debias_inference=False)
+    N, B = 100, 64
+    gamma = annealing_factor_schedules.ConstantAnnealingFactorSchedule(1.0)
+    integ = sde_integration.WeightedSDEIntegrator(
+        sde=sde, num_integration_steps=N, start_resampling_step=0, end_resampling_step=N, lightning_module=FakeLM(),
+        partial_annealing_factor_schedule=None, resampling_interval=-1, num_negative_time_steps=0, post_mcmc_steps=0,
+        batch_size=None, should_mean_free=False)
+    g = gmm_energy.GMM()
+    torch.manual_seed(99)
+    x1 = torch.randn(B, 2) * 80.0
+    with Recorder() as rec:
+        x, logw, uniq, terms, acc = integ.integrate_sde(x1.clone(), g, gamma, inverse_temperature=1.0)
+    save("em_traj_gmm_mlp.npz", x1=x1.numpy(), x_final=x.detach().numpy(),
+         noise=np.stack([r.numpy() for r in rec.randn]),
+         drift_X=np.stack([t.drift_X.reshape(B, 2).numpy() for t in terms]), N=N, sigma_min=0.01)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["schedules", "lj", "gmm", "egnn", "mlp", "prior", "resample", "traj_nodebias",
+                             "traj_debias", "post", "traj_gmm"]
+    for w in which:
+        globals()["gen_" + w]()
