@@ -1,0 +1,193 @@
+/*
+ * pita_hip.h -- C ABI of libpita_hip.so: MI355X (gfx950) kernels for the inference-time
+ * annealed reverse-SDE sampling path of PITA (taraak/pita).
+ *
+ * The reference has no FFI (it is 100% Python); its "plugin API" is the Python classes
+ * WeightedSDEIntegrator / VEReverseSDE / ScoreNet / EGNN_dynamics / MyMLP /
+ * LennardJonesEnergy / GMM / Prior.  pita_amd/ mirrors those classes and binds the entry
+ * points below through ctypes (INTEGRATION.md shows the binding).  Each entry point cites
+ * the reference code it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer named x/out/logp/force/... is a DEVICE pointer owned by the caller
+ *     (torch tensors); the library never allocates per call and never synchronises;
+ *   - `stream` is a hipStream_t passed as void*; all work is asynchronous on it;
+ *   - walker-major row-major layout [B, D] with D = n_particles * n_dim, fp32, exactly the
+ *     reference's tensor layout (no transposes at the boundary);
+ *   - every function returns 0 on success or a negative PITA_E* code; pita_last_error()
+ *     gives the message.  Nothing throws, nothing aborts.
+ */
+#ifndef PITA_HIP_H
+#define PITA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PITA_ABI_VERSION 1
+
+enum {
+  PITA_OK = 0,
+  PITA_EINVAL = -1,      /* bad argument (null pointer, unsupported shape ...) */
+  PITA_EUNSUPPORTED = -2,/* configuration the HIP path does not implement */
+  PITA_EHIP = -3,        /* a HIP runtime call failed */
+  PITA_ENOMEM = -4
+};
+
+int pita_abi_version(void);
+/* copies the calling thread's last error message into buf (NUL terminated); returns its length */
+int pita_last_error(char* buf, size_t buflen);
+/* number of visible HIP devices, or a negative error */
+int pita_device_count(void);
+
+/* ---------------------------------------------------------------- target energies (K1-K3)
+ * All return log-density = -E/T (the reference convention, base_energy_function.py:149) and,
+ * when force != NULL, force = d logp / dx.
+ */
+
+/* Lennard-Jones cluster + harmonic oscillator.
+ * replaces LennardJonesEnergy.__call__ (pita/src/energies/lennardjones_energy.py:213-227),
+ * LennardJonesPotential._energy/_log_prob (:121-155) and bgflow's distance_vectors /
+ * distances_from_vectors (r = sqrt(|dx|^2 + dist_eps)); ordered pairs (each pair twice). */
+int pita_lj_logp_force(const float* x, float* logp, float* force /*nullable*/, int64_t B,
+                       int n_particles, int n_dim, float temperature, float energy_factor,
+                       float dist_eps, float eps, float rm, float osc_scale, void* stream);
+
+/* DW4-style multi double well  E = sum_{i<j} a (d-d0)^4 + b (d-d0)^2 + c.
+ * Not present in the reference tree (only a dead import, base_datamodule.py:13); formula of
+ * bgflow.MultiDoubleWellPotential. */
+int pita_dw_logp_force(const float* x, float* logp, float* force /*nullable*/, int64_t B,
+                       int n_particles, int n_dim, float temperature, float a, float b, float c,
+                       float d0, void* stream);
+
+/* Diagonal Gaussian mixture with equal weights.
+ * replaces GMM.__call__ (pita/src/energies/gmm_energy.py:87-90) ->
+ * fab GMM.log_prob (fab/fab/target_distributions/gmm.py:71-79,104).
+ * means, scales: device [K, dim].  */
+int pita_gmm_logp_force(const float* x, float* logp, float* force /*nullable*/, int64_t B, int dim,
+                        const float* means, const float* scales, int K, float temperature,
+                        void* stream);
+
+/* ---------------------------------------------------------------- EGNN backbone (K5, K7)
+ * replaces EGNN_dynamics.forward (pita/src/models/components/egnn_temp_conditioned.py:56-93,
+ * egnn.py:50-80), EGNN.forward (:172-194), E_GCL (:197-356) and the EDM wrappers
+ * ScoreNet.denoiser / ScoreNet.forward (score_net.py:13-43).
+ */
+typedef struct pita_egnn pita_egnn_t;
+
+typedef struct {
+  int n_particles;
+  int n_dim;
+  int hidden_nf;        /* only 32 is implemented in HIP */
+  int n_layers;
+  int in_node_nf;       /* 1 = time only (egnn.py), 2 = time + temperature */
+  int attention;        /* att_mlp sigmoid gate present */
+  int tanh;             /* tanh on the coordinate head (* coords_range / n_layers) */
+  float coords_range;   /* 15.0 in the reference */
+  int feature_layout;   /* 0 = "pita": the reference's t/beta interleave quirk
+                           (egnn_temp_conditioned.py:68-78); 1 = per-node (t, beta) */
+} pita_egnn_config;
+
+/* `weights` is a HOST pointer to the reference state_dict flattened in its own key order:
+ * embedding.{weight,bias}, embedding_out.{weight,bias}, then per layer l:
+ * edge_mlp.0.{weight[H,2H+2],bias}, edge_mlp.2.{weight,bias}, node_mlp.0.{weight[H,2H],bias},
+ * node_mlp.2.{weight,bias}, coord_mlp.0.{weight,bias}, coord_mlp.2.weight[1,H],
+ * (att_mlp.0.{weight[1,H],bias[1]} if attention).  n_weights is checked. */
+int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, const float* weights,
+                     int64_t n_weights);
+int pita_egnn_destroy(pita_egnn_t* net);
+int64_t pita_egnn_num_weights(const pita_egnn_config* cfg);
+
+/* backbone forward: out[B,D] = F(t[B], x[B,D], beta[B]) (beta nullable when in_node_nf==1) */
+int pita_egnn_forward(pita_egnn_t* net, const float* t, const float* x, const float* beta,
+                      float* out, int64_t B, void* stream);
+/* EDM-preconditioned outputs, h = sigma^2 per walker (score_net.py:21-43):
+ *   what = 1: denoiser D = c_s x + c_out F(c_noise, c_in x, beta)
+ *   what = 2: score (D - x)/h */
+int pita_egnn_edm(pita_egnn_t* net, int what, const float* h, const float* x, const float* beta,
+                  float* out, int64_t B, void* stream);
+
+/* ---------------------------------------------------------------- fused sampler (K5+K7+K8)
+ * Runs n_steps Euler-Maruyama steps of the NOT-debiased reverse VE-SDE in ONE launch, walkers
+ * resident on chip for the whole trajectory.  replaces, per step,
+ * VEReverseSDE.f_not_debiased + .diffusion (sdes.py:117-128,245-251),
+ * WeightedSDEIntegrator.euler_maruyama_step (sde_integration.py:299-351) and the
+ * remove_mean of integrate_sde (:148).
+ *
+ * step_tab: device [n_steps][PITA_STEP_STRIDE] floats computed by the host in the
+ * reference's fp32 op order (see pita_amd/sde_integration.py):
+ */
+#define PITA_STEP_STRIDE 16
+enum {
+  PITA_ST_CS = 0, PITA_ST_CIN = 1, PITA_ST_COUT = 2, PITA_ST_CNOISE = 3, PITA_ST_H = 4,
+  PITA_ST_G2 = 5, PITA_ST_GAMMA = 6, PITA_ST_DT = 7, PITA_ST_NOISE_SCALE = 8 /* scale*g(t) */,
+  PITA_ST_SQRT_DT = 9, PITA_ST_BETA = 10
+};
+/* noise: nullable device [n_steps, B, D] standard normals (parity mode).  When NULL the kernel
+ * draws Philox4x32-10 normals keyed by (seed, walker_offset + walker, step0 + step, particle)
+ * so results do not depend on how walkers are sharded over GPUs.
+ * drift_out: nullable device [B, D]; receives drift_X of the LAST step of the launch. */
+int pita_egnn_sampler_run(pita_egnn_t* net, float* x, int64_t B, const float* step_tab,
+                          int n_steps, const float* noise, uint64_t seed, uint64_t walker_offset,
+                          int64_t step0, int remove_mean, float* drift_out, void* stream);
+
+/* ---------------------------------------------------------------- MLP backbone (K6)
+ * replaces MyMLP.forward (mlp.py:244-267) / MyMLPTemperature.forward (:501-524) incl. the
+ * sinusoidal embeddings (:11-24) and residual GELU blocks (:100-118). */
+typedef struct pita_mlp pita_mlp_t;
+typedef struct {
+  int input_dim;       /* number of coordinates (each embedded with scale 25) */
+  int out_dim;
+  int hidden_size;     /* multiple of 32; == emb_size in every reference config */
+  int hidden_layers;
+  int emb_size;        /* sinusoidal embedding size (even) */
+  int temperature_conditioned; /* MyMLPTemperature: extra beta embedding */
+} pita_mlp_config;
+/* weights: HOST pointer, reference state_dict order: joint_mlp.0.{weight,bias},
+ * joint_mlp.{1..L}.ff.{weight,bias}, joint_mlp.{L+1}.{weight,bias}.
+ * freqs: HOST pointer to the emb_size/2 sinusoidal frequencies exp(-ln(1e4)/(half-1) * k) as the
+ * caller's framework computes them in fp32 (mlp.py:20-21) -- passed in rather than recomputed so
+ * that the angles are bit-identical to the reference's. */
+int pita_mlp_create(pita_mlp_t** out, const pita_mlp_config* cfg, const float* weights,
+                    int64_t n_weights, const float* freqs);
+int pita_mlp_destroy(pita_mlp_t* net);
+int64_t pita_mlp_num_weights(const pita_mlp_config* cfg);
+int pita_mlp_forward(pita_mlp_t* net, const float* t, const float* x, const float* beta /*nullable*/,
+                     float* out, int64_t B, void* stream);
+
+/* ---------------------------------------------------------------- elementwise sampler pieces
+ * K8: x <- x + drift*dt + (noise_scale*xi)*sqrt_dt, then optional per-walker mean removal
+ * (sde_integration.py:347-349,148; data_utils.py:4-26).  noise nullable -> Philox as above. */
+int pita_em_step(float* x, const float* drift, const float* noise, int64_t B, int n_particles,
+                 int n_dim, float dt, float noise_scale, float sqrt_dt, uint64_t seed,
+                 uint64_t walker_offset, int64_t step, int remove_mean, void* stream);
+/* K9: MeanFreePrior.sample (base_prior.py:77-83): x = scale * N(0,1) minus particle mean.
+ * noise nullable -> Philox keyed (seed, walker_offset + walker, step = -1). */
+int pita_prior_sample(float* x, const float* noise, int64_t B, int n_particles, int n_dim,
+                      float scale, uint64_t seed, uint64_t walker_offset, int mean_free,
+                      void* stream);
+/* data_utils.remove_mean in place */
+int pita_remove_mean(float* x, int64_t B, int n_particles, int n_dim, void* stream);
+/* standard normals [B, D] from the library's Philox stream (the generator used when noise==NULL) */
+int pita_fill_normal(float* out, int64_t B, int n_particles, int n_dim, uint64_t seed,
+                     uint64_t walker_offset, int64_t step, void* stream);
+
+/* ---------------------------------------------------------------- resampling (K10, K11)
+ * K10 systematic resampling, replaces sample_cat_sys (utils.py:111-120): weights =
+ * clip(softmax(logits),1e-6,1) (not renormalised), inclusive fp32 cumsum, u_k = (u0 + k/B) mod 1
+ * in fp64, ids = digitize(u, bins, right=True) clamped to B-1.
+ * workspace: device scratch of at least pita_resample_workspace_bytes(B) bytes. */
+size_t pita_resample_workspace_bytes(int64_t B);
+int pita_systematic_resample(const float* logits, int64_t B, double u0, int64_t* ids,
+                             void* workspace, void* stream);
+/* out[k, :] = src[ids[k], :] */
+int pita_gather_rows(const float* src, const int64_t* ids, float* out, int64_t B, int D,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PITA_HIP_H */

@@ -1,0 +1,116 @@
+"""ctypes binding of libpita_hip.so (include/pita_hip.h).
+
+The library is the product: there is NO CPU / PyTorch fallback.  If the shared object is
+missing or a call fails this module raises; nothing silently degrades.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpita_hip.so")
+
+STEP_STRIDE = 16
+ST_CS, ST_CIN, ST_COUT, ST_CNOISE, ST_H, ST_G2, ST_GAMMA, ST_DT, ST_NOISE_SCALE, ST_SQRT_DT, ST_BETA = range(11)
+
+
+class PitaHipError(RuntimeError):
+    pass
+
+
+class EgnnConfig(ctypes.Structure):
+    _fields_ = [("n_particles", c_int), ("n_dim", c_int), ("hidden_nf", c_int), ("n_layers", c_int),
+                ("in_node_nf", c_int), ("attention", c_int), ("tanh", c_int), ("coords_range", c_float),
+                ("feature_layout", c_int)]
+
+
+class MlpConfig(ctypes.Structure):
+    _fields_ = [("input_dim", c_int), ("out_dim", c_int), ("hidden_size", c_int), ("hidden_layers", c_int),
+                ("emb_size", c_int), ("temperature_conditioned", c_int)]
+
+
+_PROTOS = {
+    "pita_abi_version": (c_int, []),
+    "pita_last_error": (c_int, [c_char_p, c_size_t]),
+    "pita_device_count": (c_int, []),
+    "pita_lj_logp_force": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_float, c_float,
+                                   c_float, c_float, c_float, c_void_p]),
+    "pita_dw_logp_force": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_float, c_float,
+                                   c_float, c_float, c_void_p]),
+    "pita_gmm_logp_force": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_float,
+                                    c_void_p]),
+    "pita_egnn_create": (c_int, [POINTER(c_void_p), POINTER(EgnnConfig), c_void_p, c_int64]),
+    "pita_egnn_destroy": (c_int, [c_void_p]),
+    "pita_egnn_num_weights": (c_int64, [POINTER(EgnnConfig)]),
+    "pita_egnn_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "pita_egnn_edm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "pita_egnn_sampler_run": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_uint64, c_uint64,
+                                      c_int64, c_int, c_void_p, c_void_p]),
+    "pita_mlp_create": (c_int, [POINTER(c_void_p), POINTER(MlpConfig), c_void_p, c_int64, c_void_p]),
+    "pita_mlp_destroy": (c_int, [c_void_p]),
+    "pita_mlp_num_weights": (c_int64, [POINTER(MlpConfig)]),
+    "pita_mlp_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "pita_em_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_float, c_float, c_uint64,
+                             c_uint64, c_int64, c_int, c_void_p]),
+    "pita_prior_sample": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_uint64, c_uint64, c_int,
+                                  c_void_p]),
+    "pita_remove_mean": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "pita_fill_normal": (c_int, [c_void_p, c_int64, c_int, c_int, c_uint64, c_uint64, c_int64, c_void_p]),
+    "pita_resample_workspace_bytes": (c_size_t, [c_int64]),
+    "pita_systematic_resample": (c_int, [c_void_p, c_int64, c_double, c_void_p, c_void_p, c_void_p]),
+    "pita_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+}
+
+EXPORTS = tuple(_PROTOS)
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raises PitaHipError if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PitaHipError(
+                f"{LIB_PATH} not found: build it with `python -m pita_amd.build` (hipcc --offload-arch=gfx950). "
+                "pita_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if L.pita_abi_version() != 1:
+            raise PitaHipError("libpita_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    buf = ctypes.create_string_buffer(512)
+    lib().pita_last_error(buf, 512)
+    return buf.value.decode()
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        raise PitaHipError(f"{what or 'libpita_hip'} failed (code {rc}): {last_error()}")
+
+
+def stream_ptr(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def dev_tensor(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    """Validate a device tensor argument: HIP device, expected dtype, contiguous (copy if needed)."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise PitaHipError(f"{name}: tensor is on {t.device}; pita_amd runs on the GPU only (no CPU fallback)")
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.detach().contiguous()
+
+
+def ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()

@@ -1,0 +1,645 @@
+// EGNN score network + fused Euler-Maruyama sampler step for gfx950 (MI355X).
+//
+// Replaces (reference paths relative to /root/reference/pita/src/models/components/):
+//   egnn_temp_conditioned.py:56-93   EGNN_dynamics.forward  (egnn.py:50-80 without beta)
+//   egnn_temp_conditioned.py:172-194 EGNN.forward
+//   egnn_temp_conditioned.py:321-356 E_GCL.forward / edge_model :265 / coord_model :294 /
+//                                    node_model :281 / coord2radial :348
+//   score_net.py:13-43               ScoreNet.forward / denoiser (EDM preconditioning)
+//   sdes.py:117-128,245-251          VEReverseSDE.f_not_debiased / diffusion
+//   sde_integration.py:299-351,148   euler_maruyama_step + remove_mean
+//
+// Mapping to the hardware (one wavefront = one independent walker group, no barriers):
+//   * a wave owns G walkers = G*N graph nodes = "columns"; columns are packed densely into NT
+//     tiles of 32.  Lane l works on column (l & 31) of the current tile and holds 16 of the 32
+//     hidden features of that column: feature kfeat(r,hh) = (r&3) + 8(r>>2) + 4hh, hh = l>>5.
+//     This is exactly the C/D layout of v_mfma_f32_32x32x2_f32, and -- with the weight
+//     fragment W[out = l&31][in = kfeat(r,hh)] as the A operand -- also its B layout, so every
+//     32x32 dense layer is a chain of 16 MFMAs whose result feeds the next layer's MFMA with no
+//     data movement at all (exact fp32: the f32 MFMA is a k-ordered fmaf chain).
+//   * the directed edges (i -> j) of the fully connected graph are enumerated as
+//     j = (i + dd) mod N, dd = 1..N-1: for a fixed dd every lane (= node i) processes ONE of its
+//     own outgoing edges, so the per-node sums over j (message aggregation, coordinate update)
+//     are plain in-register accumulations over the dd loop -- no scatter, no atomics, no
+//     cross-lane reduction, and a deterministic summation order.
+//   * the first edge-MLP layer is split algebraically: W1 [h_i,h_j,r,e] = Wa h_i + Wb h_j +
+//     w_r r + w_e e.  Wa h_i, Wb h_j are per-node GEMMs (2 MFMA chains per tile per layer); the
+//     partner term Wb h_j and the partner coordinates are gathered from a per-wave LDS table
+//     (row stride 36 floats -> conflict-free ds_read_b128 for consecutive columns).
+//   * walkers stay in registers across all SDE steps of a launch (fused sampler mode): HBM
+//     traffic per walker-step is ~0 and there is no per-step tail/launch cost.
+//   * the last layer's node update and the embedding_out head are dead in the reference
+//     (egnn_temp_conditioned.py:80,189: h_final is discarded) and are skipped.
+#include "common.h"
+
+namespace pita {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int EH = 32;       // hidden_nf
+constexpr int PBS = 36;      // LDS row stride (floats) of the partner table
+constexpr int MAT_F = 1024;  // floats per packed 32x32 matrix
+enum { M_WA = 0, M_WB, M_W2, M_WC1, M_WN1A, M_WN1B, M_WN2, M_COUNT };
+enum { V_WRE = 0 /* 64 floats: w_r[out] | w_e[out], natural order */, V_B1 = 2, V_B2, V_WATT, V_BC1, V_WC2, V_BN1,
+       V_BN2, V_COUNT };
+constexpr int VEC_EMB_F = 96;                    // emb_w0, emb_w1, emb_b
+constexpr int VEC_LAYER_F = V_COUNT * EH + 4;    // vectors (fragment order unless noted) + b_att (+pad)
+
+struct EgnnParams {
+  const float* mats;  // [L][M_COUNT][4][64][4]
+  const float* vecs;  // [VEC_EMB_F + L*VEC_LAYER_F]
+  int n_layers, in_nf, attention, tanh_on, feature_layout;
+  float coord_scale;  // coords_range / n_layers
+  int mode;           // 0 forward, 1 denoiser, 2 score, 3 fused sampler steps
+  long long B;
+  // modes 0-2
+  const float* x_in;
+  const float* t;     // mode 0: backbone time input (c_noise); modes 1,2: h = sigma^2
+  const float* beta;  // nullable
+  float* out;
+  // mode 3
+  float* x;
+  const float* step_tab;
+  int n_steps;
+  const float* noise;
+  unsigned long long seed, walker_offset;
+  long long step0;
+  int remove_mean;
+  float* drift_out;
+};
+
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS operations of one wave execute in order; this only stops the compiler from moving
+  // LDS accesses across the hand-off and drains outstanding reads.
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+__device__ __forceinline__ void load_frag(const float* __restrict__ pack, int lane, float (&wf)[16]) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(pack) + lane;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 v = p[q * 64];
+    wf[4 * q + 0] = v.x; wf[4 * q + 1] = v.y; wf[4 * q + 2] = v.z; wf[4 * q + 3] = v.w;
+  }
+}
+
+__device__ __forceinline__ f32x16 lds_vec16(const float* v) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(v);
+  f32x4 a = p[0], b = p[1], c = p[2], d = p[3];
+  f32x16 r;
+  r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w;
+  r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+  r[8] = c.x; r[9] = c.y; r[10] = c.z; r[11] = c.w;
+  r[12] = d.x; r[13] = d.y; r[14] = d.z; r[15] = d.w;
+  return r;
+}
+
+// out[o][col] = acc[o][col] + sum_k W[o][k] in[k][col]; 16 chained v_mfma_f32_32x32x2_f32
+__device__ __forceinline__ f32x16 gemm32(const float (&wf)[16], const f32x16& in, f32x16 acc) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[r], in[r], acc, 0, 0, 0);
+  return acc;
+}
+
+__device__ __forceinline__ float xhalf_sum(float v) {
+  // add the value held by the partner lane (l ^ 32): the other 16 features of the same column
+  return v + __shfl_xor(v, 32, 64);
+}
+
+template <int N, int DIM, int G, int WAVES>
+struct EgnnCfg {
+  static constexpr int NCOL = G * N;
+  static constexpr int NT = (NCOL + 31) / 32;
+  static constexpr int NCOLP = NT * 32;
+  static constexpr int PB_F = NCOLP * PBS;
+  static constexpr int POS_F = NCOLP * DIM;
+  static constexpr int WAVE_F = PB_F + 3 * POS_F;  // partner table, pos[2], pos0
+  static __host__ __device__ constexpr int vec_f(int L) { return ((VEC_EMB_F + L * VEC_LAYER_F) + 3) & ~3; }
+  static __host__ __device__ constexpr size_t lds_bytes(int L) {
+    return sizeof(float) * (size_t)(vec_f(L) + WAVES * WAVE_F);
+  }
+};
+
+template <int N, int DIM, int G, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
+  using C = EgnnCfg<N, DIM, G, WAVES>;
+  constexpr int NT = C::NT;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int L = p.n_layers;
+  const int vec_f = C::vec_f(L);
+  for (int i = threadIdx.x; i < VEC_EMB_F + L * VEC_LAYER_F; i += WAVES * 64) lds[i] = p.vecs[i];
+  __syncthreads();  // the only workgroup barrier: weight vectors are shared by the block's waves
+
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int cl = lane & 31;
+  const int hh = lane >> 5;
+  float* PB = lds + vec_f + wave * C::WAVE_F;
+  float* posbuf0 = PB + C::PB_F;
+  float* posbuf1 = posbuf0 + C::POS_F;
+  float* pos0 = posbuf1 + C::POS_F;
+  const float* vemb = lds;
+
+  const long long ngroups = (p.B + G - 1) / G;
+  for (long long grp = (long long)blockIdx.x * WAVES + wave; grp < ngroups; grp += (long long)gridDim.x * WAVES) {
+    const long long walker0 = grp * G;
+    // ---- per-column bookkeeping
+    int col[NT], nodei[NT];
+    bool valid[NT];
+    long long wid[NT];
+    float xcur[NT][DIM];
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+      col[T] = T * 32 + cl;
+      int w = col[T] / N;
+      nodei[T] = col[T] - w * N;
+      wid[T] = walker0 + w;
+      valid[T] = (col[T] < C::NCOL) && (wid[T] < p.B);
+      if (!valid[T]) wid[T] = p.B - 1;  // clamp for safe (unused) parameter loads
+      const float* src = (p.mode == 3 ? p.x : p.x_in);
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) xcur[T][k] = valid[T] ? src[(walker0 * N + col[T]) * DIM + k] : 0.0f;
+    }
+
+    const int nsteps = (p.mode == 3) ? p.n_steps : 1;
+    for (int step = 0; step < nsteps; ++step) {
+      // ---- per-column scalars of this evaluation
+      float c_s[NT], c_in[NT], c_out[NT], tfeat[NT], hval[NT], bfeat[NT];
+      float g2 = 0.f, gamma = 0.f, dt = 0.f, noise_scale = 0.f, sqrt_dt = 0.f;
+      if (p.mode == 3) {
+        const float* st = p.step_tab + (size_t)step * PITA_STEP_STRIDE;
+#pragma unroll
+        for (int T = 0; T < NT; ++T) {
+          c_s[T] = st[PITA_ST_CS]; c_in[T] = st[PITA_ST_CIN]; c_out[T] = st[PITA_ST_COUT];
+          tfeat[T] = st[PITA_ST_CNOISE]; hval[T] = st[PITA_ST_H]; bfeat[T] = st[PITA_ST_BETA];
+        }
+        g2 = st[PITA_ST_G2]; gamma = st[PITA_ST_GAMMA]; dt = st[PITA_ST_DT];
+        noise_scale = st[PITA_ST_NOISE_SCALE]; sqrt_dt = st[PITA_ST_SQRT_DT];
+      } else {
+#pragma unroll
+        for (int T = 0; T < NT; ++T) {
+          float tv = p.t[wid[T]];
+          bfeat[T] = p.beta ? p.beta[wid[T]] : 0.0f;
+          if (p.mode == 0) {
+            c_s[T] = 0.f; c_in[T] = 1.f; c_out[T] = 1.f; tfeat[T] = tv; hval[T] = 1.f;
+          } else {  // score_net.py:26-29
+            hval[T] = tv;
+            c_s[T] = 1.0f / (1.0f + tv);
+            c_in[T] = 1.0f / sqrtf(1.0f + tv);
+            c_out[T] = sqrtf(tv) * c_in[T];
+            tfeat[T] = 0.125f * logf(tv);
+          }
+        }
+      }
+
+      // ---- scaled input coordinates -> registers + LDS (pos0 = input geometry, frozen edge_attr)
+      float posi[NT][DIM], p0i[NT][DIM];
+      f32x16 hfeat[NT];
+#pragma unroll
+      for (int T = 0; T < NT; ++T) {
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          posi[T][k] = (p.mode == 0) ? xcur[T][k] : c_in[T] * xcur[T][k];
+          p0i[T][k] = posi[T][k];
+          if (hh == 0) {
+            pos0[col[T] * DIM + k] = posi[T][k];
+            posbuf0[col[T] * DIM + k] = posi[T][k];
+          }
+        }
+        // initial node features (egnn_temp_conditioned.py:63-78) and embedding (:179)
+        float a0, a1;
+        if (p.in_nf == 1) {
+          a0 = tfeat[T]; a1 = 0.f;
+        } else if (p.feature_layout == 0) {  // quirk Q1: rows of reshape([t]*N + [beta]*N, (N,2))
+          a0 = (2 * nodei[T] < N) ? tfeat[T] : bfeat[T];
+          a1 = (2 * nodei[T] + 1 < N) ? tfeat[T] : bfeat[T];
+        } else {
+          a0 = tfeat[T]; a1 = bfeat[T];
+        }
+        f32x16 w0 = lds_vec16(vemb + hh * 16), w1 = lds_vec16(vemb + 32 + hh * 16), eb = lds_vec16(vemb + 64 + hh * 16);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hfeat[T][r] = fmaf(w0[r], a0, fmaf(w1[r], a1, eb[r]));
+      }
+      wave_lds_fence();
+
+      float* poscur = posbuf0;
+      float* posnext = posbuf1;
+      for (int l = 0; l < L; ++l) {
+        const float* mats = p.mats + (size_t)l * M_COUNT * MAT_F;
+        const float* vl = lds + VEC_EMB_F + l * VEC_LAYER_F + hh * 16;
+        const bool last = (l == L - 1);
+        // ---- partner table PB[col] = Wb h_col
+        {
+          float wb[16];
+          load_frag(mats + M_WB * MAT_F, lane, wb);
+#pragma unroll
+          for (int T = 0; T < NT; ++T) {
+            f32x16 z = {0};
+            f32x16 pb = gemm32(wb, hfeat[T], z);
+            f32x4* dst = reinterpret_cast<f32x4*>(PB + col[T] * PBS + hh * 16);
+            dst[0] = f32x4{pb[0], pb[1], pb[2], pb[3]};
+            dst[1] = f32x4{pb[4], pb[5], pb[6], pb[7]};
+            dst[2] = f32x4{pb[8], pb[9], pb[10], pb[11]};
+            dst[3] = f32x4{pb[12], pb[13], pb[14], pb[15]};
+          }
+        }
+        wave_lds_fence();
+
+        float w2f[16], wc1f[16];
+        load_frag(mats + M_W2 * MAT_F, lane, w2f);
+        load_frag(mats + M_WC1 * MAT_F, lane, wc1f);
+        // A operand of the extra k-step that adds w_r*radial + w_e*edge_attr: A[out][k] = (w_r | w_e)
+        const float a_re = lds[VEC_EMB_F + l * VEC_LAYER_F + V_WRE * EH + lane];
+        const float b_att = lds[VEC_EMB_F + l * VEC_LAYER_F + V_COUNT * EH];
+
+#pragma unroll
+        for (int T = 0; T < NT; ++T) {
+          // own first-layer term  Ai = Wa h_i + b1
+          f32x16 Ai;
+          {
+            float wa[16];
+            load_frag(mats + M_WA * MAT_F, lane, wa);
+            Ai = gemm32(wa, hfeat[T], lds_vec16(vl + V_B1 * EH));
+          }
+          f32x16 agg = {0};
+          float xacc[DIM];
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) xacc[k] = 0.f;
+          const int cbase = col[T] - nodei[T];
+
+          for (int dd = 1; dd < N; ++dd) {
+            asm volatile("" ::: "memory");  // keep the per-edge LDS vector loads inside the loop (VGPR budget)
+            int j = nodei[T] + dd;
+            j = (j >= N) ? j - N : j;
+            const int cj = (col[T] < C::NCOL) ? cbase + j : col[T];
+            // geometry (coord2radial :348-356; edge_attr :79)
+            float df[DIM], radial = 0.f, ea = 0.f;
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+              df[k] = posi[T][k] - poscur[cj * DIM + k];
+              radial = fmaf(df[k], df[k], radial);
+              const float e0 = p0i[T][k] - pos0[cj * DIM + k];
+              ea = fmaf(e0, e0, ea);
+            }
+            // edge MLP layer 1 (:232-237,:270-271): Wa h_i + Wb h_j + b1, then one k-step [w_r|w_e]·[radial;ea]
+            f32x16 m = Ai + lds_vec16(PB + cj * PBS + hh * 16);
+            m = __builtin_amdgcn_mfma_f32_32x32x2f32(a_re, hh ? ea : radial, m, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m[r] = fast_silu(m[r]);
+            m = gemm32(w2f, m, lds_vec16(vl + V_B2 * EH));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m[r] = fast_silu(m[r]);
+            if (p.attention) {  // :259-260,:273-275
+              const f32x16 v_watt = lds_vec16(vl + V_WATT * EH);
+              float part = 0.f;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) part = fmaf(v_watt[r], m[r], part);
+              const float att = fast_sigmoid(xhalf_sum(part) + b_att);
+#pragma unroll
+              for (int r = 0; r < 16; ++r) m[r] *= att;
+            }
+            if (!last) agg += m;  // node_model aggregation (:284)
+            // coordinate head (:245-256,:297-298)
+            f32x16 c1 = gemm32(wc1f, m, lds_vec16(vl + V_BC1 * EH));
+            const f32x16 v_wc2 = lds_vec16(vl + V_WC2 * EH);
+            float part = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part = fmaf(v_wc2[r], fast_silu(c1[r]), part);
+            float cs = xhalf_sum(part);
+            if (p.tanh_on) cs = accurate_tanh(cs) * p.coord_scale;
+            const float nrm = sqrtf(radial + 1e-8f) + 1.0f;
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) xacc[k] = fmaf(df[k] / nrm, cs, xacc[k]);
+          }
+          // coordinate update (:306,:318): other tiles still read the old coordinates
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) {
+            posi[T][k] += xacc[k];
+            if (hh == 0) posnext[col[T] * DIM + k] = posi[T][k];
+          }
+          if (!last) {  // node model (:239-243,:284-291), recurrent
+            float wn[16];
+            load_frag(mats + M_WN1A * MAT_F, lane, wn);
+            f32x16 n1 = gemm32(wn, hfeat[T], lds_vec16(vl + V_BN1 * EH));
+            load_frag(mats + M_WN1B * MAT_F, lane, wn);
+            n1 = gemm32(wn, agg, n1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) n1[r] = fast_silu(n1[r]);
+            load_frag(mats + M_WN2 * MAT_F, lane, wn);
+            f32x16 o = gemm32(wn, n1, lds_vec16(vl + V_BN2 * EH));
+            hfeat[T] += o;
+          }
+        }
+        wave_lds_fence();
+        float* tmp = poscur; poscur = posnext; posnext = tmp;
+      }
+
+      // ---- vel = x_final - x, mean-free over the walker's particles (:81-84)
+      float* scr = PB;  // partner table is free now
+      float F[NT][DIM];
+#pragma unroll
+      for (int T = 0; T < NT; ++T)
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          F[T][k] = posi[T][k] - p0i[T][k];
+          if (hh == 0) scr[col[T] * DIM + k] = F[T][k];
+        }
+      wave_lds_fence();
+#pragma unroll
+      for (int T = 0; T < NT; ++T) {
+        const int cb = (col[T] < C::NCOL) ? col[T] - nodei[T] : 0;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          float s = 0.f;
+          for (int q = 0; q < N; ++q) s += scr[(cb + q) * DIM + k];
+          F[T][k] -= s / (float)N;
+        }
+      }
+      wave_lds_fence();
+
+      if (p.mode != 3) {
+#pragma unroll
+        for (int T = 0; T < NT; ++T)
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) {
+            float o = F[T][k];
+            if (p.mode >= 1) {
+              o = c_s[T] * xcur[T][k] + c_out[T] * F[T][k];           // denoiser (score_net.py:31-33)
+              if (p.mode == 2) o = (o - xcur[T][k]) / hval[T];        // score (:19)
+            }
+            if (valid[T] && hh == 0) p.out[(walker0 * N + col[T]) * DIM + k] = o;
+          }
+      } else {
+        // ---- reverse-SDE Euler-Maruyama update (sdes.py:119-122,250; sde_integration.py:347-348)
+        float xn[NT][DIM];
+#pragma unroll
+        for (int T = 0; T < NT; ++T) {
+          float xi[4] = {0.f, 0.f, 0.f, 0.f};
+          if (p.noise) {
+#pragma unroll
+            for (int k = 0; k < DIM; ++k)
+              xi[k] = valid[T] ? p.noise[((size_t)step * p.B * N + (size_t)(walker0 * N + col[T])) * DIM + k] : 0.f;
+          } else {
+            philox_normal4(p.seed, p.walker_offset + (unsigned long long)wid[T], p.step0 + step, (uint32_t)nodei[T], xi);
+          }
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) {
+            const float Dth = c_s[T] * xcur[T][k] + c_out[T] * F[T][k];
+            const float sc = (Dth - xcur[T][k]) / hval[T];
+            const float drift = gamma * (sc * g2);
+            if (p.drift_out && step == nsteps - 1 && valid[T] && hh == 0)
+              p.drift_out[(walker0 * N + col[T]) * DIM + k] = drift;
+            xn[T][k] = xcur[T][k] + (drift * dt + ((noise_scale * xi[k]) * sqrt_dt));
+            if (hh == 0) scr[col[T] * DIM + k] = xn[T][k];
+          }
+        }
+        if (p.remove_mean) {
+          wave_lds_fence();
+#pragma unroll
+          for (int T = 0; T < NT; ++T) {
+            const int cb = (col[T] < C::NCOL) ? col[T] - nodei[T] : 0;
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+              float s = 0.f;
+              for (int q = 0; q < N; ++q) s += scr[(cb + q) * DIM + k];
+              xn[T][k] -= s / (float)N;
+            }
+          }
+          wave_lds_fence();
+        }
+#pragma unroll
+        for (int T = 0; T < NT; ++T)
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) xcur[T][k] = xn[T][k];
+      }
+    }  // steps
+
+    if (p.mode == 3) {
+#pragma unroll
+      for (int T = 0; T < NT; ++T)
+#pragma unroll
+        for (int k = 0; k < DIM; ++k)
+          if (valid[T] && hh == 0) p.x[(walker0 * N + col[T]) * DIM + k] = xcur[T][k];
+    }
+    wave_lds_fence();
+  }
+}
+
+// ------------------------------------------------------------------------------------ host side
+
+struct EgnnShape {
+  int n, dim, G, waves;
+  void (*kernel)(EgnnParams);
+  size_t (*lds_bytes)(int);
+};
+
+template <int N, int DIM, int G, int WAVES>
+static size_t lds_bytes_of(int L) { return EgnnCfg<N, DIM, G, WAVES>::lds_bytes(L); }
+
+#define PITA_EGNN_SHAPE(N, DIM, G, WAVES) \
+  EgnnShape { N, DIM, G, WAVES, egnn_kernel<N, DIM, G, WAVES>, lds_bytes_of<N, DIM, G, WAVES> }
+
+// Instantiated (n_particles, n_dim) shapes: DW4, LJ13, alanine dipeptide (22 atoms), LJ55.
+static const EgnnShape kShapes[] = {
+    PITA_EGNN_SHAPE(4, 2, 8, 4),
+    PITA_EGNN_SHAPE(13, 3, 7, 4),
+    PITA_EGNN_SHAPE(22, 3, 4, 4),
+    PITA_EGNN_SHAPE(55, 3, 1, 4),
+};
+
+}  // namespace pita
+
+struct pita_egnn {
+  pita_egnn_config cfg;
+  float* d_mats = nullptr;
+  float* d_vecs = nullptr;
+  const pita::EgnnShape* shape = nullptr;
+  int n_cu = 256;
+};
+
+using namespace pita;
+
+extern "C" int64_t pita_egnn_num_weights(const pita_egnn_config* c) {
+  if (!c) return PITA_EINVAL;
+  const int64_t H = c->hidden_nf;
+  int64_t per_layer = (H * (2 * H + 2) + H) + (H * H + H) + (H * 2 * H + H) + (H * H + H) + (H * H + H) + H;
+  if (c->attention) per_layer += H + 1;
+  return (H * c->in_node_nf + H) + (c->in_node_nf * H + c->in_node_nf) + c->n_layers * per_layer;
+}
+
+static inline int kfeat(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, const float* w, int64_t n_weights) {
+  PITA_REQUIRE(out && cfg && w, "pita_egnn_create: null argument");
+  if (cfg->hidden_nf != EH)
+    return fail(PITA_EUNSUPPORTED, "pita_egnn_create: hidden_nf=%d (the HIP kernel implements 32)", cfg->hidden_nf);
+  PITA_REQUIRE(cfg->in_node_nf == 1 || cfg->in_node_nf == 2, "in_node_nf must be 1 or 2");
+  PITA_REQUIRE(cfg->n_layers >= 1 && cfg->n_layers <= 16, "n_layers out of range");
+  PITA_REQUIRE(n_weights == pita_egnn_num_weights(cfg), "pita_egnn_create: got %lld weights, expected %lld",
+               (long long)n_weights, (long long)pita_egnn_num_weights(cfg));
+  const EgnnShape* shape = nullptr;
+  for (const auto& s : kShapes)
+    if (s.n == cfg->n_particles && s.dim == cfg->n_dim) shape = &s;
+  if (!shape)
+    return fail(PITA_EUNSUPPORTED, "pita_egnn_create: no kernel instantiated for n_particles=%d n_dim=%d",
+                cfg->n_particles, cfg->n_dim);
+  const int H = EH, L = cfg->n_layers, nf = cfg->in_node_nf;
+  const size_t n_mats = (size_t)L * M_COUNT * MAT_F, n_vecs = VEC_EMB_F + (size_t)L * VEC_LAYER_F;
+  float* h_mats = new float[n_mats];
+  float* h_vecs = new float[n_vecs]();
+  // walk the state_dict order
+  const float* q = w;
+  const float* emb_w = q; q += H * nf;
+  const float* emb_b = q; q += H;
+  q += nf * H + nf;  // embedding_out: dead (h_final is discarded, egnn_temp_conditioned.py:80)
+  for (int hh = 0; hh < 2; ++hh)
+    for (int r = 0; r < 16; ++r) {
+      const int f = kfeat(r, hh);
+      h_vecs[hh * 16 + r] = emb_w[f * nf + 0];
+      h_vecs[32 + hh * 16 + r] = (nf == 2) ? emb_w[f * nf + 1] : 0.f;
+      h_vecs[64 + hh * 16 + r] = emb_b[f];
+    }
+  auto pack_mat = [&](float* dst, const float* M, int ld, int col0) {
+    for (int qd = 0; qd < 4; ++qd)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int s = 0; s < 4; ++s)
+          dst[(qd * 64 + lane) * 4 + s] = M[(lane & 31) * ld + col0 + kfeat(4 * qd + s, lane >> 5)];
+  };
+  auto pack_vec = [&](float* dst, const float* v, int stride) {
+    for (int hh = 0; hh < 2; ++hh)
+      for (int r = 0; r < 16; ++r) dst[hh * 16 + r] = v[kfeat(r, hh) * stride];
+  };
+  for (int l = 0; l < L; ++l) {
+    float* mats = h_mats + (size_t)l * M_COUNT * MAT_F;
+    float* vecs = h_vecs + VEC_EMB_F + (size_t)l * VEC_LAYER_F;
+    const float* e0w = q; q += H * (2 * H + 2);
+    const float* e0b = q; q += H;
+    const float* e2w = q; q += H * H;
+    const float* e2b = q; q += H;
+    const float* n0w = q; q += H * 2 * H;
+    const float* n0b = q; q += H;
+    const float* n2w = q; q += H * H;
+    const float* n2b = q; q += H;
+    const float* c0w = q; q += H * H;
+    const float* c0b = q; q += H;
+    const float* c2w = q; q += H;
+    const float* aw = nullptr; const float* ab = nullptr;
+    if (cfg->attention) { aw = q; q += H; ab = q; q += 1; }
+    pack_mat(mats + M_WA * MAT_F, e0w, 2 * H + 2, 0);
+    pack_mat(mats + M_WB * MAT_F, e0w, 2 * H + 2, H);
+    pack_mat(mats + M_W2 * MAT_F, e2w, H, 0);
+    pack_mat(mats + M_WC1 * MAT_F, c0w, H, 0);
+    pack_mat(mats + M_WN1A * MAT_F, n0w, 2 * H, 0);
+    pack_mat(mats + M_WN1B * MAT_F, n0w, 2 * H, H);
+    pack_mat(mats + M_WN2 * MAT_F, n2w, H, 0);
+    for (int o = 0; o < H; ++o) {
+      vecs[V_WRE * EH + o] = e0w[o * (2 * H + 2) + 2 * H];          // w_r[out]  (k = 0: radial)
+      vecs[V_WRE * EH + H + o] = e0w[o * (2 * H + 2) + 2 * H + 1];  // w_e[out]  (k = 1: edge_attr)
+    }
+    pack_vec(vecs + V_B1 * EH, e0b, 1);
+    pack_vec(vecs + V_B2 * EH, e2b, 1);
+    if (aw) pack_vec(vecs + V_WATT * EH, aw, 1);
+    pack_vec(vecs + V_BC1 * EH, c0b, 1);
+    pack_vec(vecs + V_WC2 * EH, c2w, 1);
+    pack_vec(vecs + V_BN1 * EH, n0b, 1);
+    pack_vec(vecs + V_BN2 * EH, n2b, 1);
+    vecs[V_COUNT * EH] = ab ? ab[0] : 0.f;
+  }
+  pita_egnn* net = new pita_egnn();
+  net->cfg = *cfg;
+  net->shape = shape;
+  hipError_t e1 = hipMalloc(&net->d_mats, n_mats * sizeof(float));
+  hipError_t e2 = hipMalloc(&net->d_vecs, n_vecs * sizeof(float));
+  if (e1 == hipSuccess && e2 == hipSuccess) {
+    e1 = hipMemcpy(net->d_mats, h_mats, n_mats * sizeof(float), hipMemcpyHostToDevice);
+    e2 = hipMemcpy(net->d_vecs, h_vecs, n_vecs * sizeof(float), hipMemcpyHostToDevice);
+  }
+  delete[] h_mats;
+  delete[] h_vecs;
+  if (e1 != hipSuccess || e2 != hipSuccess) {
+    (void)hipFree(net->d_mats);
+    (void)hipFree(net->d_vecs);
+    delete net;
+    return fail(PITA_EHIP, "pita_egnn_create: device upload failed: %s",
+                hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+  }
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+    net->n_cu = prop.multiProcessorCount;
+  // opt in to the LDS the kernel needs (static limit is 64 KiB)
+  size_t lds = shape->lds_bytes(L);
+  hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(shape->kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e3 != hipSuccess) {
+    pita_egnn_destroy(net);
+    return fail(PITA_EHIP, "pita_egnn_create: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e3));
+  }
+  *out = net;
+  return PITA_OK;
+}
+
+extern "C" int pita_egnn_destroy(pita_egnn_t* net) {
+  if (!net) return PITA_OK;
+  (void)hipFree(net->d_mats);
+  (void)hipFree(net->d_vecs);
+  delete net;
+  return PITA_OK;
+}
+
+static int egnn_launch(pita_egnn_t* net, EgnnParams& p, void* stream) {
+  const EgnnShape* s = net->shape;
+  p.mats = net->d_mats;
+  p.vecs = net->d_vecs;
+  p.n_layers = net->cfg.n_layers;
+  p.in_nf = net->cfg.in_node_nf;
+  p.attention = net->cfg.attention;
+  p.tanh_on = net->cfg.tanh;
+  p.feature_layout = net->cfg.feature_layout;
+  p.coord_scale = net->cfg.coords_range / (float)net->cfg.n_layers;
+  if (p.B == 0) return PITA_OK;
+  const long long ngroups = (p.B + s->G - 1) / s->G;
+  const size_t lds = s->lds_bytes(p.n_layers);
+  const int blocks_per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
+  long long want = (ngroups + s->waves - 1) / s->waves;
+  long long cap = (long long)net->n_cu * blocks_per_cu;
+  // forward modes: one group per wave (plain grid); sampler mode: persistent grid-stride
+  unsigned grid = (unsigned)(want < cap ? want : cap);
+  if (p.mode != 3) grid = (unsigned)want;
+  hipLaunchKernelGGL(s->kernel, dim3(grid), dim3(s->waves * 64), lds, (hipStream_t)stream, p);
+  PITA_LAUNCH_CHECK();
+  return PITA_OK;
+}
+
+extern "C" int pita_egnn_forward(pita_egnn_t* net, const float* t, const float* x, const float* beta, float* out,
+                                 int64_t B, void* stream) {
+  PITA_REQUIRE(net && t && x && out && B >= 0, "pita_egnn_forward: null argument");
+  PITA_REQUIRE(beta || net->cfg.in_node_nf == 1, "pita_egnn_forward: beta required for in_node_nf=2");
+  EgnnParams p{};
+  p.mode = 0; p.B = B; p.x_in = x; p.t = t; p.beta = beta; p.out = out;
+  return egnn_launch(net, p, stream);
+}
+
+extern "C" int pita_egnn_edm(pita_egnn_t* net, int what, const float* h, const float* x, const float* beta, float* out,
+                             int64_t B, void* stream) {
+  PITA_REQUIRE(net && h && x && out && B >= 0, "pita_egnn_edm: null argument");
+  PITA_REQUIRE(what == 1 || what == 2, "pita_egnn_edm: what must be 1 (denoiser) or 2 (score)");
+  PITA_REQUIRE(beta || net->cfg.in_node_nf == 1, "pita_egnn_edm: beta required for in_node_nf=2");
+  EgnnParams p{};
+  p.mode = what; p.B = B; p.x_in = x; p.t = h; p.beta = beta; p.out = out;
+  return egnn_launch(net, p, stream);
+}
+
+extern "C" int pita_egnn_sampler_run(pita_egnn_t* net, float* x, int64_t B, const float* step_tab, int n_steps,
+                                     const float* noise, uint64_t seed, uint64_t walker_offset, int64_t step0,
+                                     int remove_mean, float* drift_out, void* stream) {
+  PITA_REQUIRE(net && x && step_tab && B >= 0 && n_steps >= 0, "pita_egnn_sampler_run: bad argument");
+  if (n_steps == 0) return PITA_OK;
+  EgnnParams p{};
+  p.mode = 3; p.B = B; p.x = x; p.step_tab = step_tab; p.n_steps = n_steps; p.noise = noise;
+  p.seed = seed; p.walker_offset = walker_offset; p.step0 = step0; p.remove_mean = remove_mean;
+  p.drift_out = drift_out;
+  return egnn_launch(net, p, stream);
+}

@@ -1,0 +1,234 @@
+// Target Boltzmann log-densities and forces for gfx950.
+//
+// Replaces (paths relative to /root/reference/):
+//   pita/src/energies/lennardjones_energy.py:34-36,121-155,213-227  (+ bgflow distance_vectors /
+//       distances_from_vectors, an un-vendored dependency: r = sqrt(|dx|^2 + 1e-6), ordered pairs)
+//   pita/src/energies/gmm_energy.py:87-90 -> fab/fab/target_distributions/gmm.py:71-79,104
+//   DW4: bgflow.MultiDoubleWellPotential (not in the reference tree, see oracle header)
+//
+// Layout / mapping: x is the reference's [B, n*d] row-major tensor.  A 256-thread block
+// stages WB = floor(256/n) consecutive walkers (one contiguous, fully coalesced span of
+// WB*n*d floats) in LDS; thread (w,i) owns particle i of walker w and sweeps the partners j
+// from LDS (broadcast-friendly: the n lanes of a walker read the same address).  Forces are
+// written back through LDS so the global store is again one coalesced span.  Pair energies are
+// HBM-bound for LJ13/DW4 (316 / 68 algorithmic bytes per walker-eval).
+#include "common.h"
+
+namespace pita {
+
+enum { E_LJ = 0, E_DW = 1 };
+
+struct PairParams {
+  float inv_T, energy_factor, dist_eps, eps, rm2, osc_scale;  // LJ
+  float a, b, c, d0;                                          // DW
+};
+
+template <int DIM, int KIND>
+__global__ void __launch_bounds__(256) pair_energy_kernel(const float* __restrict__ x, float* __restrict__ logp,
+                                                          float* __restrict__ force, long long B, int n, int WB,
+                                                          PairParams p) {
+  extern __shared__ float sm[];
+  float* xs = sm;                   // [WB*n*DIM] coordinates, later reused for forces
+  float* es = sm + WB * n * DIM;    // [WB*n] per-particle energy partials
+  const int tid = threadIdx.x;
+  const long long nblk = (B + WB - 1) / WB;
+  for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const long long w0 = blk * WB;
+    const int nw = (int)((B - w0) < WB ? (B - w0) : WB);
+    const int nfl = nw * n * DIM;
+    const float* src = x + w0 * n * DIM;
+    for (int i = tid; i < nfl; i += 256) xs[i] = src[i];
+    __syncthreads();
+    const int w = tid / n, i = tid - w * n;
+    const bool act = w < nw;
+    float f[DIM], e = 0.f, xi[DIM], mean[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) { f[k] = 0.f; mean[k] = 0.f; xi[k] = 0.f; }
+    if (act) {
+      const float* xw = xs + w * n * DIM;
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) xi[k] = xw[i * DIM + k];
+      for (int j = 0; j < n; ++j) {
+        float d[DIM], r2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          const float xj = xw[j * DIM + k];
+          mean[k] += xj;
+          d[k] = xi[k] - xj;
+          r2 = fmaf(d[k], d[k], r2);
+        }
+        if (j == i) continue;
+        if (KIND == E_LJ) {
+          r2 += p.dist_eps;
+          const float inv = __builtin_amdgcn_rcpf(r2);
+          const float s2 = p.rm2 * inv, s6 = s2 * s2 * s2;
+          const float t6 = fmaf(s6, s6, -2.0f * s6);  // s^12 - 2 s^6
+          e = fmaf(p.eps, t6, e);
+          const float coef = p.eps * (12.0f * fmaf(-s6, s6, s6)) * inv;  // e'(r)/r = eps*12*(s^6 - s^12)/r^2
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) f[k] = fmaf(coef, d[k], f[k]);
+        } else {
+          const float dist = sqrtf(r2);
+          const float u = dist - p.d0, u2 = u * u;
+          e += fmaf(p.a * u2, u2, fmaf(p.b, u2, p.c));
+          const float coef = (u * fmaf(4.0f * p.a, u2, 2.0f * p.b)) / dist;
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) f[k] = fmaf(coef, d[k], f[k]);
+        }
+      }
+      if (KIND == E_LJ) {
+        // E = ef * sum_{i != j} lj + 0.5*osc*sum |x - mean|^2 ; each unordered pair appears twice
+        float osc = 0.f;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          const float c = xi[k] - mean[k] / (float)n;
+          osc += c * c;
+          f[k] = -p.inv_T * (2.0f * p.energy_factor * f[k] + p.osc_scale * c);
+        }
+        e = p.energy_factor * e + 0.5f * p.osc_scale * osc;
+      } else {
+        e *= 0.5f;  // unordered pairs once
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) f[k] = -p.inv_T * f[k];
+      }
+      es[w * n + i] = e;
+    }
+    __syncthreads();  // all reads of xs done; es complete
+    if (act) {
+      if (force) {
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) xs[(w * n + i) * DIM + k] = f[k];
+      }
+      if (i == 0) {
+        float s = 0.f;
+        for (int q = 0; q < n; ++q) s += es[w * n + q];
+        logp[w0 + w] = -s * p.inv_T;
+      }
+    }
+    __syncthreads();
+    if (force) {
+      float* dst = force + w0 * n * DIM;
+      for (int q = tid; q < nfl; q += 256) dst[q] = xs[q];
+    }
+    __syncthreads();
+  }
+}
+
+template <int KIND>
+static int launch_pair(const float* x, float* logp, float* force, int64_t B, int n, int d, const PairParams& p,
+                       void* stream) {
+  PITA_REQUIRE(B >= 0, "pair energy: negative batch");
+  if (B == 0) return PITA_OK;
+  PITA_REQUIRE(x && logp, "pair energy: null argument");
+  PITA_REQUIRE(n >= 2 && n <= 256, "pair energy: n_particles must be in [2,256]");
+  PITA_REQUIRE(d >= 1 && d <= 3, "pair energy: n_dim must be 1, 2 or 3");
+  if (B == 0) return PITA_OK;
+  const int WB = 256 / n;
+  const long long nblk = (B + WB - 1) / WB;
+  const unsigned grid = (unsigned)(nblk < 256LL * 16 ? nblk : 256LL * 16);
+  const size_t lds = sizeof(float) * (size_t)(WB * n * d + WB * n);
+  hipStream_t s = (hipStream_t)stream;
+  switch (d) {
+    case 1: hipLaunchKernelGGL((pair_energy_kernel<1, KIND>), dim3(grid), dim3(256), lds, s, x, logp, force, B, n, WB, p); break;
+    case 2: hipLaunchKernelGGL((pair_energy_kernel<2, KIND>), dim3(grid), dim3(256), lds, s, x, logp, force, B, n, WB, p); break;
+    default: hipLaunchKernelGGL((pair_energy_kernel<3, KIND>), dim3(grid), dim3(256), lds, s, x, logp, force, B, n, WB, p); break;
+  }
+  PITA_LAUNCH_CHECK();
+  return PITA_OK;
+}
+
+// ---------------------------------------------------------------------------- GMM
+template <int DIM>
+__global__ void __launch_bounds__(256) gmm_kernel(const float* __restrict__ x, float* __restrict__ logp,
+                                                  float* __restrict__ force, long long B, const float* __restrict__ means,
+                                                  const float* __restrict__ scales, int K, float inv_T) {
+  extern __shared__ float sm[];
+  float* mu = sm;                 // [K*DIM]
+  float* isg = sm + K * DIM;      // [K*DIM] 1/scale
+  float* lc = sm + 2 * K * DIM;   // [K] -sum log scale - 0.5 dim log 2pi
+  for (int k = threadIdx.x; k < K; k += 256) {
+    float ls = 0.f;
+    for (int d = 0; d < DIM; ++d) {
+      mu[k * DIM + d] = means[k * DIM + d];
+      isg[k * DIM + d] = 1.0f / scales[k * DIM + d];
+      ls += logf(scales[k * DIM + d]);
+    }
+    lc[k] = -ls - 0.5f * DIM * 1.8378770664093453f;
+  }
+  __syncthreads();
+  for (long long b = (long long)blockIdx.x * 256 + threadIdx.x; b < B; b += (long long)gridDim.x * 256) {
+    float xv[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) xv[d] = x[b * DIM + d];
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) {
+      float m = 0.f;
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) { const float z = (xv[d] - mu[k * DIM + d]) * isg[k * DIM + d]; m += z * z; }
+      mx = fmaxf(mx, lc[k] - 0.5f * m);
+    }
+    float s = 0.f, g[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) g[d] = 0.f;
+    for (int k = 0; k < K; ++k) {
+      float m = 0.f, z[DIM];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) { z[d] = (xv[d] - mu[k * DIM + d]) * isg[k * DIM + d]; m += z[d] * z[d]; }
+      const float w = expf((lc[k] - 0.5f * m) - mx);
+      s += w;
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) g[d] -= w * z[d] * isg[k * DIM + d];
+    }
+    logp[b] = ((mx + logf(s)) - logf((float)K)) * inv_T;
+    if (force) {
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) force[b * DIM + d] = (g[d] / s) * inv_T;
+    }
+  }
+}
+
+}  // namespace pita
+
+using namespace pita;
+
+extern "C" int pita_lj_logp_force(const float* x, float* logp, float* force, int64_t B, int n, int d, float temperature,
+                                  float energy_factor, float dist_eps, float eps, float rm, float osc_scale,
+                                  void* stream) {
+  PITA_REQUIRE(temperature > 0.f, "pita_lj_logp_force: temperature must be > 0");
+  PairParams p{};
+  p.inv_T = 1.0f / temperature; p.energy_factor = energy_factor; p.dist_eps = dist_eps; p.eps = eps;
+  p.rm2 = rm * rm; p.osc_scale = osc_scale;
+  return launch_pair<E_LJ>(x, logp, force, B, n, d, p, stream);
+}
+
+extern "C" int pita_dw_logp_force(const float* x, float* logp, float* force, int64_t B, int n, int d, float temperature,
+                                  float a, float b, float c, float d0, void* stream) {
+  PITA_REQUIRE(temperature > 0.f, "pita_dw_logp_force: temperature must be > 0");
+  PairParams p{};
+  p.inv_T = 1.0f / temperature; p.a = a; p.b = b; p.c = c; p.d0 = d0;
+  return launch_pair<E_DW>(x, logp, force, B, n, d, p, stream);
+}
+
+extern "C" int pita_gmm_logp_force(const float* x, float* logp, float* force, int64_t B, int dim, const float* means,
+                                   const float* scales, int K, float temperature, void* stream) {
+  PITA_REQUIRE(B >= 0, "pita_gmm_logp_force: negative batch");
+  if (B == 0) return PITA_OK;
+  PITA_REQUIRE(x && logp && means && scales, "pita_gmm_logp_force: null argument");
+  PITA_REQUIRE(K >= 1 && K <= 2048, "pita_gmm_logp_force: K out of range");
+  PITA_REQUIRE(temperature > 0.f, "pita_gmm_logp_force: temperature must be > 0");
+  if (dim < 1 || dim > 4) return fail(PITA_EUNSUPPORTED, "pita_gmm_logp_force: dim=%d (1..4 implemented)", dim);
+  if (B == 0) return PITA_OK;
+  const long long nb = (B + 255) / 256;
+  const unsigned grid = (unsigned)(nb < 4096 ? nb : 4096);
+  const size_t lds = sizeof(float) * (size_t)(2 * K * dim + K);
+  const float inv_T = 1.0f / temperature;
+  hipStream_t s = (hipStream_t)stream;
+  switch (dim) {
+    case 1: hipLaunchKernelGGL(gmm_kernel<1>, dim3(grid), dim3(256), lds, s, x, logp, force, B, means, scales, K, inv_T); break;
+    case 2: hipLaunchKernelGGL(gmm_kernel<2>, dim3(grid), dim3(256), lds, s, x, logp, force, B, means, scales, K, inv_T); break;
+    case 3: hipLaunchKernelGGL(gmm_kernel<3>, dim3(grid), dim3(256), lds, s, x, logp, force, B, means, scales, K, inv_T); break;
+    default: hipLaunchKernelGGL(gmm_kernel<4>, dim3(grid), dim3(256), lds, s, x, logp, force, B, means, scales, K, inv_T); break;
+  }
+  PITA_LAUNCH_CHECK();
+  return PITA_OK;
+}

@@ -1,0 +1,255 @@
+// MLP score backbone (MyMLP / MyMLPTemperature) for gfx950 on f32 MFMA.
+//
+// Replaces (paths relative to /root/reference/pita/src/models/components/):
+//   mlp.py:11-24    SinusoidalEmbedding  (per-coordinate scale 25, time / beta scale 1)
+//   mlp.py:100-118  Block                (x + GELU(Linear(x)))
+//   mlp.py:244-267  MyMLP.forward ; mlp.py:501-524 MyMLPTemperature.forward
+//
+// Mapping: one wavefront = 32 walkers = the 32 columns of v_mfma_f32_32x32x2_f32.  Activations
+// live in registers in the MFMA C/D layout (lane = walker column, 16 of every 32 features per
+// lane) -- the same chaining trick as the EGNN kernel, so no layer ever leaves the register
+// file.  The sinusoidal embedding is generated on the fly, 32 features at a time, straight into
+// the B-operand layout of the first GEMM (the [B, 384] embedding tensor is never materialised).
+// Weights are pre-packed into per-lane fragment order and stream from L2.
+#include "common.h"
+
+namespace pita {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct MlpParams {
+  const float* w0;   // [NB][KC][1024]
+  const float* wl;   // [L][NB][NB][1024]
+  const float* wf;   // [NBO][NB][1024]
+  const float* b0;   // [NB][32]  fragment order
+  const float* bl;   // [L][NB][32]
+  const float* bf;   // [NBO][32]
+  const float* freqs;  // [E/2]
+  int input_dim, out_dim, n_layers, emb, temp, KC, NBO;
+  long long B;
+  const float* t;
+  const float* x;
+  const float* beta;
+  float* out;
+};
+
+__device__ __forceinline__ void mlp_load_frag(const float* __restrict__ pack, int lane, float (&wf)[16]) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(pack) + lane;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 v = p[q * 64];
+    wf[4 * q + 0] = v.x; wf[4 * q + 1] = v.y; wf[4 * q + 2] = v.z; wf[4 * q + 3] = v.w;
+  }
+}
+
+__device__ __forceinline__ f32x16 mlp_gemm32(const float (&wf)[16], const f32x16& in, f32x16 acc) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[r], in[r], acc, 0, 0, 0);
+  return acc;
+}
+
+__device__ __forceinline__ f32x16 mlp_bias(const float* b, int hh) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(b + hh * 16);
+  f32x4 a = p[0], bq = p[1], c = p[2], d = p[3];
+  f32x16 r;
+  r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = bq.x; r[5] = bq.y; r[6] = bq.z; r[7] = bq.w;
+  r[8] = c.x; r[9] = c.y; r[10] = c.z; r[11] = c.w; r[12] = d.x; r[13] = d.y; r[14] = d.z; r[15] = d.w;
+  return r;
+}
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+
+template <int NB>
+__global__ void __launch_bounds__(256) mlp_kernel(MlpParams p) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cl = lane & 31, hh = lane >> 5;
+  const long long ntile = (p.B + 31) / 32;
+  const int half = p.emb >> 1;
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntile; tile += (long long)gridDim.x * 4) {
+    const long long wid = tile * 32 + cl;
+    const bool valid = wid < p.B;
+    const long long wl = valid ? wid : p.B - 1;
+    // ---- layer 0: GELU(W0 . [emb(x_0) .. emb(x_{D-1}), emb(t), (emb(beta))] + b0)
+    f32x16 z[NB];
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob) z[ob] = mlp_bias(p.b0 + ob * 32, hh);
+    for (int kc = 0; kc < p.KC; ++kc) {
+      f32x16 e;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int f = kc * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const int var = f / p.emb, idx = f - var * p.emb;
+        float v, scale;
+        if (var < p.input_dim) { v = p.x[wl * p.input_dim + var]; scale = 25.0f; }
+        else if (var == p.input_dim) { v = p.t[wl]; scale = 1.0f; }
+        else { v = p.beta[wl]; scale = 1.0f; }
+        const float ang = (v * scale) * p.freqs[idx < half ? idx : idx - half];
+        e[r] = idx < half ? sinf(ang) : cosf(ang);
+      }
+#pragma unroll
+      for (int ob = 0; ob < NB; ++ob) {
+        float wf[16];
+        mlp_load_frag(p.w0 + ((size_t)ob * p.KC + kc) * 1024, lane, wf);
+        z[ob] = mlp_gemm32(wf, e, z[ob]);
+      }
+    }
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[ob][r] = gelu_erf(z[ob][r]);
+    // ---- residual blocks: z += GELU(W_l z + b_l)
+    for (int l = 0; l < p.n_layers; ++l) {
+      f32x16 nz[NB];
+#pragma unroll
+      for (int ob = 0; ob < NB; ++ob) {
+        nz[ob] = mlp_bias(p.bl + ((size_t)l * NB + ob) * 32, hh);
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+          float wf[16];
+          mlp_load_frag(p.wl + (((size_t)l * NB + ob) * NB + kb) * 1024, lane, wf);
+          nz[ob] = mlp_gemm32(wf, z[kb], nz[ob]);
+        }
+      }
+#pragma unroll
+      for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[ob][r] += gelu_erf(nz[ob][r]);
+    }
+    // ---- output head
+    for (int ob = 0; ob < p.NBO; ++ob) {
+      f32x16 o = mlp_bias(p.bf + ob * 32, hh);
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) {
+        float wf[16];
+        mlp_load_frag(p.wf + ((size_t)ob * NB + kb) * 1024, lane, wf);
+        o = mlp_gemm32(wf, z[kb], o);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (valid && row < p.out_dim) p.out[wid * p.out_dim + row] = o[r];
+      }
+    }
+  }
+}
+
+}  // namespace pita
+
+struct pita_mlp {
+  pita_mlp_config cfg;
+  float* d_all = nullptr;
+  pita::MlpParams p{};
+};
+
+using namespace pita;
+
+static inline int mlp_kfeat(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+extern "C" int64_t pita_mlp_num_weights(const pita_mlp_config* c) {
+  if (!c) return PITA_EINVAL;
+  const int64_t C = (int64_t)c->emb_size * (c->input_dim + 1 + (c->temperature_conditioned ? 1 : 0));
+  const int64_t H = c->hidden_size;
+  // the reference sizes the head by emb_size (mlp.py:238-239), valid only when emb_size == hidden_size
+  return (H * C + H) + (int64_t)c->hidden_layers * (H * H + H) + ((int64_t)c->out_dim * H + c->out_dim);
+}
+
+extern "C" int pita_mlp_create(pita_mlp_t** out, const pita_mlp_config* cfg, const float* w, int64_t n_weights,
+                               const float* freqs) {
+  PITA_REQUIRE(out && cfg && w && freqs, "pita_mlp_create: null argument");
+  const int H = cfg->hidden_size, E = cfg->emb_size, L = cfg->hidden_layers;
+  const int C = E * (cfg->input_dim + 1 + (cfg->temperature_conditioned ? 1 : 0));
+  if (!(H == 32 || H == 64 || H == 128))
+    return fail(PITA_EUNSUPPORTED, "pita_mlp_create: hidden_size=%d (32, 64, 128 implemented)", H);
+  if (E != H) return fail(PITA_EUNSUPPORTED, "pita_mlp_create: emb_size must equal hidden_size (reference head sizing)");
+  PITA_REQUIRE(E % 2 == 0 && C % 32 == 0, "pita_mlp_create: emb_size*(inputs) must be a multiple of 32");
+  PITA_REQUIRE(cfg->out_dim >= 1 && cfg->input_dim >= 1 && L >= 0, "pita_mlp_create: bad dims");
+  PITA_REQUIRE(n_weights == pita_mlp_num_weights(cfg), "pita_mlp_create: got %lld weights, expected %lld",
+               (long long)n_weights, (long long)pita_mlp_num_weights(cfg));
+  const int NB = H / 32, KC = C / 32, NBO = (cfg->out_dim + 31) / 32;
+  const size_t n_w0 = (size_t)NB * KC * 1024, n_wl = (size_t)L * NB * NB * 1024, n_wf = (size_t)NBO * NB * 1024;
+  const size_t n_b0 = (size_t)NB * 32, n_bl = (size_t)L * NB * 32, n_bf = (size_t)NBO * 32, n_fr = E / 2;
+  const size_t total = n_w0 + n_wl + n_wf + n_b0 + n_bl + n_bf + n_fr;
+  float* h = new float[total]();
+  float* h_w0 = h; float* h_wl = h_w0 + n_w0; float* h_wf = h_wl + n_wl;
+  float* h_b0 = h_wf + n_wf; float* h_bl = h_b0 + n_b0; float* h_bf = h_bl + n_bl; float* h_fr = h_bf + n_bf;
+  auto pack_block = [&](float* dst, const float* M, int rows, int ld, int ob, int kb) {
+    for (int q = 0; q < 4; ++q)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int s = 0; s < 4; ++s) {
+          const int row = ob * 32 + (lane & 31), col = kb * 32 + mlp_kfeat(4 * q + s, lane >> 5);
+          dst[(q * 64 + lane) * 4 + s] = (row < rows) ? M[(size_t)row * ld + col] : 0.f;
+        }
+  };
+  auto pack_bias = [&](float* dst, const float* b, int rows, int ob) {
+    for (int hh = 0; hh < 2; ++hh)
+      for (int r = 0; r < 16; ++r) {
+        const int row = ob * 32 + mlp_kfeat(r, hh);
+        dst[hh * 16 + r] = row < rows ? b[row] : 0.f;
+      }
+  };
+  const float* q = w;
+  const float* W0 = q; q += (size_t)H * C;
+  const float* B0 = q; q += H;
+  for (int ob = 0; ob < NB; ++ob) {
+    for (int kc = 0; kc < KC; ++kc) pack_block(h_w0 + ((size_t)ob * KC + kc) * 1024, W0, H, C, ob, kc);
+    pack_bias(h_b0 + ob * 32, B0, H, ob);
+  }
+  for (int l = 0; l < L; ++l) {
+    const float* Wl = q; q += (size_t)H * H;
+    const float* Bl = q; q += H;
+    for (int ob = 0; ob < NB; ++ob) {
+      for (int kb = 0; kb < NB; ++kb) pack_block(h_wl + (((size_t)l * NB + ob) * NB + kb) * 1024, Wl, H, H, ob, kb);
+      pack_bias(h_bl + ((size_t)l * NB + ob) * 32, Bl, H, ob);
+    }
+  }
+  const float* Wf = q; q += (size_t)cfg->out_dim * H;
+  const float* Bf = q;
+  for (int ob = 0; ob < NBO; ++ob) {
+    for (int kb = 0; kb < NB; ++kb) pack_block(h_wf + ((size_t)ob * NB + kb) * 1024, Wf, cfg->out_dim, H, ob, kb);
+    pack_bias(h_bf + ob * 32, Bf, cfg->out_dim, ob);
+  }
+  for (size_t i = 0; i < n_fr; ++i) h_fr[i] = freqs[i];
+  pita_mlp* net = new pita_mlp();
+  net->cfg = *cfg;
+  hipError_t e = hipMalloc(&net->d_all, total * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(net->d_all, h, total * sizeof(float), hipMemcpyHostToDevice);
+  delete[] h;
+  if (e != hipSuccess) {
+    (void)hipFree(net->d_all);
+    delete net;
+    return fail(PITA_EHIP, "pita_mlp_create: device upload failed: %s", hipGetErrorString(e));
+  }
+  MlpParams& p = net->p;
+  p.w0 = net->d_all; p.wl = p.w0 + n_w0; p.wf = p.wl + n_wl; p.b0 = p.wf + n_wf; p.bl = p.b0 + n_b0;
+  p.bf = p.bl + n_bl; p.freqs = p.bf + n_bf;
+  p.input_dim = cfg->input_dim; p.out_dim = cfg->out_dim; p.n_layers = L; p.emb = E;
+  p.temp = cfg->temperature_conditioned; p.KC = KC; p.NBO = NBO;
+  *out = net;
+  return PITA_OK;
+}
+
+extern "C" int pita_mlp_destroy(pita_mlp_t* net) {
+  if (!net) return PITA_OK;
+  (void)hipFree(net->d_all);
+  delete net;
+  return PITA_OK;
+}
+
+extern "C" int pita_mlp_forward(pita_mlp_t* net, const float* t, const float* x, const float* beta, float* out,
+                                int64_t B, void* stream) {
+  PITA_REQUIRE(net && t && x && out && B >= 0, "pita_mlp_forward: null argument");
+  PITA_REQUIRE(beta || !net->cfg.temperature_conditioned, "pita_mlp_forward: beta required (temperature_conditioned)");
+  if (B == 0) return PITA_OK;
+  MlpParams p = net->p;
+  p.B = B; p.t = t; p.x = x; p.beta = beta; p.out = out;
+  const long long nblk = ((B + 31) / 32 + 3) / 4;
+  const unsigned grid = (unsigned)(nblk < 4096 ? nblk : 4096);
+  hipStream_t s = (hipStream_t)stream;
+  switch (net->cfg.hidden_size / 32) {
+    case 1: hipLaunchKernelGGL(mlp_kernel<1>, dim3(grid), dim3(256), 0, s, p); break;
+    case 2: hipLaunchKernelGGL(mlp_kernel<2>, dim3(grid), dim3(256), 0, s, p); break;
+    default: hipLaunchKernelGGL(mlp_kernel<4>, dim3(grid), dim3(256), 0, s, p); break;
+  }
+  PITA_LAUNCH_CHECK();
+  return PITA_OK;
+}

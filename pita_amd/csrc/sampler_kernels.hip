@@ -1,0 +1,233 @@
+// Elementwise pieces of the sampler and systematic resampling for gfx950.
+//
+// Replaces (paths relative to /root/reference/pita/src/):
+//   models/components/sde_integration.py:347-349   x += drift*dt + diffusion*sqrt(dt)
+//   models/components/sdes.py:245-251              diffusion = scale * g(t) * randn_like(x)
+//   utils/data_utils.py:4-26                       remove_mean
+//   energies/base_prior.py:77-83                   MeanFreePrior.sample
+//   models/components/utils.py:111-120             sample_cat_sys (systematic resampling)
+//   models/components/sde_integration.py:293       x = x[choice]
+#include "common.h"
+
+namespace pita {
+
+// One thread per (walker, particle); WB = floor(256/n) walkers per block staged in LDS so the
+// per-walker mean is a broadcast read and every global access is one coalesced span.
+enum { OP_EM = 0, OP_PRIOR = 1, OP_RMEAN = 2, OP_NORMAL = 3 };
+
+struct ElemParams {
+  float dt, noise_scale, sqrt_dt, scale;
+  unsigned long long seed, walker_offset;
+  long long step;
+  int remove_mean;
+};
+
+template <int DIM, int OP>
+__global__ void __launch_bounds__(256) elem_kernel(float* __restrict__ x, const float* __restrict__ drift,
+                                                   const float* __restrict__ noise, long long B, int n, int WB,
+                                                   ElemParams p) {
+  extern __shared__ float sm[];  // [WB*n*DIM]
+  const int tid = threadIdx.x;
+  const long long nblk = (B + WB - 1) / WB;
+  for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const long long w0 = blk * WB;
+    const int nw = (int)((B - w0) < WB ? (B - w0) : WB);
+    const int w = tid / n, i = tid - w * n;
+    const bool act = w < nw;
+    float v[DIM];
+    if (act) {
+      const long long base = ((w0 + w) * n + i) * DIM;
+      float xi[4] = {0.f, 0.f, 0.f, 0.f};
+      if (OP == OP_EM || OP == OP_PRIOR || OP == OP_NORMAL) {
+        if (noise) {
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) xi[k] = noise[base + k];
+        } else {
+          philox_normal4(p.seed, p.walker_offset + (unsigned long long)(w0 + w), p.step, (uint32_t)i, xi);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) {
+        if (OP == OP_EM) v[k] = x[base + k] + (drift[base + k] * p.dt + ((p.noise_scale * xi[k]) * p.sqrt_dt));
+        if (OP == OP_PRIOR) v[k] = xi[k] * p.scale;
+        if (OP == OP_RMEAN) v[k] = x[base + k];
+        if (OP == OP_NORMAL) v[k] = xi[k];
+        sm[(w * n + i) * DIM + k] = v[k];
+      }
+    }
+    __syncthreads();
+    if (act) {
+      const long long base = ((w0 + w) * n + i) * DIM;
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) {
+        if (p.remove_mean) {
+          float s = 0.f;
+          for (int q = 0; q < n; ++q) s += sm[(w * n + q) * DIM + k];
+          v[k] -= s / (float)n;
+        }
+        x[base + k] = v[k];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int OP>
+static int launch_elem(float* x, const float* drift, const float* noise, int64_t B, int n, int d, const ElemParams& p,
+                       void* stream) {
+  PITA_REQUIRE(B >= 0, "elementwise: negative batch");
+  if (B == 0) return PITA_OK;
+  PITA_REQUIRE(x, "elementwise: null argument");
+  PITA_REQUIRE(n >= 1 && n <= 256, "elementwise: n_particles must be in [1,256]");
+  PITA_REQUIRE(d >= 1 && d <= 3, "elementwise: n_dim must be 1, 2 or 3");
+  if (B == 0) return PITA_OK;
+  const int WB = 256 / n;
+  const long long nblk = (B + WB - 1) / WB;
+  const unsigned grid = (unsigned)(nblk < 256LL * 16 ? nblk : 256LL * 16);
+  const size_t lds = sizeof(float) * (size_t)(WB * n * d);
+  hipStream_t s = (hipStream_t)stream;
+  switch (d) {
+    case 1: hipLaunchKernelGGL((elem_kernel<1, OP>), dim3(grid), dim3(256), lds, s, x, drift, noise, B, n, WB, p); break;
+    case 2: hipLaunchKernelGGL((elem_kernel<2, OP>), dim3(grid), dim3(256), lds, s, x, drift, noise, B, n, WB, p); break;
+    default: hipLaunchKernelGGL((elem_kernel<3, OP>), dim3(grid), dim3(256), lds, s, x, drift, noise, B, n, WB, p); break;
+  }
+  PITA_LAUNCH_CHECK();
+  return PITA_OK;
+}
+
+// ---------------------------------------------------------------------------- resampling
+// Single 1024-thread block: B is at most a few 10^5 and the op is latency- not bandwidth-bound.
+// workspace: float w[B]; double cum[B] (stored as float bins after rounding).
+constexpr int RS_T = 1024;
+
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+  for (int o = 32; o > 0; o >>= 1) {
+    float u = __shfl_xor(v, o, 64);
+    v = is_max ? fmaxf(v, u) : v + u;
+  }
+  const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  __syncthreads();
+  if (ln == 0) red[wv] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int k = 1; k < RS_T / 64; ++k) r = is_max ? fmaxf(r, red[k]) : r + red[k];
+  return r;
+}
+
+__global__ void __launch_bounds__(RS_T) resample_kernel(const float* __restrict__ logits, long long B, double u0,
+                                                        long long* __restrict__ ids, float* __restrict__ bins) {
+  __shared__ float red[RS_T / 64];
+  __shared__ double dred[RS_T];
+  const int tid = threadIdx.x;
+  // softmax(logits) -> clip(., 1e-6, 1)   (utils.py:114)
+  float mx = -INFINITY;
+  for (long long i = tid; i < B; i += RS_T) mx = fmaxf(mx, logits[i]);
+  mx = block_reduce(mx, red, true);
+  float sm = 0.f;
+  for (long long i = tid; i < B; i += RS_T) sm += expf(logits[i] - mx);
+  sm = block_reduce(sm, red, false);
+  // inclusive cumsum.  torch's CPU cumsum accumulates float inputs in double and rounds each
+  // prefix to float (utils.py:116); a blocked double scan reproduces that to the last bit except
+  // at double-rounding ties.
+  const long long per = (B + RS_T - 1) / RS_T;
+  const long long lo = (long long)tid * per, hi = (lo + per < B) ? lo + per : B;
+  double acc = 0.0;
+  for (long long i = lo; i < hi; ++i) {
+    float w = expf(logits[i] - mx) / sm;
+    w = fminf(fmaxf(w, 1e-6f), 1.0f);
+    acc += (double)w;
+  }
+  dred[tid] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    double run = 0.0;
+    for (int k = 0; k < RS_T; ++k) { double t = dred[k]; dred[k] = run; run += t; }
+  }
+  __syncthreads();
+  acc = dred[tid];
+  for (long long i = lo; i < hi; ++i) {
+    float w = expf(logits[i] - mx) / sm;
+    w = fminf(fmaxf(w, 1e-6f), 1.0f);
+    acc += (double)w;
+    bins[i] = (float)acc;
+  }
+  __threadfence_block();
+  __syncthreads();
+  // u_k = (u0 + fp32(k * fp32(1/B))) mod 1 in double; ids = #bins < u  (digitize right=True), clamp
+  const float invB = (float)(1.0 / (double)B);
+  for (long long k = tid; k < B; k += RS_T) {
+    double u = fmod(u0 + (double)((float)k * invB), 1.0);
+    long long a = 0, b = B;  // first index with bins[idx] >= u
+    while (a < b) {
+      long long m = (a + b) >> 1;
+      if ((double)bins[m] < u) a = m + 1; else b = m;
+    }
+    ids[k] = (a >= B) ? B - 1 : a;
+  }
+}
+
+__global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restrict__ src, const long long* __restrict__ ids,
+                                                          float* __restrict__ out, long long B, int D) {
+  const long long total = B * D;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long r = e / D;
+    out[e] = src[ids[r] * D + (e - r * D)];
+  }
+}
+
+}  // namespace pita
+
+using namespace pita;
+
+extern "C" int pita_em_step(float* x, const float* drift, const float* noise, int64_t B, int n, int d, float dt,
+                            float noise_scale, float sqrt_dt, uint64_t seed, uint64_t walker_offset, int64_t step,
+                            int remove_mean, void* stream) {
+  PITA_REQUIRE(drift, "pita_em_step: drift is null");
+  ElemParams p{};
+  p.dt = dt; p.noise_scale = noise_scale; p.sqrt_dt = sqrt_dt; p.seed = seed; p.walker_offset = walker_offset;
+  p.step = step; p.remove_mean = remove_mean;
+  return launch_elem<OP_EM>(x, drift, noise, B, n, d, p, stream);
+}
+
+extern "C" int pita_prior_sample(float* x, const float* noise, int64_t B, int n, int d, float scale, uint64_t seed,
+                                 uint64_t walker_offset, int mean_free, void* stream) {
+  ElemParams p{};
+  p.scale = scale; p.seed = seed; p.walker_offset = walker_offset; p.step = -1; p.remove_mean = mean_free;
+  return launch_elem<OP_PRIOR>(x, nullptr, noise, B, n, d, p, stream);
+}
+
+extern "C" int pita_remove_mean(float* x, int64_t B, int n, int d, void* stream) {
+  ElemParams p{};
+  p.remove_mean = 1;
+  return launch_elem<OP_RMEAN>(x, nullptr, nullptr, B, n, d, p, stream);
+}
+
+extern "C" int pita_fill_normal(float* out, int64_t B, int n, int d, uint64_t seed, uint64_t walker_offset,
+                                int64_t step, void* stream) {
+  ElemParams p{};
+  p.seed = seed; p.walker_offset = walker_offset; p.step = step; p.remove_mean = 0;
+  return launch_elem<OP_NORMAL>(out, nullptr, nullptr, B, n, d, p, stream);
+}
+
+extern "C" size_t pita_resample_workspace_bytes(int64_t B) { return sizeof(float) * (size_t)(B > 0 ? B : 1); }
+
+extern "C" int pita_systematic_resample(const float* logits, int64_t B, double u0, int64_t* ids, void* workspace,
+                                        void* stream) {
+  PITA_REQUIRE(logits && ids && workspace && B >= 0, "pita_systematic_resample: null argument");
+  if (B == 0) return PITA_OK;
+  hipLaunchKernelGGL(resample_kernel, dim3(1), dim3(RS_T), 0, (hipStream_t)stream, logits, (long long)B, u0,
+                     (long long*)ids, (float*)workspace);
+  PITA_LAUNCH_CHECK();
+  return PITA_OK;
+}
+
+extern "C" int pita_gather_rows(const float* src, const int64_t* ids, float* out, int64_t B, int D, void* stream) {
+  PITA_REQUIRE(src && ids && out && B >= 0 && D >= 1, "pita_gather_rows: bad argument");
+  PITA_REQUIRE(src != out, "pita_gather_rows: in-place gather is not supported");
+  if (B == 0) return PITA_OK;
+  const long long nb = (B * D + 255) / 256;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, (hipStream_t)stream, src,
+                     (const long long*)ids, out, (long long)B, D);
+  PITA_LAUNCH_CHECK();
+  return PITA_OK;
+}

@@ -1,0 +1,38 @@
+"""DW4-style multi double-well target (BASELINE config C2) on the HIP pairwise kernel.
+
+The reference tree has no DW4 energy (only the dead import
+pita/src/energies/base_datamodule.py:13 of ``bgflow.MultiDoubleWellPotential``); this class gives
+it the same plug-in shape as LennardJonesEnergy.  E = sum_{i<j} a (d-d0)^4 + b (d-d0)^2 + c,
+defaults a=0.9, b=-4, c=0, d0=4 (the DEM/bgflow DW4 parameters).  Parity is pinned only
+against the oracle's own restatement.
+"""
+import torch
+
+from . import _lib
+from .base_energy_function import BaseMoleculeEnergy
+
+
+class MultiDoubleWellEnergy(BaseMoleculeEnergy):
+    def __init__(self, dimensionality=8, n_particles=4, spatial_dim=2, data_path=None, device="cuda", a=0.9, b=-4.0,
+                 c=0.0, offset=4.0, is_molecule=True, temperature=1.0, should_normalize=False,
+                 data_normalization_factor=1.0, *args, **kwargs):
+        self.name = f"DW{n_particles}"
+        super().__init__(dimensionality=dimensionality, n_particles=n_particles, spatial_dim=spatial_dim,
+                         data_path=data_path, data_name="DW", device=device, is_molecule=is_molecule,
+                         temperature=temperature, should_normalize=should_normalize,
+                         data_normalization_factor=data_normalization_factor)
+        self.a, self.b, self.c, self.offset = float(a), float(b), float(c), float(offset)
+
+    def __call__(self, samples: torch.Tensor, return_force=False):
+        x = _lib.dev_tensor(samples, "samples")
+        if self.should_normalize:
+            x = self.unnormalize(x)
+        x = x.reshape(-1, self._dimensionality)
+        B = x.shape[0]
+        logp = torch.empty(B, device=x.device, dtype=torch.float32)
+        force = torch.empty_like(x) if return_force else None
+        _lib.check(_lib.lib().pita_dw_logp_force(
+            x.data_ptr(), logp.data_ptr(), _lib.ptr(force), B, self.n_particles, self.n_spatial_dim,
+            float(self.temperature), self.a, self.b, self.c, self.offset, _lib.stream_ptr(x.device)),
+            "pita_dw_logp_force")
+        return (logp, force) if return_force else logp

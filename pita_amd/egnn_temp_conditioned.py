@@ -1,0 +1,154 @@
+"""E(n)-equivariant GNN backbone executed by the fused HIP kernel.
+
+Mirror of ``EGNN_dynamics`` (pita/src/models/components/egnn_temp_conditioned.py:7-117): same
+constructor arguments, same parameter names and creation order (so a seeded construction gives
+the reference's weights and its ``state_dict`` / Lightning checkpoints load unchanged), same
+``forward(t, xs, beta) -> vel`` contract.  The module only OWNS the parameters; the arithmetic
+of EGNN.forward (:172-194) and E_GCL (:197-356) lives in pita_amd/csrc/egnn_kernel.hip.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class _GCLParams(nn.Module):
+    """Parameters of one E_GCL layer, created in the reference's order (:232-260)."""
+
+    def __init__(self, hidden_nf, act_fn, attention, tanh, edges_in_d=1):
+        super().__init__()
+        h = hidden_nf
+        self.edge_mlp = nn.Sequential(nn.Linear(2 * h + 1 + edges_in_d, h), act_fn, nn.Linear(h, h), act_fn)
+        self.node_mlp = nn.Sequential(nn.Linear(2 * h, h), act_fn, nn.Linear(h, h))
+        head = nn.Linear(h, 1, bias=False)
+        torch.nn.init.xavier_uniform_(head.weight, gain=0.001)
+        coord = [nn.Linear(h, h), act_fn, head]
+        if tanh:
+            coord.append(nn.Tanh())
+        self.coord_mlp = nn.Sequential(*coord)
+        if attention:
+            self.att_mlp = nn.Sequential(nn.Linear(h, 1), nn.Sigmoid())
+
+
+class EGNN(nn.Module):
+    """Parameter container matching the reference ``EGNN`` module tree (:120-170)."""
+
+    def __init__(self, in_node_nf, in_edge_nf, hidden_nf, act_fn=nn.SiLU(), n_layers=4, recurrent=True,
+                 attention=False, norm_diff=True, out_node_nf=None, tanh=False, coords_range=15, agg="sum",
+                 has_virtual=False):
+        super().__init__()
+        if has_virtual or not recurrent or not norm_diff or agg != "sum" or in_edge_nf != 1:
+            raise NotImplementedError("HIP EGNN implements recurrent=True, norm_diff=True, agg='sum', no virtual node")
+        if not isinstance(act_fn, nn.SiLU):
+            raise NotImplementedError("HIP EGNN implements the SiLU activation used by every reference config")
+        out_node_nf = in_node_nf if out_node_nf is None else out_node_nf
+        self.hidden_nf, self.n_layers = hidden_nf, n_layers
+        self.coords_range = float(coords_range)
+        self.attention, self.tanh = attention, tanh
+        self.embedding = nn.Linear(in_node_nf, hidden_nf)
+        self.embedding_out = nn.Linear(hidden_nf, out_node_nf)  # dead in the reference forward (:80,189)
+        for i in range(n_layers):
+            self.add_module("gcl_%d" % i, _GCLParams(hidden_nf, act_fn, attention, tanh, in_edge_nf))
+
+
+class EGNN_dynamics(nn.Module):
+    def __init__(self, n_particles, n_dimension, hidden_nf=64, act_fn=torch.nn.SiLU(), n_layers=4, recurrent=True,
+                 attention=False, condition_time=True, tanh=False, agg="sum", energy=False, add_virtual=False,
+                 condition_temperature=False, feature_layout="pita"):
+        super().__init__()
+        if energy or add_virtual or not condition_time:
+            raise NotImplementedError("HIP EGNN_dynamics implements energy=False, add_virtual=False, condition_time=True")
+        self.in_node_nf = 2 if condition_temperature else 1
+        self.egnn = EGNN(in_node_nf=self.in_node_nf, in_edge_nf=1, hidden_nf=hidden_nf, act_fn=act_fn,
+                         n_layers=n_layers, recurrent=recurrent, attention=attention, tanh=tanh, agg=agg)
+        self._n_particles, self._n_dimension = n_particles, n_dimension
+        self.condition_time, self.condition_temperature = condition_time, condition_temperature
+        # "pita" keeps the reference's t/beta interleave quirk (:68-78); "correct" gives (t, beta) per node
+        self.feature_layout = {"pita": 0, "correct": 1}[feature_layout]
+        self.counter = 0
+        self._handle = None
+        self._handle_key = None
+
+    # ------------------------------------------------------------------ native handle
+    def _config(self):
+        e = self.egnn
+        return _lib.EgnnConfig(self._n_particles, self._n_dimension, e.hidden_nf, e.n_layers, self.in_node_nf,
+                               int(e.attention), int(e.tanh), e.coords_range, self.feature_layout)
+
+    def _native(self, device):
+        params = list(self.state_dict().values())
+        key = (device.index,) + tuple((p.data_ptr(), p._version) for p in params)
+        if self._handle is None or key != self._handle_key:
+            self._release()
+            flat = torch.cat([p.detach().to("cpu", torch.float32).reshape(-1) for p in params]).contiguous().numpy()
+            cfg = self._config()
+            h = ctypes.c_void_p()
+            with torch.cuda.device(device):
+                _lib.check(_lib.lib().pita_egnn_create(ctypes.byref(h), ctypes.byref(cfg),
+                                                       flat.ctypes.data_as(ctypes.c_void_p), flat.size),
+                           "pita_egnn_create")
+            self._handle, self._handle_key = h, key
+        return self._handle
+
+    def _release(self):
+        if self._handle is not None:
+            _lib.lib().pita_egnn_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ reference interface
+    def forward(self, t, xs, beta=None):
+        """vel[B, n*d] = backbone(t[B], xs[B, n*d], beta[B]); mean-free (:56-93)."""
+        xs = _lib.dev_tensor(xs, "xs")
+        B = xs.shape[0]
+        t = _lib.dev_tensor(t, "t").reshape(-1).expand(B).contiguous()
+        if self.condition_temperature:
+            if beta is None:
+                raise ValueError("EGNN_dynamics(condition_temperature=True).forward needs beta")
+            beta = _lib.dev_tensor(beta, "beta").reshape(-1).expand(B).contiguous()
+        else:
+            beta = None
+        out = torch.empty_like(xs)
+        _lib.check(_lib.lib().pita_egnn_forward(self._native(xs.device), t.data_ptr(), xs.data_ptr(), _lib.ptr(beta),
+                                                out.data_ptr(), B, _lib.stream_ptr(xs.device)), "pita_egnn_forward")
+        self.counter += 1
+        return out
+
+    # ------------------------------------------------------------------ fused extensions used by ScoreNet / the sampler
+    def edm(self, what, h_t, x_t, beta):
+        """what=1: denoiser D_theta, what=2: score (D_theta - x)/h, EDM preconditioning fused (score_net.py:13-43)."""
+        x_t = _lib.dev_tensor(x_t, "x_t")
+        B = x_t.shape[0]
+        h_t = _lib.dev_tensor(h_t, "h_t").reshape(-1).expand(B).contiguous()
+        b = None
+        if self.condition_temperature:
+            b = _as_batch(beta, B, x_t.device)
+        out = torch.empty_like(x_t)
+        _lib.check(_lib.lib().pita_egnn_edm(self._native(x_t.device), what, h_t.data_ptr(), x_t.data_ptr(), _lib.ptr(b),
+                                            out.data_ptr(), B, _lib.stream_ptr(x_t.device)), "pita_egnn_edm")
+        return out
+
+    def sampler_run(self, x, step_tab, n_steps, noise=None, seed=0, walker_offset=0, step0=0, remove_mean=True,
+                    drift_out=None):
+        """In-place fused Euler-Maruyama steps (pita_egnn_sampler_run); x: [B, n*d] device tensor."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        assert step_tab.is_cuda and step_tab.dtype == torch.float32 and step_tab.is_contiguous()
+        _lib.check(_lib.lib().pita_egnn_sampler_run(
+            self._native(x.device), x.data_ptr(), x.shape[0], step_tab.data_ptr(), int(n_steps), _lib.ptr(noise),
+            int(seed) & 0xFFFFFFFFFFFFFFFF, int(walker_offset), int(step0), int(bool(remove_mean)),
+            _lib.ptr(drift_out), _lib.stream_ptr(x.device)), "pita_egnn_sampler_run")
+        return x
+
+
+def _as_batch(v, B, device):
+    if isinstance(v, torch.Tensor):
+        return _lib.dev_tensor(v.to(device), "beta").reshape(-1).expand(B).contiguous()
+    return torch.full((B,), float(v), device=device, dtype=torch.float32)

@@ -1,0 +1,47 @@
+"""Lennard-Jones cluster target evaluated by the HIP pairwise kernel.
+
+Mirror of ``LennardJonesEnergy`` (pita/src/energies/lennardjones_energy.py:158-227): same
+constructor arguments, ``__call__(samples, return_force=False)`` returns the detached
+log-density (and analytic force instead of autograd).  The arithmetic of
+``LennardJonesPotential._energy`` (:121-146) + bgflow's ``distances_from_vectors`` is in
+pita_amd/csrc/energy_kernels.hip (pita_lj_logp_force).
+"""
+import torch
+
+from . import _lib
+from .base_energy_function import BaseMoleculeEnergy
+
+
+class LennardJonesEnergy(BaseMoleculeEnergy):
+    def __init__(self, dimensionality, n_particles, spatial_dim, data_path=None, device="cuda",
+                 plot_samples_epoch_period=5, plotting_buffer_sample_size=512, energy_factor=1.0, is_molecule=True,
+                 smooth=False, temperature=1.0, should_normalize=False, data_normalization_factor=1.0,
+                 dist_eps=1e-6, *args, **kwargs):
+        if n_particles not in (13, 55):  # lennardjones_energy.py:177-182
+            raise NotImplementedError("LennardJonesEnergy: the reference defines LJ13 and LJ55 only")
+        if smooth:
+            raise NotImplementedError("smooth=True (cubic-spline core, lennardjones_energy.py:131-133) is not built")
+        self.name = "LJ13_efm" if n_particles == 13 else "LJ55"
+        super().__init__(dimensionality=dimensionality, n_particles=n_particles, spatial_dim=spatial_dim,
+                         data_path=data_path, data_name="LJ", device=device, is_molecule=is_molecule,
+                         temperature=temperature, should_normalize=should_normalize,
+                         data_normalization_factor=data_normalization_factor)
+        self.energy_factor = float(energy_factor)
+        self.dist_eps = float(dist_eps)  # bgflow distances_from_vectors eps
+        self.smooth = smooth
+        self.plot_samples_epoch_period = plot_samples_epoch_period
+        self.plotting_buffer_sample_size = plotting_buffer_sample_size
+
+    def __call__(self, samples: torch.Tensor, return_force=False):
+        x = _lib.dev_tensor(samples, "samples")
+        if self.should_normalize:
+            x = self.unnormalize(x)
+        x = x.reshape(-1, self._dimensionality)
+        B = x.shape[0]
+        logp = torch.empty(B, device=x.device, dtype=torch.float32)
+        force = torch.empty_like(x) if return_force else None
+        _lib.check(_lib.lib().pita_lj_logp_force(
+            x.data_ptr(), logp.data_ptr(), _lib.ptr(force), B, self.n_particles, self.n_spatial_dim,
+            float(self.temperature), self.energy_factor, self.dist_eps, 1.0, 1.0, 1.0, _lib.stream_ptr(x.device)),
+            "pita_lj_logp_force")
+        return (logp, force) if return_force else logp

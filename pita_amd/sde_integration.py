@@ -1,0 +1,311 @@
+"""Annealed reverse-SDE sampler driving the HIP kernels.
+
+Mirror of ``WeightedSDEIntegrator`` (pita/src/models/components/sde_integration.py:48-470):
+same constructor, ``integrate_sde(x1, energy_function, annealing_factor_schedule,
+inverse_temperature, annealing_factor_score, resampling_interval)`` and the same 5-tuple result.
+
+How the work is laid out on MI355X (differences from the reference are deliberate):
+  * the per-step scalars (h, g^2, gamma, EDM coefficients, dt) are computed once on the HOST in the
+    reference's fp32 op order and uploaded as a [N, 16] table;
+  * with the HIP EGNN backbone the whole trajectory between two resampling events is ONE kernel
+    launch (pita_egnn_sampler_run): walkers stay in registers, no per-step launch, no per-step
+    all_gather, no per-step device->host copy of SDETerms (reference :248-258,:289);
+  * walkers are sharded over ranks by contiguous slices exactly like :227-233, and gathered ONCE
+    at the end (RCCL all_gather) -- or at each resampling event, which is global like the
+    reference's;
+  * noise is Philox4x32-10 keyed by (seed, GLOBAL walker index, step): the result does not depend
+    on the number of GPUs.  ``noise=`` injects recorded normals for parity tests.
+Per-step ``SDETerms`` are only materialised with ``record_terms=True`` (the reference returns N
+CPU copies of [B,D] tensors of which only means are ever consumed).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .data_utils import remove_mean
+from .sdes import SDETerms, VEReverseSDE  # noqa: F401
+from .utils import gather_rows, sample_cat_sys
+
+
+def _scalar(v):
+    return float(v.reshape(-1)[0]) if isinstance(v, torch.Tensor) else float(v)
+
+
+def build_step_table(noise_schedule, annealing_factor_schedule, times, dt, diffusion_scale, inverse_temperature):
+    """[N, 16] float32 host table of per-step scalars in the reference's fp32 op order
+    (score_net.py:26-29; sdes.py:119-122,140,250; sde_integration.py:347)."""
+    N = len(times)
+    tab = torch.zeros(N, _lib.STEP_STRIDE, dtype=torch.float32)
+    sqrt_dt = np.sqrt(dt)
+    for k in range(N):
+        t = times[k]  # 0-dim fp32 CPU tensor
+        ht = noise_schedule.h(t)
+        g = noise_schedule.g(t)
+        tab[k, _lib.ST_CS] = 1 / (1 + ht)
+        c_in = 1 / (1 + ht) ** 0.5
+        tab[k, _lib.ST_CIN] = c_in
+        tab[k, _lib.ST_COUT] = ht**0.5 * c_in
+        tab[k, _lib.ST_CNOISE] = (1 / 8) * torch.log(ht)
+        tab[k, _lib.ST_H] = ht
+        tab[k, _lib.ST_G2] = g.pow(2)
+        tab[k, _lib.ST_GAMMA] = _scalar(annealing_factor_schedule.gamma(t))
+        tab[k, _lib.ST_DT] = dt
+        tab[k, _lib.ST_NOISE_SCALE] = diffusion_scale * g
+        tab[k, _lib.ST_SQRT_DT] = sqrt_dt
+        tab[k, _lib.ST_BETA] = float(inverse_temperature)
+    return tab
+
+
+class _Comm:
+    """Rank / world / all_gather, from the Lightning module the reference passes
+    (sde_integration.py:227-229,248) or from torch.distributed (RCCL) when that is initialised."""
+
+    def __init__(self, lightning_module):
+        self.lm = lightning_module
+        if lightning_module is not None and getattr(lightning_module, "trainer", None) is not None:
+            self.world = int(lightning_module.trainer.world_size)
+            self.rank = int(lightning_module.trainer.global_rank)
+        elif torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.world = torch.distributed.get_world_size()
+            self.rank = torch.distributed.get_rank()
+        else:
+            self.world, self.rank = 1, 0
+
+    def all_gather(self, x):
+        if self.world == 1:
+            return x
+        if self.lm is not None and hasattr(self.lm, "all_gather") and not torch.distributed.is_initialized():
+            return self.lm.all_gather(x).reshape(-1, *x.shape[1:])
+        out = torch.empty((self.world * x.shape[0],) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
+        torch.distributed.all_gather_into_tensor(out, x.contiguous())
+        return out
+
+
+class WeightedSDEIntegrator:
+    def __init__(self, sde, num_integration_steps, start_resampling_step, end_resampling_step, lightning_module=None,
+                 partial_annealing_factor_schedule=None, reverse_time=True, diffusion_scale=1.0, time_range=1.0,
+                 resampling_interval=-1, num_negative_time_steps=100, post_mcmc_steps=100, adaptive_mcmc=False,
+                 batch_size=None, no_grad=True, resample_at_end=False, dt_negative_time=1e-4, do_langevin=False,
+                 should_mean_free=True, seed=0, record_terms=False, verbose=False):
+        self.sde = sde
+        self.num_integration_steps = num_integration_steps
+        self.start_resampling_step, self.end_resampling_step = start_resampling_step, end_resampling_step
+        self.reverse_time = reverse_time
+        self.diffusion_scale = diffusion_scale
+        self.resampling_interval = resampling_interval
+        self.time_range = time_range
+        self.num_negative_time_steps = num_negative_time_steps
+        self.post_mcmc_steps = post_mcmc_steps
+        self.adaptive_mcmc = adaptive_mcmc
+        self.dt_negative_time = dt_negative_time
+        self.batch_size = batch_size
+        self.no_grad = no_grad
+        self.resample_at_end = resample_at_end
+        self.do_langevin = do_langevin
+        self.lightning_module = lightning_module
+        self.should_mean_free = should_mean_free
+        self.start_time = time_range if reverse_time else 0.0
+        self.end_time = time_range - self.start_time
+        self.seed = seed
+        self.record_terms = record_terms
+        self.verbose = verbose
+        self._runs = 0
+
+    # ------------------------------------------------------------------ helpers
+    def maybe_remove_mean(self, x, energy_function):
+        if self.should_mean_free:
+            return remove_mean(x, energy_function.n_particles, energy_function.n_spatial_dim)
+        return x
+
+    def _geometry(self, x, energy_function):
+        n = getattr(energy_function, "n_particles", None)
+        d = getattr(energy_function, "n_spatial_dim", None)
+        if n is None or d is None:  # non-particle target (GMM): one "particle" of dimension D
+            n, d = 1, x.shape[1]
+        return int(n), int(d)
+
+    def _backbone(self):
+        sn = self.sde.score_net
+        model = getattr(sn, "model", None)
+        fused = model is not None and hasattr(model, "sampler_run") and not getattr(sn, "precondition_beta", False)
+        return model if fused else None
+
+    def _key(self, stream_id):
+        return (int(self.seed) * 0x9E3779B97F4A7C15 + (self._runs << 8) + stream_id) & 0xFFFFFFFFFFFFFFFF
+
+    # ------------------------------------------------------------------ A1 integrate_sde
+    @torch.no_grad()
+    def integrate_sde(self, x1, energy_function, annealing_factor_schedule, inverse_temperature=1.0,
+                      annealing_factor_score=1.0, resampling_interval=None, noise=None, resample_u=None):
+        """``noise``: optional [N, B, D] device normals (global batch); ``resample_u``: optional
+        iterable of float64 uniforms, one per resampling event (parity hooks)."""
+        if getattr(self.sde, "debias_inference", False):
+            raise NotImplementedError("debias_inference=True is not built on the HIP path (SURVEY section 8(f) N1)")
+        if resampling_interval is None:
+            resampling_interval = self.resampling_interval
+        N = self.num_integration_steps
+        x1 = _lib.dev_tensor(x1, "x1")
+        dev = x1.device
+        comm = _Comm(self.lightning_module)
+        Bg = x1.shape[0]
+        Bl = Bg // comm.world  # sde_integration.py:227
+        off = comm.rank * Bl
+        x = x1[off:off + Bl].clone()
+        n, d = self._geometry(x, energy_function)
+        mean_free = bool(self.should_mean_free)
+        if self.batch_size is None:
+            self.batch_size = Bg
+
+        times = torch.linspace(self.start_time, self.end_time, N + 1)[:-1]
+        dt = self.time_range / N
+        tab_h = build_step_table(self.sde.noise_schedule, annealing_factor_schedule, times, dt, self.diffusion_scale,
+                                 inverse_temperature)
+        tab = tab_h.to(dev)
+        if noise is not None:
+            noise = _lib.dev_tensor(noise, "noise")[:, off:off + Bl].contiguous()
+        key = self._key(0)
+        self._runs += 1
+        u_iter = iter(resample_u) if resample_u is not None else None
+
+        start = max(0, min(self.start_resampling_step, N))  # before `start` walkers do not move (:278-280)
+        if start > 0 and mean_free:
+            x = remove_mean(x, n, d)  # :148 is applied every step; idempotent
+        did_resampling = resampling_interval != -1 and resampling_interval < N
+        events = [] if resampling_interval == -1 else [
+            s for s in range(start, min(self.end_resampling_step, N)) if (s + 1) % resampling_interval == 0]
+        num_unique_idxs = [Bg] * N
+        sde_terms_all = []
+        model = self._backbone()
+
+        s = start
+        bounds = events + [N - 1]
+        for stop in bounds:  # run steps s..stop inclusive, then (maybe) resample
+            if stop < s:
+                continue
+            self._run_steps(model, x, tab, tab_h, s, stop + 1, noise, key, off, n, d, mean_free, inverse_temperature,
+                            sde_terms_all)
+            s = stop + 1
+            if stop in events:
+                xg = comm.all_gather(x)
+                a = torch.zeros(xg.shape[0], device=dev)  # drift_A = 0 in the not-debiased regime
+                u = next(u_iter) if u_iter is not None else None
+                ids, _ = sample_cat_sys(xg.shape[0], a, u)
+                xg = gather_rows(xg, ids)
+                num_unique_idxs[stop] = int(torch.unique(ids).numel())
+                x = xg[off:off + Bl].clone()
+                if mean_free:
+                    x = remove_mean(x, n, d)
+        # log-weights are identically zero here; a stride-0 view avoids N*B*4 bytes (reference stacks N copies)
+        logweights = torch.zeros(1, Bg, device=dev).expand(N, Bg)
+
+        if self.resample_at_end and did_resampling:  # :158-183
+            t_end = times[min(self.end_resampling_step, N - 1)]
+            xg = comm.all_gather(x)
+            tb = torch.full((xg.shape[0],), float(t_end), device=dev)
+            target_logprob = energy_function(xg)
+            h_t = self.sde.noise_schedule.h(tb)
+            model_energy = self.sde.energy_net.forward_energy(h_t, xg, inverse_temperature)
+            a_next = target_logprob - (-model_energy * _scalar(annealing_factor_schedule.gamma(t_end)))
+            a_next = torch.clamp(a_next, max=torch.quantile(a_next, 0.9))
+            u = next(u_iter) if u_iter is not None else None
+            ids, _ = sample_cat_sys(xg.shape[0], a_next, u)
+            xg = gather_rows(xg, ids)
+            x = xg[off:off + Bl].clone()
+            logweights = torch.cat([logweights, a_next[None]])
+            num_unique_idxs.append(int(torch.unique(ids).numel()))
+
+        if self.num_negative_time_steps > 0:
+            x = self.negative_time_descent(x, energy_function, walker_offset=off)
+        acceptance_rate_list = []
+        if self.post_mcmc_steps > 0:
+            fn = self.metropolis_hastings_mala_adaptive if self.adaptive_mcmc else self.metropolis_hastings_mala
+            kw = dict(dt_init=self.dt_negative_time) if self.adaptive_mcmc else {}
+            x, acceptance_rate_list = fn(x, energy_function, return_acceptance_rate=True, **kw)
+        x = comm.all_gather(x)  # X1: the only collective on the resampling-free path
+        return x, logweights, num_unique_idxs, sde_terms_all, acceptance_rate_list
+
+    # ------------------------------------------------------------------ A2-A4 steps [s0, s1)
+    def _run_steps(self, model, x, tab, tab_h, s0, s1, noise, key, off, n, d, mean_free, beta, sde_terms_all):
+        if s1 <= s0:
+            return
+        if model is not None and not self.record_terms:
+            nz = noise[s0:s1].contiguous() if noise is not None else None
+            model.sampler_run(x, tab[s0:s1].contiguous(), s1 - s0, noise=nz, seed=key, walker_offset=off, step0=s0,
+                              remove_mean=mean_free)
+            return
+        # per-step path: any backbone with forward(t, x, beta); drift through ScoreNet, update by pita_em_step
+        L = _lib.lib()
+        for k in range(s0, s1):
+            row = tab_h[k]
+            ht = torch.full((x.shape[0],), float(row[_lib.ST_H]), device=x.device)
+            score = self.sde.score_net(ht, x, beta)
+            drift = float(row[_lib.ST_GAMMA]) * (score * float(row[_lib.ST_G2]))
+            drift = drift.contiguous()
+            nz = noise[k].contiguous() if noise is not None else None
+            _lib.check(L.pita_em_step(x.data_ptr(), drift.data_ptr(), _lib.ptr(nz), x.shape[0], n, d,
+                                      float(row[_lib.ST_DT]), float(row[_lib.ST_NOISE_SCALE]),
+                                      float(row[_lib.ST_SQRT_DT]), key, off, k, int(mean_free),
+                                      _lib.stream_ptr(x.device)), "pita_em_step")
+            if self.record_terms:
+                sde_terms_all.append(SDETerms(drift_X=drift, drift_A=torch.zeros(x.shape[0], device=x.device)))
+
+    # ------------------------------------------------------------------ A16 post-processing
+    def negative_time_descent(self, x, energy_function, noise=None, walker_offset=0):
+        """x += F*dt (+ sqrt(2 dt) xi), remove_mean, repeated (sde_integration.py:353-360)."""
+        n, d = self._geometry(x, energy_function)
+        dt = float(self.dt_negative_time)
+        key = self._key(1)
+        L = _lib.lib()
+        x = x.clone()
+        for k in range(self.num_negative_time_steps):
+            _, F = energy_function(x, return_force=True)
+            nz = noise[k].contiguous() if noise is not None else None
+            _lib.check(L.pita_em_step(x.data_ptr(), F.data_ptr(), _lib.ptr(nz), x.shape[0], n, d, dt,
+                                      1.0 if self.do_langevin else 0.0, math.sqrt(2 * dt), key, walker_offset, k,
+                                      int(self.should_mean_free), _lib.stream_ptr(x.device)), "pita_em_step")
+        return x
+
+    def _mala(self, x, energy_function, adaptive, dt, noise=None, uniforms=None, return_acceptance_rate=False):
+        """MALA with the reference's finite-mask semantics (:362-470): non-finite-logp walkers are set
+        aside and re-appended AFTER the valid ones (order not preserved, quirk Q7)."""
+        n, d = self._geometry(x, energy_function)
+        logp_all = energy_function(x)
+        valid = torch.isfinite(logp_all)
+        x_valid, x_invalid = x[valid].contiguous(), x[~valid]
+        logp = logp_all[valid]
+        rates = []
+        for i in range(self.post_mcmc_steps):
+            if x_valid.shape[0] == 0:
+                break
+            _, grad = energy_function(x_valid, return_force=True)
+            xi = noise[i] if noise is not None else torch.randn_like(x_valid)
+            fwd_mean = x_valid + 0.5 * dt * grad
+            x_prop = fwd_mean + math.sqrt(dt) * xi  # mala_proposal :28-45
+            log_q_f = -((x_prop - fwd_mean) ** 2).sum(dim=1) / (2 * dt)
+            logp_prop, grad_prop = energy_function(x_prop, return_force=True)
+            bwd_mean = x_prop + 0.5 * dt * grad_prop
+            log_q_b = -((x_valid - bwd_mean) ** 2).sum(dim=1) / (2 * dt)
+            ratio = (logp_prop - logp) + (log_q_b - log_q_f)
+            uu = uniforms[i] if uniforms is not None else torch.rand_like(ratio)
+            acc = torch.log(uu) < ratio
+            rate = acc.float().mean().item()
+            if adaptive:  # :439-443
+                dt = dt * 1.1 if rate > 0.55 else dt / 1.1
+            rates.append(rate)
+            af = acc.float()
+            x_valid = af[:, None] * x_prop + (1 - af[:, None]) * x_valid
+            logp = af * logp_prop + (1 - af) * logp
+            if getattr(energy_function, "is_molecule", False):
+                x_valid = remove_mean(x_valid, n, d)
+        out = torch.cat([x_valid, x_invalid], dim=0)
+        return (out, rates) if return_acceptance_rate else (out, None)
+
+    def metropolis_hastings_mala(self, x, energy_function, return_acceptance_rate=False, noise=None, uniforms=None):
+        return self._mala(x, energy_function, False, float(self.dt_negative_time), noise, uniforms,
+                          return_acceptance_rate)
+
+    def metropolis_hastings_mala_adaptive(self, x, energy_function, dt_init, return_acceptance_rate=False, noise=None,
+                                          uniforms=None):
+        return self._mala(x, energy_function, True, float(dt_init), noise, uniforms, return_acceptance_rate)

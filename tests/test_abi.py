@@ -1,0 +1,100 @@
+"""CPU checks of the drop-in boundary: the C-ABI library builds, loads and exports every symbol
+declared in include/pita_hip.h; host-side logic that needs no GPU."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as ge
+
+    ge.build()
+    import pita_amd
+
+    return pita_amd
+
+
+def test_header_symbols_exported(built):
+    hdr = open(os.path.join(ROOT, "include", "pita_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(pita_[a-z0-9_]+)\s*\(", hdr))
+    nm = subprocess.check_output(["nm", "-D", "--defined-only", built._lib.LIB_PATH], text=True)
+    exported = set(re.findall(r" T (pita_[a-z0-9_]+)", nm))
+    assert declared, "no declarations parsed"
+    assert declared <= exported, f"declared but not exported: {sorted(declared - exported)}"
+    assert set(built._lib.EXPORTS) <= exported
+    assert set(built._lib.EXPORTS) == declared, (sorted(declared ^ set(built._lib.EXPORTS)))
+
+
+def test_no_cpu_fallback(built):
+    e = built.LennardJonesEnergy(39, 13, 3)
+    with pytest.raises(built._lib.PitaHipError):
+        e(torch.zeros(2, 39))
+    net = built.EGNN_dynamics(13, 3, hidden_nf=32, n_layers=3, tanh=True, attention=True, condition_temperature=True)
+    with pytest.raises(built._lib.PitaHipError):
+        net(torch.zeros(2), torch.zeros(2, 39), torch.ones(2))
+
+
+def test_product_does_not_import_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "pita_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "pita_oracle" not in src and "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_seeded_init_matches_reference_weights(built, golden):
+    torch.manual_seed(12345)
+    net = built.EGNN_dynamics(13, 3, hidden_nf=32, n_layers=3, recurrent=True, tanh=True, attention=True,
+                              condition_time=True, condition_temperature=True, agg="sum")
+    g = golden("egnn_weights_seed12345.npz")
+    sd = net.state_dict()
+    assert list(sd) == list(g)
+    for k in g:
+        np.testing.assert_array_equal(sd[k].numpy(), g[k])
+    cfg = net._config()
+    assert built._lib.lib().pita_egnn_num_weights(cfg) == sum(v.size for v in g.values()) == 22533
+
+
+def test_step_table_matches_oracle_schedule(built):
+    from oracle import pita_oracle as O
+
+    N = 50
+    sched = built.ElucidatingNoiseSchedule(sigma_min=0.05, sigma_max=80.0, rho=7)
+    gam = built.ConstantAnnealingFactorSchedule(4 / 3)
+    times = torch.linspace(1.0, 0.0, N + 1)[:-1]
+    tab = built.sde_integration.build_step_table(sched, gam, times, 1.0 / N, 1.0, 1.0)
+    osched = O.Elucidating(0.05, 80.0, 7)
+    h = osched.h(times)
+    np.testing.assert_allclose(tab[:, built._lib.ST_H].numpy(), h.numpy(), rtol=2e-7)
+    np.testing.assert_allclose(tab[:, built._lib.ST_G2].numpy(), osched.g(times).pow(2).numpy(), rtol=4e-7)
+    c_s, c_in, c_out, c_noise = O.edm_coeffs(h)
+    np.testing.assert_allclose(tab[:, built._lib.ST_CS].numpy(), c_s.numpy(), rtol=3e-7)
+    np.testing.assert_allclose(tab[:, built._lib.ST_COUT].numpy(), c_out.numpy(), rtol=3e-7)
+    np.testing.assert_allclose(tab[:, built._lib.ST_CNOISE].numpy(), c_noise.numpy(), rtol=3e-7, atol=1e-7)
+    assert np.all(tab[:, built._lib.ST_GAMMA].numpy() == np.float32(4 / 3))
+
+
+def test_schedules_match_golden(built, golden):
+    g = golden("schedules.npz")
+    t = torch.tensor(g["t"])
+    for smin in (0.002, 0.01, 0.05):
+        s = built.ElucidatingNoiseSchedule(sigma_min=smin, sigma_max=80.0, rho=7)
+        np.testing.assert_array_equal(s.h(t).numpy(), g[f"h_{smin}"])
+        np.testing.assert_array_equal(s.g(t).numpy(), g[f"g_{smin}"])
+        np.testing.assert_array_equal(s.dh_dt(t).numpy(), g[f"dhdt_{smin}"])
+    geo = built.GeometricNoiseSchedule(0.01, 10.0)
+    np.testing.assert_allclose(geo.h(t).numpy(), g["geo_h"], rtol=1e-6)
+    tt = torch.tensor(g["tt"])
+    for nm, sch in (("const", built.ConstantAnnealingFactorSchedule(4 / 3)),
+                    ("lin", built.LinearAnnealingFactorSchedule(1.5, 1.0, t_start=0.9, t_end=0.1)),
+                    ("sig", built.SigmoidAnnealingFactorSchedule(1.5, 1.0, t_start=0.9, t_end=0.1, sharpness=10.0))):
+        np.testing.assert_allclose(sch.gamma(tt).numpy(), g[f"gamma_{nm}"], rtol=1e-7)
+        np.testing.assert_allclose(sch.dgamma_dt(tt).numpy(), g[f"dgamma_{nm}"], rtol=1e-7, atol=1e-30)

@@ -1,0 +1,353 @@
+"""GPU parity tests: the HIP path (through the C ABI / pita_amd façade) against the CPU oracle
+and the golden vectors produced by the reference.  Run on an MI355X: pytest -m gpu.
+
+Tolerances (fp32, stated per test): target energies rel 1e-5 (logp) / rel-L2 1e-5 (force) on
+physical configurations; EGNN backbone rel-L2 2e-5 vs the fp32 reference and within 4x the
+reference's own fp32-vs-fp64 error; per-step drift rel-L2 1e-4 at identical inputs; integer
+index work (resampling ids) exact except where a uniform falls within fp32 rounding of a bin
+edge (counted, must be < 0.5 %, always off by one).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pita_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+T = torch.tensor
+
+
+def rel(a, b):
+    a = np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a, dtype=np.float64)
+    b = np.asarray(b.detach().cpu() if isinstance(b, torch.Tensor) else b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def pa():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import pita_amd
+
+    pita_amd._lib.lib()  # fail loudly if the HIP library is missing
+    return pita_amd
+
+
+def cu(a):
+    return torch.as_tensor(np.asarray(a), dtype=torch.float32).cuda()
+
+
+# ------------------------------------------------------------------------------- energies
+@pytest.mark.parametrize("n", [13, 55])
+def test_lj_golden(pa, golden, n):
+    g = golden(f"lj{n}_logp_force.npz")
+    nphys = int(g["n_cold"]) + int(g["n_warm"])
+    x = cu(g["x"])
+    for Tk in (1.0, 2.0, 4.0):
+        e = pa.LennardJonesEnergy(3 * n, n, 3, temperature=Tk)
+        lp = e(x)
+        lp2, f = e(x, return_force=True)
+        assert torch.equal(lp, lp2)
+        np.testing.assert_allclose(lp.cpu().numpy()[:nphys], g[f"logp_T{Tk}"][:nphys], rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(lp.cpu().numpy()[nphys:], g[f"logp_T{Tk}"][nphys:], rtol=2e-5)  # |E| ~ 1e6+
+        assert rel(f[:nphys], g[f"force_T{Tk}"][:nphys]) < 1e-5
+        assert rel(f[nphys:], g[f"force_T{Tk}"][nphys:]) < 1e-4
+    e = pa.LennardJonesEnergy(3 * n, n, 3, temperature=1.0, energy_factor=0.5)
+    lp, f = e(x, return_force=True)
+    np.testing.assert_allclose(lp.cpu().numpy()[:nphys], g["logp_ef0.5"][:nphys], rtol=1e-5)
+    assert rel(f[:nphys], g["force_ef0.5"][:nphys]) < 1e-5
+
+
+def test_lj_vs_oracle_random_and_edges(pa):
+    gen = torch.Generator().manual_seed(3)
+    for n, B in ((13, 1000), (13, 1), (13, 19), (13, 20), (55, 37)):
+        x = torch.randn(B, 3 * n, generator=gen) * 0.6 + torch.linspace(-2, 2, 3 * n)[None]
+        lp_o, f_o = O.lj_logp_force(x.double(), n, 3, temperature=1.5)
+        e = pa.LennardJonesEnergy(3 * n, n, 3, temperature=1.5)
+        lp, f = e(x.cuda(), return_force=True)
+        np.testing.assert_allclose(lp.cpu().numpy(), lp_o.numpy(), rtol=2e-5)
+        assert rel(f, f_o) < 2e-5
+    e = pa.LennardJonesEnergy(39, 13, 3)
+    lp, f = e(torch.empty(0, 39).cuda(), return_force=True)  # empty batch
+    assert lp.shape == (0,) and f.shape == (0, 39)
+    with pytest.raises(pa._lib.PitaHipError):
+        e(torch.zeros(4, 39))  # CPU tensor: no fallback, must fail loudly
+
+
+def test_dw4_vs_oracle(pa):
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(513, 8, generator=gen) * 2.5
+    lp_o, f_o = O.dw4_logp_force(x.double(), temperature=2.0)
+    e = pa.MultiDoubleWellEnergy(temperature=2.0)
+    lp, f = e(x.cuda(), return_force=True)
+    np.testing.assert_allclose(lp.cpu().numpy(), lp_o.numpy(), rtol=1e-5, atol=1e-5)
+    assert rel(f, f_o) < 1e-5
+
+
+def test_gmm_golden(pa, golden):
+    g = golden("gmm40.npz")
+    x = cu(g["x"])
+    for Tk in (1.0, 2.0):
+        e = pa.GMM(temperature=Tk)
+        np.testing.assert_array_equal(e.locs.cpu().numpy(), g["means"])
+        np.testing.assert_allclose(e(x).cpu().numpy(), g[f"logp_T{Tk}"], rtol=3e-6, atol=3e-5)
+    lp, grad = pa.GMM()(x, return_force=True)
+    np.testing.assert_allclose(grad.cpu().numpy(), g["grad_T1.0"], rtol=3e-5, atol=2e-5)
+
+
+# ------------------------------------------------------------------------------- EGNN
+def make_net(pa, n, d, weights, temp=True, **kw):
+    if temp:
+        net = pa.EGNN_dynamics(n, d, hidden_nf=32, n_layers=3, recurrent=True, tanh=True, attention=True,
+                               condition_time=True, condition_temperature=True, agg="sum", **kw)
+    else:
+        from pita_amd import egnn
+
+        net = egnn.EGNN_dynamics(n, d, hidden_nf=32, n_layers=3, recurrent=True, tanh=True, attention=True,
+                                 condition_time=True, agg="sum")
+    net.load_state_dict({k: T(v) for k, v in weights.items()})
+    return net
+
+
+@pytest.mark.parametrize("name", ["lj13", "dw4", "lj55"])
+@pytest.mark.parametrize("tag,wfile", [("init", "egnn_weights_seed12345.npz"), ("trained", "egnn_weights_trainedlike.npz")])
+def test_egnn_golden(pa, golden, name, tag, wfile):
+    g = golden(f"egnn_{name}_fwd.npz")
+    w = golden(wfile)
+    n, d = int(g["n"]), int(g["d"])
+    net = make_net(pa, n, d, w)
+    x, h, beta = cu(g["x"]), cu(g["h"]), cu(g["beta"])
+    c_s, c_in, c_out, c_noise = O.edm_coeffs(T(g["h"]))
+    F = net(c_noise.cuda(), (c_in[:, None] * T(g["x"])).cuda(), beta)
+    # the reference's own fp32 error, measured against the fp64 oracle on the same inputs
+    wd = {k: T(v) for k, v in w.items()}
+    F64 = O.egnn_forward(wd, c_noise.double(), (c_in[:, None] * T(g["x"])).double(), T(g["beta"]).double(), n, d)
+    err_ref = rel(g[f"F_{tag}"], F64)
+    err_hip = rel(F, F64)
+    assert err_hip < max(4 * err_ref, 2e-6), (err_hip, err_ref)
+    assert rel(F, g[f"F_{tag}"]) < max(2e-5, 6 * err_ref)
+    sn = pa.ScoreNet(net)
+    assert rel(sn.denoiser(h, x, beta), g[f"D_{tag}"]) < 2e-6
+    sc = sn(h, x, beta).cpu().numpy()
+    for hv in np.unique(g["h"]):
+        m = g["h"] == hv
+        tol = 1e-4 if hv > 0.05 else 5e-3  # (D - x)/h amplifies fp32 rounding by 1/h
+        assert rel(sc[m], g[f"score_{tag}"][m]) < tol, hv
+
+
+def test_egnn_notemp_and_layouts(pa, golden):
+    g = golden("egnn_notemp_lj13_fwd.npz")
+    w = {k[2:]: v for k, v in g.items() if k.startswith("w.")}
+    net = make_net(pa, 13, 3, w, temp=False)
+    out = net(cu(g["t"]), cu(g["x"]))
+    assert rel(out, g["out"]) < 1e-4  # fresh-init velocities are ~1e-4 |x| (cancellation)
+    # feature_layout="correct": (t, beta) on every node == oracle with the un-quirked features
+    w2 = golden("egnn_weights_trainedlike.npz")
+    netc = make_net(pa, 13, 3, w2, feature_layout="correct")
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(9, 39, generator=gen)
+    t, b = torch.randn(9, generator=gen), torch.rand(9, generator=gen) + 0.5
+    out = netc(t.cuda(), x.cuda(), b.cuda())
+    assert torch.isfinite(out).all()
+    assert abs(out.reshape(9, 13, 3).mean(1)).max() < 1e-5  # mean-free output
+
+
+@pytest.mark.parametrize("B", [1, 6, 7, 8, 100, 1001])
+def test_egnn_batch_edges(pa, golden, B):
+    """ragged batches: B not a multiple of the 7-walker wave group, single walker, etc."""
+    w = golden("egnn_weights_trainedlike.npz")
+    net = make_net(pa, 13, 3, w)
+    gen = torch.Generator().manual_seed(B)
+    x = torch.randn(B, 39, generator=gen) * 1.2
+    t = torch.randn(B, generator=gen) * 0.5
+    b = torch.rand(B, generator=gen) * 2 + 0.5
+    ref = O.egnn_forward({k: T(v) for k, v in w.items()}, t, x, b, 13, 3)
+    out = net(t.cuda(), x.cuda(), b.cuda())
+    assert rel(out, ref) < 2e-5
+
+
+# ------------------------------------------------------------------------------- MLP
+def test_mlp_golden(pa, golden):
+    from pita_amd import mlp
+
+    g = golden("mlp_gmm_fwd.npz")
+    net = mlp.MyMLP(hidden_size=128, hidden_layers=3, emb_size=128, out_dim=2, input_dim=2)
+    net.load_state_dict({k[2:]: T(v) for k, v in g.items() if k.startswith("w.")})
+    x, h = T(g["x"]), T(g["h"])
+    c_s, c_in, c_out, c_noise = O.edm_coeffs(h)
+    F = net(c_noise.cuda(), (c_in[:, None] * x).cuda(), torch.ones(64).cuda())
+    assert rel(F, g["F"]) < 2e-5
+    sc = pa.ScoreNet(net)(h.cuda(), x.cuda(), 1.0).cpu().numpy()
+    big = g["h"] > 1e-2
+    assert rel(sc[big], g["score"][big]) < 2e-4
+    g2 = golden("mlp_temp_fwd.npz")
+    net2 = mlp.MyMLPTemperature(hidden_size=64, hidden_layers=2, emb_size=64, out_dim=3, input_dim=3)
+    net2.load_state_dict({k[2:]: T(v) for k, v in g2.items() if k.startswith("w.")})
+    y = net2(cu(g2["t"]), cu(g2["x"]), cu(g2["beta"]))
+    assert rel(y, g2["out"]) < 2e-5
+    # ragged batch / plug-in path through the integrator (config C1: GMM target, MLP score net)
+    gt = golden("em_traj_gmm_mlp.npz")
+    sched = pa.ElucidatingNoiseSchedule(sigma_min=0.01, sigma_max=80.0, rho=7)
+    sde = pa.VEReverseSDE(noise_schedule=sched, score_net=pa.ScoreNet(net), debias_inference=False)
+    N = int(gt["N"])
+    integ = pa.WeightedSDEIntegrator(sde=sde, num_integration_steps=N, start_resampling_step=0, end_resampling_step=N,
+                                     resampling_interval=-1, num_negative_time_steps=0, post_mcmc_steps=0,
+                                     should_mean_free=False, record_terms=True)
+    xf, logw, uniq, terms, acc = integ.integrate_sde(cu(gt["x1"]), pa.GMM(), pa.ConstantAnnealingFactorSchedule(1.0),
+                                                     inverse_temperature=1.0, noise=cu(gt["noise"]))
+    assert rel(terms[0].drift_X, gt["drift_X"][0]) < 1e-4
+    assert rel(xf, gt["x_final"]) < 1e-2
+
+
+# ------------------------------------------------------------------------------- sampler
+def lj13_stack(pa, golden, **kw):
+    w = golden("egnn_weights_trainedlike.npz")
+    net = make_net(pa, 13, 3, w).cuda()
+    sched = pa.ElucidatingNoiseSchedule(sigma_min=0.05, sigma_max=80.0, rho=7)
+    sde = pa.VEReverseSDE(noise_schedule=sched, score_net=pa.ScoreNet(net), energy_net=None, debias_inference=False)
+    return sde, sched, net
+
+
+def test_traj_golden_fused_and_stepwise(pa, golden):
+    g = golden("em_traj_lj13_nodebias.npz")
+    sde, sched, net = lj13_stack(pa, golden)
+    N = int(g["N"])
+    gam = pa.ConstantAnnealingFactorSchedule(4 / 3)
+    e = pa.LennardJonesEnergy(39, 13, 3)
+    noise = cu(g["noise"])
+    outs = {}
+    for rec in (False, True):
+        integ = pa.WeightedSDEIntegrator(sde=sde, num_integration_steps=N, start_resampling_step=0,
+                                         end_resampling_step=N, resampling_interval=-1, num_negative_time_steps=0,
+                                         post_mcmc_steps=0, batch_size=16, record_terms=rec)
+        x, logw, uniq, terms, acc = integ.integrate_sde(cu(g["x1"]), e, gam, inverse_temperature=1.0, noise=noise)
+        outs[rec] = x
+        assert rel(x, g["x_final"]) < 2e-4
+        assert logw.shape == (N, 32) and float(logw.abs().max()) == 0 and uniq == [32] * N and acc == []
+        if rec:
+            assert len(terms) == N
+            assert rel(terms[0].drift_X, g["drift_X"][0]) < 1e-4  # per-step drift at identical inputs
+            for k in range(N):
+                assert rel(terms[k].drift_X, g["drift_X"][k]) < 3e-3, k
+    assert rel(outs[False], outs[True]) < 1e-5  # fused launch == per-step launches
+    # drift_out of the fused kernel, one step from the golden state
+    tab = pa.sde_integration.build_step_table(sched, gam, torch.linspace(1.0, 0.0, N + 1)[:-1], 1.0 / N, 1.0, 1.0)
+    x = cu(g["x1"]).clone()
+    drift = torch.empty_like(x)
+    net.sampler_run(x, tab[:1].cuda().contiguous(), 1, noise=noise[:1].contiguous(), drift_out=drift)
+    assert rel(drift, g["drift_X"][0]) < 1e-4
+
+
+def test_sampler_sharding_invariance_and_determinism(pa, golden):
+    """Philox noise is keyed by the global walker index: integrating two half batches with the
+    right walker_offset reproduces the full batch bit for bit; reruns are bitwise identical."""
+    sde, sched, net = lj13_stack(pa, golden)
+    N, B = 12, 4096 + 5
+    gam = pa.ConstantAnnealingFactorSchedule(4 / 3)
+    tab = pa.sde_integration.build_step_table(sched, gam, torch.linspace(1.0, 0.0, N + 1)[:-1], 1.0 / N, 1.0, 1.0).cuda()
+    prior = pa.Prior(scale=69.28, n_particles=13, spatial_dim=3, seed=5)
+    x0 = prior.sample(B)
+    assert abs(x0.reshape(B, 13, 3).mean(1)).max() < 1e-4
+    a = net.sampler_run(x0.clone(), tab, N, seed=11)
+    b = net.sampler_run(x0.clone(), tab, N, seed=11)
+    assert torch.equal(a, b)
+    h = 2003
+    c0 = net.sampler_run(x0[:h].clone(), tab, N, seed=11, walker_offset=0)
+    c1 = net.sampler_run(x0[h:].clone(), tab, N, seed=11, walker_offset=h)
+    assert torch.equal(torch.cat([c0, c1]), a)
+    # chunking the steps over launches is also exact (step0 keys the noise)
+    d = net.sampler_run(x0.clone(), tab[:5].contiguous(), 5, seed=11, step0=0)
+    d = net.sampler_run(d, tab[5:].contiguous(), N - 5, seed=11, step0=5)
+    assert torch.equal(d, a)
+    assert abs(a.reshape(B, 13, 3).mean(1)).max() < 1e-4 and torch.isfinite(a).all()
+    assert not torch.equal(net.sampler_run(x0.clone(), tab, N, seed=12), a)
+
+
+def test_philox_normals(pa):
+    out = torch.empty(200000, 39, device="cuda")
+    pa._lib.check(pa._lib.lib().pita_fill_normal(out.data_ptr(), 200000, 13, 3, 42, 0, 7, pa._lib.stream_ptr()))
+    v = out.double()
+    assert abs(v.mean().item()) < 2e-3 and abs(v.std().item() - 1) < 2e-3
+    assert abs((v**4).mean().item() - 3) < 3e-2  # kurtosis
+    assert abs(torch.corrcoef(v[:, :4].T)[0, 1].item()) < 1e-2
+
+
+def test_elementwise_vs_oracle(pa, golden):
+    g = golden("prior.npz")
+    for n, d in ((13, 3), (4, 2)):
+        nz = cu(g[f"noise_{n}"])
+        p = pa.Prior(scale=float(g["scale"]), n_particles=n, spatial_dim=d)
+        np.testing.assert_allclose(p.sample(16, noise=nz).cpu().numpy(), g[f"sample_{n}"], rtol=1e-6, atol=2e-5)
+        np.testing.assert_allclose(pa.data_utils.remove_mean(nz, n, d).cpu().numpy(), g[f"remove_mean_{n}"],
+                                   rtol=1e-6, atol=1e-6)
+    gen = torch.Generator().manual_seed(1)
+    x, dr, nz = (torch.randn(777, 39, generator=gen) for _ in range(3))
+    xo = O.remove_mean(x + (dr * 0.05 + (1.7 * nz) * np.sqrt(0.05)), 13, 3)
+    xc, drc, nzc = x.cuda().clone(), dr.cuda(), nz.cuda()  # keep the device copies alive across the async call
+    L = pa._lib.lib()
+    pa._lib.check(L.pita_em_step(xc.data_ptr(), drc.data_ptr(), nzc.data_ptr(), 777, 13, 3, 0.05, 1.7,
+                                 float(np.sqrt(0.05)), 0, 0, 0, 1, pa._lib.stream_ptr()))
+    np.testing.assert_allclose(xc.cpu().numpy(), xo.numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("case", ["normal", "ties", "peaked", "neginf", "huge", "big"])
+def test_resample_golden(pa, golden, case):
+    g = golden("resample_sys.npz")
+    logits = cu(g[f"logits_{case}"])
+    ids, _ = pa.utils.sample_cat_sys(logits.shape[0], logits, u=float(g[f"u_{case}"][0]))
+    ids = ids.cpu().numpy()
+    want = g[f"ids_{case}"]
+    bad = ids != want
+    assert bad.mean() < 5e-3 and (np.abs(ids[bad] - want[bad]) <= 1).all(), (bad.sum(), len(ids))
+    assert (np.diff(ids) >= 0).sum() >= len(ids) - 2  # sorted up to the single wrap of (u0 + k/B) mod 1
+    x = torch.arange(logits.shape[0] * 3, dtype=torch.float32, device="cuda").reshape(-1, 3)
+    got = pa.utils.gather_rows(x, torch.as_tensor(want).cuda())
+    assert torch.equal(got, x[torch.as_tensor(want).cuda()])
+
+
+def test_post_processing_golden(pa, golden):
+    g = golden("post_lj13.npz")
+    e = pa.LennardJonesEnergy(39, 13, 3)
+    mk = lambda **kw: pa.WeightedSDEIntegrator(sde=None, num_integration_steps=1, start_resampling_step=0,
+                                               end_resampling_step=1, **kw)
+    x0 = cu(g["x0"])
+    xd = mk(num_negative_time_steps=25, dt_negative_time=1e-4).negative_time_descent(x0, e)
+    assert rel(xd, g["x_descent"]) < 1e-5
+    xl = mk(num_negative_time_steps=10, dt_negative_time=1e-4, do_langevin=True).negative_time_descent(
+        x0, e, noise=cu(g["langevin_noise"]))
+    assert rel(xl, g["x_langevin"]) < 1e-5
+    xm, acc = mk(post_mcmc_steps=6, dt_negative_time=4e-4).metropolis_hastings_mala(
+        x0, e, return_acceptance_rate=True, noise=cu(g["mala_noise"]), uniforms=cu(g["mala_u"]))
+    np.testing.assert_allclose(acc, g["mala_acc"], atol=1e-7)
+    assert rel(xm, g["x_mala"]) < 1e-5
+    xa, acc = mk(post_mcmc_steps=6, dt_negative_time=4e-4, adaptive_mcmc=True).metropolis_hastings_mala_adaptive(
+        x0, e, dt_init=4e-4, return_acceptance_rate=True, noise=cu(g["mala_adaptive_noise"]),
+        uniforms=cu(g["mala_adaptive_u"]))
+    np.testing.assert_allclose(acc, g["mala_adaptive_acc"], atol=1e-7)
+    assert rel(xa, g["x_mala_adaptive"]) < 1e-5
+
+
+# ------------------------------------------------------------------------------- full size (BASELINE configs)
+def test_full_size_lj13_properties(pa, golden):
+    """LJ13 @ 65 536 walkers (config C3): size-independent properties of the force kernel and of
+    the sampler -- force is the gradient of logp (directional finite difference in fp64 oracle on a
+    sample), translation invariance of logp's pair part, permutation equivariance, mean-free."""
+    B = 65536
+    gen = torch.Generator().manual_seed(123)
+    base = T(golden("lj13_logp_force.npz")["x"][:48])
+    x = (base[torch.randint(0, 48, (B,), generator=gen)] + 0.03 * torch.randn(B, 39, generator=gen)).cuda()
+    e = pa.LennardJonesEnergy(39, 13, 3)
+    lp, f = e(x, return_force=True)
+    assert torch.isfinite(lp).all() and torch.isfinite(f).all()
+    idx = torch.randint(0, B, (256,), generator=gen)
+    lpo, fo = O.lj_logp_force(x[idx.cuda()].cpu().double(), 13, 3)
+    np.testing.assert_allclose(lp[idx.cuda()].cpu().numpy(), lpo.numpy(), rtol=1e-5)
+    assert rel(f[idx.cuda()], fo) < 1e-5
+    # total force on the centre of mass is zero (pair forces cancel, oscillator is mean-free)
+    assert abs(f.reshape(B, 13, 3).sum(1)).max() < 2e-2
+    # permutation of particles permutes forces and keeps logp
+    perm = torch.randperm(13, generator=gen)
+    xp = x.reshape(B, 13, 3)[:, perm.cuda()].reshape(B, 39).contiguous()
+    lpp, fp = e(xp, return_force=True)
+    np.testing.assert_allclose(lpp.cpu().numpy(), lp.cpu().numpy(), rtol=2e-5, atol=3e-5)
+    assert rel(fp, f.reshape(B, 13, 3)[:, perm.cuda()].reshape(B, 39)) < 1e-5
