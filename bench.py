@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- walker-steps/s of the fused HIP annealed-SDE sampler (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): LJ13
+(13 particles x 3D), EGNN score net (hidden 32 x 3 layers, tanh, attention, temperature
+conditioned; seed-12345 initialisation, i.e. the reference's own untrained init), Elucidating
+schedule (sigma_min 0.05, sigma_max 80, rho 7), gamma = 4/3, beta = 1, diffusion_scale 1,
+NOT-debiased reverse VE-SDE, resampling off, 65 536 walkers PER GPU (weak scaling), synthetic
+walkers from the mean-free prior.  One "step" = one Euler-Maruyama step of all walkers:
+EDM-preconditioned EGNN forward + drift + noise + update + remove_mean, all inside the fused
+kernel `egnn_kernel<13,3,7,4>`; the K timed steps run as K/c launches of c = gcd(K, W) steps each
+(the warm-up uses the same launch size so every launch of the kernel in this process is equal
+and the rocprof average is comparable).  After the timed region a separately timed loop of LJ13
+log-density+force evaluations gives the HBM roofline of the pairwise-force kernel.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_WALKER_STEP = 4.197e6   # EGNN forward h32x3, LJ13 (2 x 2 098 304 MAC)
+LJ13_BYTES_PER_EVAL = 316        # read x (39 f32) + write force (39) + logp (1)
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def build_model(pa, seed=12345):
+    torch.manual_seed(seed)
+    net = pa.EGNN_dynamics(13, 3, hidden_nf=32, n_layers=3, recurrent=True, tanh=True, attention=True,
+                           condition_time=True, condition_temperature=True, agg="sum")
+    return net
+
+
+def cpu_baseline(n_walkers, n_steps, seed=12345):
+    """The oracle (torch-CPU restatement of the reference's sampler, kind = "port") timed on this
+    host's cores on a bounded sample of the same workload."""
+    from oracle import pita_oracle as O
+
+    torch.manual_seed(seed)
+    import pita_amd
+
+    net = build_model(pita_amd, seed)
+    w = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    bb = lambda cn, xs, b: O.egnn_forward(w, cn, xs, b, 13, 3)
+    sched, gam = O.Elucidating(0.05, 80.0, 7), O.GammaConstant(4 / 3)
+    gen = torch.Generator().manual_seed(1)
+    x1 = O.prior_from_noise(torch.randn(n_walkers, 39, generator=gen), O.prior_scale(sched, gam, 1.0), 13, 3)
+    cfg = O.IntegratorConfig(num_integration_steps=1000, end_resampling_step=1000)
+    # time n_steps steps out of the 1000-step grid
+    cfg_run = O.IntegratorConfig(num_integration_steps=n_steps, end_resampling_step=n_steps)
+    drift = lambda t, xc: O.f_not_debiased(bb, sched, gam, t, xc, 1.0)
+    noise_fn = lambda i, shp: torch.randn(shp, generator=gen)
+    with torch.no_grad():
+        O.integrate_sde(O.IntegratorConfig(num_integration_steps=2, end_resampling_step=2), x1, drift, sched.g, noise_fn,
+                        13, 3)  # warm-up
+        t0 = time.perf_counter()
+        O.integrate_sde(cfg_run, x1, drift, sched.g, noise_fn, 13, 3)
+        dt = time.perf_counter() - t0
+    return {"value": n_walkers * n_steps / dt, "unit": "walker-steps/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"oracle integrate_sde, LJ13 EGNN h32x3, {n_walkers} walkers x {n_steps} steps, "
+            f"torch-CPU fp32, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--walkers", type=int, default=65536, help="walkers per GPU")
+    ap.add_argument("--chunk", type=int, default=0, help="SDE steps per kernel launch (default gcd(steps, warmup))")
+    ap.add_argument("--force-evals", type=int, default=200, help="LJ13 force-kernel launches for its roofline")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-walkers", type=int, default=512)
+    ap.add_argument("--cpu-steps", type=int, default=100)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=dev)
+
+    import pita_amd
+
+    pita_amd._lib.lib()  # fail loudly if the HIP library is missing
+    B, K, W = args.walkers, args.steps, args.warmup
+    chunk = args.chunk or (math.gcd(K, W) if W > 0 else K)
+    assert K % chunk == 0 and W % chunk == 0
+
+    net = build_model(pita_amd)
+    sched = pita_amd.ElucidatingNoiseSchedule(sigma_min=0.05, sigma_max=80.0, rho=7)
+    gam = pita_amd.ConstantAnnealingFactorSchedule(4 / 3)
+    NGRID = 1000  # the 1000-step time grid of the reference config; K+W steps walk along it (wrapping)
+    times = torch.linspace(1.0, 0.0, NGRID + 1)[:-1]
+    tab_h = pita_amd.sde_integration.build_step_table(sched, gam, times, 1.0 / NGRID, 1.0, 1.0)
+    idx = torch.arange(W + K) % NGRID
+    tab = tab_h[idx].contiguous().to(dev)
+    scale = float((sched.h(torch.tensor(1.0)) / gam.gamma(torch.tensor(1.0))) ** 0.5)
+    prior = pita_amd.Prior(scale=scale, n_particles=13, spatial_dim=3, device=dev, seed=12345)
+    x = prior.sample(B, walker_offset=rank * B)
+    energy = pita_amd.LennardJonesEnergy(39, 13, 3, device=dev)
+    seed = 12345
+
+    def run(s0, s1):
+        for s in range(s0, s1, chunk):
+            net.sampler_run(x, tab[s:s + chunk], chunk, seed=seed, walker_offset=rank * B, step0=s, remove_mean=True)
+
+    run(0, W)  # warm-up (also builds the native handle)
+    gathered = torch.empty(world * B, 39, device=dev) if world > 1 else None
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    n_launch = K // chunk
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_launch + 1)]
+    t0 = time.perf_counter()
+    evs[0].record()
+    for i, s in enumerate(range(W, W + K, chunk)):
+        net.sampler_run(x, tab[s:s + chunk], chunk, seed=seed, walker_offset=rank * B, step0=s, remove_mean=True)
+        evs[i + 1].record()
+    if world > 1:  # X1: the only collective of the resampling-free path
+        torch.distributed.all_gather_into_tensor(gathered, x)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    launch_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(n_launch)]
+    assert torch.isfinite(x).all(), "sampler produced non-finite walkers"
+
+    # ---- pairwise-force kernel roofline (HBM-bound), separately timed
+    force_rl = None
+    if rank == 0 and args.force_evals > 0:
+        logp, force = energy(x, return_force=True)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        L = pita_amd._lib.lib()
+        sp = pita_amd._lib.stream_ptr(dev)
+        e0.record()
+        for _ in range(args.force_evals):
+            L.pita_lj_logp_force(x.data_ptr(), logp.data_ptr(), force.data_ptr(), B, 13, 3, 1.0, 1.0, 1e-6, 1.0, 1.0, 1.0, sp)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / args.force_evals
+        gbs = B * LJ13_BYTES_PER_EVAL / (us * 1e-6) / 1e9
+        force_rl = {"kernel": "pair_energy_kernel<3,LJ> (LJ13 logp+force)", "bound": "hbm", "achieved": gbs,
+                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                    "us_per_launch": us, "walker_evals_per_s": B / (us * 1e-6), "launches": args.force_evals}
+
+    if rank == 0:
+        avg_ms = float(np.mean(launch_ms))
+        achieved = B * chunk * FLOP_PER_WALKER_STEP / (avg_ms * 1e-3) / 1e12
+        out = {
+            "metric": "walker-steps/sec (batch x T) LJ13 @ 65k walkers/GPU",
+            "value": world * B * K / elapsed,
+            "unit": "walker-steps/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": elapsed * 1e3 / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "LJ13 (13x3D) annealed reverse VE-SDE, EGNN h32x3 score net (seed-12345 init), "
+                                   "not-debiased, resampling off, Elucidating(0.05,80,7), gamma=4/3, beta=1",
+                       "walkers_per_gpu": B, "global_walkers": world * B, "steps_per_launch": chunk,
+                       "parallelism": f"walker-sharded x{world}, final all_gather only"},
+            "roofline": {"kernel": "egnn_kernel<13,3,7,4> (fused EGNN score + EM step)", "bound": "mfma",
+                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "algorithmic_flop_per_walker_step": FLOP_PER_WALKER_STEP, "ms_per_launch": avg_ms,
+                         "launches": n_launch},
+            "roofline_force": force_rl,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_walkers, args.cpu_steps)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

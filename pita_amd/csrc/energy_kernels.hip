@@ -114,6 +114,122 @@ __global__ void __launch_bounds__(256) pair_energy_kernel(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------------------- LJ13 fast path
+// LJ13 (n = 13, d = 3) with one walker per lane(-pair): coordinates are staged once in LDS (row
+// stride 39 words = odd, so the per-lane row reads are bank-conflict free and use immediate
+// offsets), the 39 force accumulators live in VGPRs, and the 78 unordered pairs are enumerated
+// at compile time as the circulant (i, i+dd mod 13), dd = 1..6, with Newton's third law (the
+// generic kernel above evaluates every ordered pair).  P = 2 wave-pairs share a walker set:
+// half 0 takes dd in {1,3,4}; half 1 runs the same code on the relabelled particles
+// k -> 2k mod 13, which maps {1,3,4} onto {2,6,8=-5}: exactly the other three circulant distances.
+// The partial force sets meet in LDS on the way to one fully coalesced float4 store.  At 65 536
+// walkers this doubles the waves per SIMD and halves the dependent VALU chain per wave.
+template <int P, int MULT>
+__device__ __forceinline__ void lj13_body(const float* __restrict__ xw, float* __restrict__ fw, float* __restrict__ e_out,
+                                          const PairParams& p, bool act, bool first) {
+  constexpr int N = 13, NDD = 6 / P;
+  constexpr int DD[2][6] = {{1, 2, 3, 4, 5, 6}, {1, 3, 4, 0, 0, 0}};
+  float fr[39];
+#pragma unroll
+  for (int q = 0; q < 39; ++q) fr[q] = 0.f;
+  float e = 0.f;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    // keep the walker's coordinates in LDS: without these fences the compiler hoists all 39 reads (plus
+    // packed-math shuffles) to the top and spills; with them the live set is the 39 force accumulators
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const int pi = ((MULT * i) % N) * 3;
+    const float xi0 = xw[pi], xi1 = xw[pi + 1], xi2 = xw[pi + 2];
+#pragma unroll
+    for (int t = 0; t < NDD; ++t) {
+      const int j = (i + DD[P - 1][t]) % N;
+      const int pj = ((MULT * j) % N) * 3;
+      const float d0 = xi0 - xw[pj], d1 = xi1 - xw[pj + 1], d2 = xi2 - xw[pj + 2];
+      const float r2 = fmaf(d2, d2, fmaf(d1, d1, fmaf(d0, d0, p.dist_eps)));
+      const float inv = __builtin_amdgcn_rcpf(r2);
+      const float s2 = p.rm2 * inv, s6 = s2 * s2 * s2;
+      e += fmaf(s6, s6, -2.0f * s6);
+      const float coef = (12.0f * fmaf(-s6, s6, s6)) * inv;
+      fr[i * 3] = fmaf(coef, d0, fr[i * 3]); fr[i * 3 + 1] = fmaf(coef, d1, fr[i * 3 + 1]); fr[i * 3 + 2] = fmaf(coef, d2, fr[i * 3 + 2]);
+      fr[j * 3] = fmaf(-coef, d0, fr[j * 3]); fr[j * 3 + 1] = fmaf(-coef, d1, fr[j * 3 + 1]); fr[j * 3 + 2] = fmaf(-coef, d2, fr[j * 3 + 2]);
+    }
+  }
+  // harmonic oscillator about the particle mean: counted once (by the first half)
+  float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < N; ++k) { m0 += xw[k * 3]; m1 += xw[k * 3 + 1]; m2 += xw[k * 3 + 2]; }
+  m0 /= (float)N; m1 /= (float)N; m2 /= (float)N;
+  const float oscw = first ? p.osc_scale : 0.f;
+  const float pair_w = 2.0f * p.energy_factor * p.eps;  // every unordered pair counts twice in the reference sum
+  float osc = 0.f;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const int pk = ((MULT * k) % N) * 3;
+    const float c0 = xw[pk] - m0, c1 = xw[pk + 1] - m1, c2 = xw[pk + 2] - m2;
+    osc = fmaf(c0, c0, fmaf(c1, c1, fmaf(c2, c2, osc)));
+    fr[k * 3] = -p.inv_T * fmaf(pair_w, fr[k * 3], oscw * c0);
+    fr[k * 3 + 1] = -p.inv_T * fmaf(pair_w, fr[k * 3 + 1], oscw * c1);
+    fr[k * 3 + 2] = -p.inv_T * fmaf(pair_w, fr[k * 3 + 2], oscw * c2);
+  }
+  // pin the results before the barrier: otherwise the compiler sinks ALL the arithmetic below it (its only
+  // users are the guarded stores) while the 39 coordinate loads must stay above -> everything spills
+#pragma unroll
+  for (int q = 0; q < 39; ++q) asm volatile("" : "+v"(fr[q]));
+  asm volatile("" : "+v"(e), "+v"(osc));
+  __syncthreads();  // all coordinate reads of the block are done: the stage may be overwritten with forces
+  if (act) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const int pk = ((MULT * k) % N) * 3;
+      fw[pk] = fr[k * 3]; fw[pk + 1] = fr[k * 3 + 1]; fw[pk + 2] = fr[k * 3 + 2];
+    }
+    *e_out = fmaf(pair_w, e, 0.5f * oscw * osc);
+  }
+}
+
+template <int P>
+__global__ void __launch_bounds__(256, 4) lj13_kernel(const float* __restrict__ x, float* __restrict__ logp,
+                                                      float* __restrict__ force, long long B, PairParams p) {
+  constexpr int D = 39, WPB = 256 / P;
+  __shared__ __attribute__((aligned(16))) float fb[P][WPB * D];  // fb[0] doubles as the coordinate stage
+  __shared__ float es[P][WPB];
+  const int tid = threadIdx.x;
+  const int half = tid / WPB, wl = tid - half * WPB;  // half is wave-uniform (WPB is a multiple of 64)
+  const long long nblk = (B + WPB - 1) / WPB;
+  for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const long long w0 = blk * WPB;
+    const int nw = (int)((B - w0) < WPB ? (B - w0) : WPB);
+    const int nfl = nw * D;
+    {  // coalesced stage-in (16 B per lane; block base is 16 B aligned because WPB % 4 == 0)
+      const float4* src4 = reinterpret_cast<const float4*>(x + w0 * D);
+      float4* dst4 = reinterpret_cast<float4*>(&fb[0][0]);
+      for (int q = tid; q < nfl / 4; q += 256) dst4[q] = src4[q];
+      for (int q = (nfl & ~3) + tid; q < nfl; q += 256) fb[0][q] = x[w0 * D + q];
+    }
+    __syncthreads();
+    const bool act = wl < nw;
+    const int row = (act ? wl : 0) * D;
+    if (P == 1 || half == 0) lj13_body<P, 1>(&fb[0][row], &fb[0][row], &es[0][wl], p, act, true);
+    else lj13_body<P, 2>(&fb[0][row], &fb[P - 1][row], &es[P - 1][wl], p, act, false);
+    __syncthreads();
+    if (force) {
+      float4* dst4 = reinterpret_cast<float4*>(force + w0 * D);
+      for (int q = tid; q < nfl / 4; q += 256) {
+        float4 v = reinterpret_cast<const float4*>(&fb[0][0])[q];
+        if (P == 2) {
+          const float4 u = reinterpret_cast<const float4*>(&fb[P - 1][0])[q];
+          v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        dst4[q] = v;
+      }
+      for (int q = (nfl & ~3) + tid; q < nfl; q += 256) force[w0 * D + q] = fb[0][q] + (P == 2 ? fb[P - 1][q] : 0.f);
+    }
+    if (tid < nw) logp[w0 + tid] = -p.inv_T * (es[0][tid] + (P == 2 ? es[P - 1][tid] : 0.f));
+    __syncthreads();
+  }
+}
+
 template <int KIND>
 static int launch_pair(const float* x, float* logp, float* force, int64_t B, int n, int d, const PairParams& p,
                        void* stream) {
@@ -198,6 +314,18 @@ extern "C" int pita_lj_logp_force(const float* x, float* logp, float* force, int
   PairParams p{};
   p.inv_T = 1.0f / temperature; p.energy_factor = energy_factor; p.dist_eps = dist_eps; p.eps = eps;
   p.rm2 = rm * rm; p.osc_scale = osc_scale;
+  if (n == 13 && d == 3 && B > 0) {
+    PITA_REQUIRE(x && logp, "pita_lj_logp_force: null argument");
+    // 2 lanes per walker while the batch cannot fill every SIMD twice with 1 lane per walker
+    const bool two = B <= 256LL * 1024;
+    const int WPB = two ? 128 : 256;
+    const long long nblk = (B + WPB - 1) / WPB;
+    const unsigned grid = (unsigned)(nblk < 256LL * 32 ? nblk : 256LL * 32);
+    if (two) hipLaunchKernelGGL(lj13_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, logp, force, (long long)B, p);
+    else hipLaunchKernelGGL(lj13_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, logp, force, (long long)B, p);
+    PITA_LAUNCH_CHECK();
+    return PITA_OK;
+  }
   return launch_pair<E_LJ>(x, logp, force, B, n, d, p, stream);
 }
 
