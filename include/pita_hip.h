@@ -89,6 +89,10 @@ typedef struct {
   float coords_range;   /* 15.0 in the reference */
   int feature_layout;   /* 0 = "pita": the reference's t/beta interleave quirk
                            (egnn_temp_conditioned.py:68-78); 1 = per-node (t, beta) */
+  int precision;        /* arithmetic of the dense layers, both fp32-accurate:
+                           0 = v_mfma_f32_32x32x2_f32 (bit-exact fp32 fmaf chains),
+                           1 = bf16 matrix pipe with an exact 3-way operand split (6 products,
+                               error <= 2^-24 |w||x|: fp32-equivalent, not bit-identical to 0) */
 } pita_egnn_config;
 
 /* `weights` is a HOST pointer to the reference state_dict flattened in its own key order:

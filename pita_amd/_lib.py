@@ -23,7 +23,7 @@ class PitaHipError(RuntimeError):
 class EgnnConfig(ctypes.Structure):
     _fields_ = [("n_particles", c_int), ("n_dim", c_int), ("hidden_nf", c_int), ("n_layers", c_int),
                 ("in_node_nf", c_int), ("attention", c_int), ("tanh", c_int), ("coords_range", c_float),
-                ("feature_layout", c_int)]
+                ("feature_layout", c_int), ("precision", c_int)]
 
 
 class MlpConfig(ctypes.Structure):

@@ -47,6 +47,7 @@ constexpr int VEC_EMB_F = 96;                    // emb_w0, emb_w1, emb_b
 constexpr int VEC_LAYER_F = V_COUNT * EH + 4;    // vectors (fragment order unless noted) + b_att (+pad)
 
 struct EgnnParams {
+  const unsigned* mats16;  // [L][M_COUNT][3][2][64][4]  bf16-split fragments (PREC 1)
   const float* mats;  // [L][M_COUNT][4][64][4]
   const float* vecs;  // [VEC_EMB_F + L*VEC_LAYER_F]
   int n_layers, in_nf, attention, tanh_on, feature_layout;
@@ -95,11 +96,113 @@ __device__ __forceinline__ f32x16 lds_vec16(const float* v) {
   return r;
 }
 
-// out[o][col] = acc[o][col] + sum_k W[o][k] in[k][col]; 16 chained v_mfma_f32_32x32x2_f32
-__device__ __forceinline__ f32x16 gemm32(const float (&wf)[16], const f32x16& in, f32x16 acc) {
+// ---- 32x32 dense layer  out[o][col] = acc[o][col] + sum_k W[o][k] in[k][col]  in two arithmetic modes.
+//
+// PREC 0: 16 chained v_mfma_f32_32x32x2_f32 -- bit-exact fp32 (k-ordered fmaf chain).  On gfx950 the
+//   f32-input MFMA runs at the fp32 VECTOR rate and (measured: SQ_VALU_MFMA_COEXEC_CYCLES = 0,
+//   MFMA-busy + VALU-active = wave residency) does not overlap with VALU work on the same SIMD.
+// PREC 1: the bf16 matrix pipe with an EXACT three-way split.  Every fp32 operand is cut by
+//   truncation into three bf16 pieces x = x1 + x2 + x3 (8+8+8 significand bits, no rounding); the six
+//   products W1X1, W1X2, W2X1, W1X3, W3X1, W2X2 (each exact in the fp32 accumulator) are summed by
+//   12 v_mfma_f32_32x32x16_bf16; the dropped terms are <= 2^-24 |w||x|, i.e. the result is
+//   fp32-equivalent (same error level as PREC 0, different rounding).  16x the MAC rate of PREC 0 and it
+//   co-executes with the VALU (activations) of the partner wave.  Weight pieces are cut on the host.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int MAT_W = 1536;  // 32-bit words per bf16-split packed matrix: [piece 3][kstep 2][lane 64][4]
+
+template <int PREC>
+struct WFrag;
+
+template <>
+struct WFrag<0> {
+  float wf[16];
+  __device__ __forceinline__ void load(const float* __restrict__ m32, const unsigned* __restrict__, int mat, int lane) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(m32 + (size_t)mat * MAT_F) + lane;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[r], in[r], acc, 0, 0, 0);
-  return acc;
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = p[q * 64];
+      wf[4 * q + 0] = v.x; wf[4 * q + 1] = v.y; wf[4 * q + 2] = v.z; wf[4 * q + 3] = v.w;
+    }
+  }
+  __device__ __forceinline__ f32x16 mul(const f32x16& in, f32x16 acc) const {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[r], in[r], acc, 0, 0, 0);
+    return acc;
+  }
+};
+
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+template <>
+struct WFrag<1> {
+  u32x4 w[3][2];  // [piece][k-step], 8 bf16 each
+  __device__ __forceinline__ void load(const float* __restrict__, const unsigned* __restrict__ m16, int mat, int lane) {
+    const u32x4* p = reinterpret_cast<const u32x4*>(m16 + (size_t)mat * MAT_W) + lane;
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) w[pc][st] = p[(pc * 2 + st) * 64];
+  }
+  __device__ __forceinline__ f32x16 mul(const f32x16& in, f32x16 acc) const {
+    u32x4 x[3][2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned a = __float_as_uint(in[8 * st + 2 * q]), b = __float_as_uint(in[8 * st + 2 * q + 1]);
+        const unsigned a1 = a & 0xFFFF0000u, b1 = b & 0xFFFF0000u;
+        const unsigned ar = __float_as_uint(__uint_as_float(a) - __uint_as_float(a1));  // exact
+        const unsigned br = __float_as_uint(__uint_as_float(b) - __uint_as_float(b1));
+        const unsigned a2 = ar & 0xFFFF0000u, b2 = br & 0xFFFF0000u;
+        const unsigned a3 = __float_as_uint(__uint_as_float(ar) - __uint_as_float(a2));  // exact; truncated on packing
+        const unsigned b3 = __float_as_uint(__uint_as_float(br) - __uint_as_float(b2));
+        x[0][st][q] = __builtin_amdgcn_perm(b1, a1, 0x07060302u);  // {hi16(b), hi16(a)}
+        x[1][st][q] = __builtin_amdgcn_perm(b2, a2, 0x07060302u);
+        x[2][st][q] = __builtin_amdgcn_perm(b3, a3, 0x07060302u);
+      }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {  // smallest terms first
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w[2][st]), as_bf16x8(x[0][st]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w[0][st]), as_bf16x8(x[2][st]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w[1][st]), as_bf16x8(x[1][st]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w[1][st]), as_bf16x8(x[0][st]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w[0][st]), as_bf16x8(x[1][st]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w[0][st]), as_bf16x8(x[0][st]), acc, 0, 0, 0);
+    }
+    return acc;
+  }
+};
+
+// ---- packed fp32 helpers.  Measured on gfx950: a wave64 VALU instruction occupies its SIMD's issue for 4 cycles
+// (8 for v_exp/v_rcp) whether it is v_mul_f32 or v_pk_mul_f32, so packed math (2 lanes-worth of fp32 per
+// instruction) halves the issue cost of every mul/add/fma around the transcendentals.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 silu2(f32x2 v) {
+  const f32x2 t = v * -1.44269504088896341f;
+  f32x2 e;
+  e.x = __builtin_amdgcn_exp2f(t.x);
+  e.y = __builtin_amdgcn_exp2f(t.y);
+  const f32x2 d = e + 1.0f;
+  f32x2 r;
+  r.x = __builtin_amdgcn_rcpf(d.x);
+  r.y = __builtin_amdgcn_rcpf(d.y);
+  return v * r;
+}
+__device__ __forceinline__ void silu16(f32x16& m) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const f32x2 y = silu2(f32x2{m[2 * q], m[2 * q + 1]});
+    m[2 * q] = y.x;
+    m[2 * q + 1] = y.y;
+  }
+}
+__device__ __forceinline__ float dot16(const f32x16& w, const f32x16& m) {
+  f32x2 acc = {0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    acc = __builtin_elementwise_fma(f32x2{w[2 * q], w[2 * q + 1]}, f32x2{m[2 * q], m[2 * q + 1]}, acc);
+  return acc.x + acc.y;
 }
 
 __device__ __forceinline__ float xhalf_sum(float v) {
@@ -121,7 +224,7 @@ struct EgnnCfg {
   }
 };
 
-template <int N, int DIM, int G, int WAVES>
+template <int N, int DIM, int G, int WAVES, int PREC>
 __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
   using C = EgnnCfg<N, DIM, G, WAVES>;
   constexpr int NT = C::NT;
@@ -142,9 +245,17 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
   float* pos0 = posbuf1 + C::POS_F;
   const float* vemb = lds;
 
-  const long long ngroups = (p.B + G - 1) / G;
-  for (long long grp = (long long)blockIdx.x * WAVES + wave; grp < ngroups; grp += (long long)gridDim.x * WAVES) {
-    const long long walker0 = grp * G;
+  // Work split: every wave gets the same contiguous quota of walkers (65 536 walkers on 2 048 resident waves =
+  // 32 each) and cuts it into groups of at most G walkers (7,7,7,7,4): all waves finish together instead of a
+  // ragged last round of whole groups.  Results do not depend on the grouping (tested bitwise).
+  const long long total_waves = (long long)gridDim.x * WAVES;
+  const long long quota = (p.B + total_waves - 1) / total_waves;
+  const long long wbeg = ((long long)blockIdx.x * WAVES + wave) * quota;
+  const long long wend = (wbeg + quota < p.B) ? wbeg + quota : p.B;
+  for (long long walker0 = wbeg; walker0 < wend; walker0 += G) {
+    const int nwalk = (int)((wend - walker0) < G ? (wend - walker0) : G);
+    const int ncol = nwalk * N;              // live columns of this group
+    const int ntile = (ncol + 31) >> 5;      // live column tiles (uniform)
     // ---- per-column bookkeeping
     int col[NT], nodei[NT];
     bool valid[NT];
@@ -156,7 +267,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
       int w = col[T] / N;
       nodei[T] = col[T] - w * N;
       wid[T] = walker0 + w;
-      valid[T] = (col[T] < C::NCOL) && (wid[T] < p.B);
+      valid[T] = (col[T] < ncol);
       if (!valid[T]) wid[T] = p.B - 1;  // clamp for safe (unused) parameter loads
       const float* src = (p.mode == 3 ? p.x : p.x_in);
 #pragma unroll
@@ -228,16 +339,18 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
       float* posnext = posbuf1;
       for (int l = 0; l < L; ++l) {
         const float* mats = p.mats + (size_t)l * M_COUNT * MAT_F;
+        const unsigned* mats16 = p.mats16 + (size_t)l * M_COUNT * MAT_W;
         const float* vl = lds + VEC_EMB_F + l * VEC_LAYER_F + hh * 16;
         const bool last = (l == L - 1);
         // ---- partner table PB[col] = Wb h_col
         {
-          float wb[16];
-          load_frag(mats + M_WB * MAT_F, lane, wb);
+          WFrag<PREC> wb;
+          wb.load(mats, mats16, M_WB, lane);
 #pragma unroll
           for (int T = 0; T < NT; ++T) {
+            if (T >= ntile) continue;
             f32x16 z = {0};
-            f32x16 pb = gemm32(wb, hfeat[T], z);
+            f32x16 pb = wb.mul(hfeat[T], z);
             f32x4* dst = reinterpret_cast<f32x4*>(PB + col[T] * PBS + hh * 16);
             dst[0] = f32x4{pb[0], pb[1], pb[2], pb[3]};
             dst[1] = f32x4{pb[4], pb[5], pb[6], pb[7]};
@@ -247,21 +360,22 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
         }
         wave_lds_fence();
 
-        float w2f[16], wc1f[16];
-        load_frag(mats + M_W2 * MAT_F, lane, w2f);
-        load_frag(mats + M_WC1 * MAT_F, lane, wc1f);
+        WFrag<PREC> w2f, wc1f;
+        w2f.load(mats, mats16, M_W2, lane);
+        wc1f.load(mats, mats16, M_WC1, lane);
         // A operand of the extra k-step that adds w_r*radial + w_e*edge_attr: A[out][k] = (w_r | w_e)
         const float a_re = lds[VEC_EMB_F + l * VEC_LAYER_F + V_WRE * EH + lane];
         const float b_att = lds[VEC_EMB_F + l * VEC_LAYER_F + V_COUNT * EH];
 
 #pragma unroll
         for (int T = 0; T < NT; ++T) {
+          if (T >= ntile) continue;
           // own first-layer term  Ai = Wa h_i + b1
           f32x16 Ai;
           {
-            float wa[16];
-            load_frag(mats + M_WA * MAT_F, lane, wa);
-            Ai = gemm32(wa, hfeat[T], lds_vec16(vl + V_B1 * EH));
+            WFrag<PREC> wa;
+            wa.load(mats, mats16, M_WA, lane);
+            Ai = wa.mul(hfeat[T], lds_vec16(vl + V_B1 * EH));
           }
           f32x16 agg = {0};
           float xacc[DIM];
@@ -273,7 +387,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
             asm volatile("" ::: "memory");  // keep the per-edge LDS vector loads inside the loop (VGPR budget)
             int j = nodei[T] + dd;
             j = (j >= N) ? j - N : j;
-            const int cj = (col[T] < C::NCOL) ? cbase + j : col[T];
+            const int cj = (col[T] < ncol) ? cbase + j : col[T];
             // geometry (coord2radial :348-356; edge_attr :79)
             float df[DIM], radial = 0.f, ea = 0.f;
 #pragma unroll
@@ -286,28 +400,18 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
             // edge MLP layer 1 (:232-237,:270-271): Wa h_i + Wb h_j + b1, then one k-step [w_r|w_e]·[radial;ea]
             f32x16 m = Ai + lds_vec16(PB + cj * PBS + hh * 16);
             m = __builtin_amdgcn_mfma_f32_32x32x2f32(a_re, hh ? ea : radial, m, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) m[r] = fast_silu(m[r]);
-            m = gemm32(w2f, m, lds_vec16(vl + V_B2 * EH));
-#pragma unroll
-            for (int r = 0; r < 16; ++r) m[r] = fast_silu(m[r]);
+            silu16(m);
+            m = w2f.mul(m, lds_vec16(vl + V_B2 * EH));
+            silu16(m);
             if (p.attention) {  // :259-260,:273-275
-              const f32x16 v_watt = lds_vec16(vl + V_WATT * EH);
-              float part = 0.f;
-#pragma unroll
-              for (int r = 0; r < 16; ++r) part = fmaf(v_watt[r], m[r], part);
-              const float att = fast_sigmoid(xhalf_sum(part) + b_att);
-#pragma unroll
-              for (int r = 0; r < 16; ++r) m[r] *= att;
+              const float att = fast_sigmoid(xhalf_sum(dot16(lds_vec16(vl + V_WATT * EH), m)) + b_att);
+              m *= att;
             }
             if (!last) agg += m;  // node_model aggregation (:284)
             // coordinate head (:245-256,:297-298)
-            f32x16 c1 = gemm32(wc1f, m, lds_vec16(vl + V_BC1 * EH));
-            const f32x16 v_wc2 = lds_vec16(vl + V_WC2 * EH);
-            float part = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) part = fmaf(v_wc2[r], fast_silu(c1[r]), part);
-            float cs = xhalf_sum(part);
+            f32x16 c1 = wc1f.mul(m, lds_vec16(vl + V_BC1 * EH));
+            silu16(c1);
+            float cs = xhalf_sum(dot16(lds_vec16(vl + V_WC2 * EH), c1));
             if (p.tanh_on) cs = accurate_tanh(cs) * p.coord_scale;
             const float nrm = sqrtf(radial + 1e-8f) + 1.0f;
 #pragma unroll
@@ -320,15 +424,14 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
             if (hh == 0) posnext[col[T] * DIM + k] = posi[T][k];
           }
           if (!last) {  // node model (:239-243,:284-291), recurrent
-            float wn[16];
-            load_frag(mats + M_WN1A * MAT_F, lane, wn);
-            f32x16 n1 = gemm32(wn, hfeat[T], lds_vec16(vl + V_BN1 * EH));
-            load_frag(mats + M_WN1B * MAT_F, lane, wn);
-            n1 = gemm32(wn, agg, n1);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) n1[r] = fast_silu(n1[r]);
-            load_frag(mats + M_WN2 * MAT_F, lane, wn);
-            f32x16 o = gemm32(wn, n1, lds_vec16(vl + V_BN2 * EH));
+            WFrag<PREC> wn;
+            wn.load(mats, mats16, M_WN1A, lane);
+            f32x16 n1 = wn.mul(hfeat[T], lds_vec16(vl + V_BN1 * EH));
+            wn.load(mats, mats16, M_WN1B, lane);
+            n1 = wn.mul(agg, n1);
+            silu16(n1);
+            wn.load(mats, mats16, M_WN2, lane);
+            f32x16 o = wn.mul(n1, lds_vec16(vl + V_BN2 * EH));
             hfeat[T] += o;
           }
         }
@@ -349,7 +452,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
       wave_lds_fence();
 #pragma unroll
       for (int T = 0; T < NT; ++T) {
-        const int cb = (col[T] < C::NCOL) ? col[T] - nodei[T] : 0;
+        const int cb = (col[T] < ncol) ? col[T] - nodei[T] : 0;
 #pragma unroll
         for (int k = 0; k < DIM; ++k) {
           float s = 0.f;
@@ -399,7 +502,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
           wave_lds_fence();
 #pragma unroll
           for (int T = 0; T < NT; ++T) {
-            const int cb = (col[T] < C::NCOL) ? col[T] - nodei[T] : 0;
+            const int cb = (col[T] < ncol) ? col[T] - nodei[T] : 0;
 #pragma unroll
             for (int k = 0; k < DIM; ++k) {
               float s = 0.f;
@@ -431,7 +534,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
 
 struct EgnnShape {
   int n, dim, G, waves;
-  void (*kernel)(EgnnParams);
+  void (*kernel[2])(EgnnParams);  // [PREC]
   size_t (*lds_bytes)(int);
 };
 
@@ -439,7 +542,7 @@ template <int N, int DIM, int G, int WAVES>
 static size_t lds_bytes_of(int L) { return EgnnCfg<N, DIM, G, WAVES>::lds_bytes(L); }
 
 #define PITA_EGNN_SHAPE(N, DIM, G, WAVES) \
-  EgnnShape { N, DIM, G, WAVES, egnn_kernel<N, DIM, G, WAVES>, lds_bytes_of<N, DIM, G, WAVES> }
+  EgnnShape { N, DIM, G, WAVES, {egnn_kernel<N, DIM, G, WAVES, 0>, egnn_kernel<N, DIM, G, WAVES, 1>}, lds_bytes_of<N, DIM, G, WAVES> }
 
 // Instantiated (n_particles, n_dim) shapes: DW4, LJ13, alanine dipeptide (22 atoms), LJ55.
 static const EgnnShape kShapes[] = {
@@ -453,6 +556,7 @@ static const EgnnShape kShapes[] = {
 
 struct pita_egnn {
   pita_egnn_config cfg;
+  unsigned* d_mats16 = nullptr;
   float* d_mats = nullptr;
   float* d_vecs = nullptr;
   const pita::EgnnShape* shape = nullptr;
@@ -476,6 +580,7 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
   if (cfg->hidden_nf != EH)
     return fail(PITA_EUNSUPPORTED, "pita_egnn_create: hidden_nf=%d (the HIP kernel implements 32)", cfg->hidden_nf);
   PITA_REQUIRE(cfg->in_node_nf == 1 || cfg->in_node_nf == 2, "in_node_nf must be 1 or 2");
+  PITA_REQUIRE(cfg->precision == 0 || cfg->precision == 1, "precision must be 0 (f32 MFMA) or 1 (bf16x3 split)");
   PITA_REQUIRE(cfg->n_layers >= 1 && cfg->n_layers <= 16, "n_layers out of range");
   PITA_REQUIRE(n_weights == pita_egnn_num_weights(cfg), "pita_egnn_create: got %lld weights, expected %lld",
                (long long)n_weights, (long long)pita_egnn_num_weights(cfg));
@@ -489,6 +594,8 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
   const size_t n_mats = (size_t)L * M_COUNT * MAT_F, n_vecs = VEC_EMB_F + (size_t)L * VEC_LAYER_F;
   float* h_mats = new float[n_mats];
   float* h_vecs = new float[n_vecs]();
+  const size_t n_mats16 = (size_t)L * M_COUNT * MAT_W;
+  unsigned* h_mats16 = new unsigned[n_mats16];
   // walk the state_dict order
   const float* q = w;
   const float* emb_w = q; q += H * nf;
@@ -506,6 +613,24 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
       for (int lane = 0; lane < 64; ++lane)
         for (int s = 0; s < 4; ++s)
           dst[(qd * 64 + lane) * 4 + s] = M[(lane & 31) * ld + col0 + kfeat(4 * qd + s, lane >> 5)];
+  };
+  // bf16 three-way truncation split of the same fragments: word q of (piece, kstep st, lane) packs the
+  // pieces of elements r = 8 st + 2q (low half) and r + 1 (high half)
+  auto trunc16 = [](float v) { unsigned u; memcpy(&u, &v, 4); u &= 0xFFFF0000u; float o; memcpy(&o, &u, 4); return o; };
+  auto hi16 = [](float v) { unsigned u; memcpy(&u, &v, 4); return u >> 16; };
+  auto pack_mat16 = [&](unsigned* dst, const float* M, int ld, int col0) {
+    for (int lane = 0; lane < 64; ++lane)
+      for (int st = 0; st < 2; ++st)
+        for (int qd = 0; qd < 4; ++qd) {
+          unsigned pcs[2][3];
+          for (int e = 0; e < 2; ++e) {
+            const float w = M[(lane & 31) * ld + col0 + kfeat(8 * st + 2 * qd + e, lane >> 5)];
+            const float w1 = trunc16(w), r1 = w - w1, w2 = trunc16(r1), r2 = r1 - w2;
+            pcs[e][0] = hi16(w1); pcs[e][1] = hi16(w2); pcs[e][2] = hi16(r2);
+          }
+          for (int pc = 0; pc < 3; ++pc)
+            dst[(((size_t)pc * 2 + st) * 64 + lane) * 4 + qd] = pcs[0][pc] | (pcs[1][pc] << 16);
+        }
   };
   auto pack_vec = [&](float* dst, const float* v, int stride) {
     for (int hh = 0; hh < 2; ++hh)
@@ -527,6 +652,14 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
     const float* c2w = q; q += H;
     const float* aw = nullptr; const float* ab = nullptr;
     if (cfg->attention) { aw = q; q += H; ab = q; q += 1; }
+    unsigned* m16 = h_mats16 + (size_t)l * M_COUNT * MAT_W;
+    pack_mat16(m16 + M_WA * MAT_W, e0w, 2 * H + 2, 0);
+    pack_mat16(m16 + M_WB * MAT_W, e0w, 2 * H + 2, H);
+    pack_mat16(m16 + M_W2 * MAT_W, e2w, H, 0);
+    pack_mat16(m16 + M_WC1 * MAT_W, c0w, H, 0);
+    pack_mat16(m16 + M_WN1A * MAT_W, n0w, 2 * H, 0);
+    pack_mat16(m16 + M_WN1B * MAT_W, n0w, 2 * H, H);
+    pack_mat16(m16 + M_WN2 * MAT_W, n2w, H, 0);
     pack_mat(mats + M_WA * MAT_F, e0w, 2 * H + 2, 0);
     pack_mat(mats + M_WB * MAT_F, e0w, 2 * H + 2, H);
     pack_mat(mats + M_W2 * MAT_F, e2w, H, 0);
@@ -552,15 +685,20 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
   net->shape = shape;
   hipError_t e1 = hipMalloc(&net->d_mats, n_mats * sizeof(float));
   hipError_t e2 = hipMalloc(&net->d_vecs, n_vecs * sizeof(float));
-  if (e1 == hipSuccess && e2 == hipSuccess) {
+  hipError_t e0 = hipMalloc(&net->d_mats16, n_mats16 * sizeof(unsigned));
+  if (e1 == hipSuccess && e2 == hipSuccess && e0 == hipSuccess) {
     e1 = hipMemcpy(net->d_mats, h_mats, n_mats * sizeof(float), hipMemcpyHostToDevice);
     e2 = hipMemcpy(net->d_vecs, h_vecs, n_vecs * sizeof(float), hipMemcpyHostToDevice);
+    e0 = hipMemcpy(net->d_mats16, h_mats16, n_mats16 * sizeof(unsigned), hipMemcpyHostToDevice);
   }
+  if (e0 != hipSuccess && e1 == hipSuccess) e1 = e0;
   delete[] h_mats;
   delete[] h_vecs;
+  delete[] h_mats16;
   if (e1 != hipSuccess || e2 != hipSuccess) {
     (void)hipFree(net->d_mats);
     (void)hipFree(net->d_vecs);
+    (void)hipFree(net->d_mats16);
     delete net;
     return fail(PITA_EHIP, "pita_egnn_create: device upload failed: %s",
                 hipGetErrorString(e1 != hipSuccess ? e1 : e2));
@@ -571,8 +709,11 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
     net->n_cu = prop.multiProcessorCount;
   // opt in to the LDS the kernel needs (static limit is 64 KiB)
   size_t lds = shape->lds_bytes(L);
-  hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(shape->kernel),
+  hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(shape->kernel[0]),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e3 == hipSuccess)
+    e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(shape->kernel[1]),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e3 != hipSuccess) {
     pita_egnn_destroy(net);
     return fail(PITA_EHIP, "pita_egnn_create: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e3));
@@ -585,6 +726,7 @@ extern "C" int pita_egnn_destroy(pita_egnn_t* net) {
   if (!net) return PITA_OK;
   (void)hipFree(net->d_mats);
   (void)hipFree(net->d_vecs);
+  (void)hipFree(net->d_mats16);
   delete net;
   return PITA_OK;
 }
@@ -592,6 +734,7 @@ extern "C" int pita_egnn_destroy(pita_egnn_t* net) {
 static int egnn_launch(pita_egnn_t* net, EgnnParams& p, void* stream) {
   const EgnnShape* s = net->shape;
   p.mats = net->d_mats;
+  p.mats16 = net->d_mats16;
   p.vecs = net->d_vecs;
   p.n_layers = net->cfg.n_layers;
   p.in_nf = net->cfg.in_node_nf;
@@ -608,7 +751,8 @@ static int egnn_launch(pita_egnn_t* net, EgnnParams& p, void* stream) {
   // forward modes: one group per wave (plain grid); sampler mode: persistent grid-stride
   unsigned grid = (unsigned)(want < cap ? want : cap);
   if (p.mode != 3) grid = (unsigned)want;
-  hipLaunchKernelGGL(s->kernel, dim3(grid), dim3(s->waves * 64), lds, (hipStream_t)stream, p);
+  const int prec = net->cfg.precision == 1 ? 1 : 0;
+  hipLaunchKernelGGL(s->kernel[prec], dim3(grid), dim3(s->waves * 64), lds, (hipStream_t)stream, p);
   PITA_LAUNCH_CHECK();
   return PITA_OK;
 }

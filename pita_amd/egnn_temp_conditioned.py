@@ -57,7 +57,7 @@ class EGNN(nn.Module):
 class EGNN_dynamics(nn.Module):
     def __init__(self, n_particles, n_dimension, hidden_nf=64, act_fn=torch.nn.SiLU(), n_layers=4, recurrent=True,
                  attention=False, condition_time=True, tanh=False, agg="sum", energy=False, add_virtual=False,
-                 condition_temperature=False, feature_layout="pita"):
+                 condition_temperature=False, feature_layout="pita", precision="bf16x3"):
         super().__init__()
         if energy or add_virtual or not condition_time:
             raise NotImplementedError("HIP EGNN_dynamics implements energy=False, add_virtual=False, condition_time=True")
@@ -68,6 +68,9 @@ class EGNN_dynamics(nn.Module):
         self.condition_time, self.condition_temperature = condition_time, condition_temperature
         # "pita" keeps the reference's t/beta interleave quirk (:68-78); "correct" gives (t, beta) per node
         self.feature_layout = {"pita": 0, "correct": 1}[feature_layout]
+        # dense-layer arithmetic, both fp32-accurate: "f32" = f32 MFMA (bit-exact fmaf chains), "bf16x3" = bf16
+        # matrix pipe with an exact three-way operand split (see csrc/egnn_kernel.hip)
+        self.precision = {"f32": 0, "bf16x3": 1}[precision]
         self.counter = 0
         self._handle = None
         self._handle_key = None
@@ -76,11 +79,11 @@ class EGNN_dynamics(nn.Module):
     def _config(self):
         e = self.egnn
         return _lib.EgnnConfig(self._n_particles, self._n_dimension, e.hidden_nf, e.n_layers, self.in_node_nf,
-                               int(e.attention), int(e.tanh), e.coords_range, self.feature_layout)
+                               int(e.attention), int(e.tanh), e.coords_range, self.feature_layout, self.precision)
 
     def _native(self, device):
         params = list(self.state_dict().values())
-        key = (device.index,) + tuple((p.data_ptr(), p._version) for p in params)
+        key = (device.index, self.precision) + tuple((p.data_ptr(), p._version) for p in params)
         if self._handle is None or key != self._handle_key:
             self._release()
             flat = torch.cat([p.detach().to("cpu", torch.float32).reshape(-1) for p in params]).contiguous().numpy()

@@ -109,13 +109,17 @@ def make_net(pa, n, d, weights, temp=True, **kw):
     return net
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 @pytest.mark.parametrize("name", ["lj13", "dw4", "lj55"])
 @pytest.mark.parametrize("tag,wfile", [("init", "egnn_weights_seed12345.npz"), ("trained", "egnn_weights_trainedlike.npz")])
-def test_egnn_golden(pa, golden, name, tag, wfile):
+def test_egnn_golden(pa, golden, name, tag, wfile, precision):
+    """Both dense-layer arithmetic modes (f32 MFMA; bf16 matrix pipe with exact 3-way split) must be
+    fp32-accurate: within 4x the reference's own fp32-vs-fp64 error."""
     g = golden(f"egnn_{name}_fwd.npz")
     w = golden(wfile)
     n, d = int(g["n"]), int(g["d"])
-    net = make_net(pa, n, d, w)
+    net = make_net(pa, n, d, w, precision=precision)
+    print(f"[{name}/{tag}/{precision}]", end=" ")
     x, h, beta = cu(g["x"]), cu(g["h"]), cu(g["beta"])
     c_s, c_in, c_out, c_noise = O.edm_coeffs(T(g["h"]))
     F = net(c_noise.cuda(), (c_in[:, None] * T(g["x"])).cuda(), beta)
@@ -124,6 +128,7 @@ def test_egnn_golden(pa, golden, name, tag, wfile):
     F64 = O.egnn_forward(wd, c_noise.double(), (c_in[:, None] * T(g["x"])).double(), T(g["beta"]).double(), n, d)
     err_ref = rel(g[f"F_{tag}"], F64)
     err_hip = rel(F, F64)
+    print(f"err_hip_vs_fp64={err_hip:.3e} err_ref_vs_fp64={err_ref:.3e}")
     assert err_hip < max(4 * err_ref, 2e-6), (err_hip, err_ref)
     assert rel(F, g[f"F_{tag}"]) < max(2e-5, 6 * err_ref)
     sn = pa.ScoreNet(net)
