@@ -147,10 +147,11 @@ __device__ __forceinline__ void lj13_body(const float* __restrict__ xw, float* _
       const int pj = ((MULT * j) % N) * 3;
       const float d0 = xi0 - xw[pj], d1 = xi1 - xw[pj + 1], d2 = xi2 - xw[pj + 2];
       const float r2 = fmaf(d2, d2, fmaf(d1, d1, fmaf(d0, d0, p.dist_eps)));
-      const float inv = __builtin_amdgcn_rcpf(r2);
-      const float s2 = p.rm2 * inv, s6 = s2 * s2 * s2;
-      e += fmaf(s6, s6, -2.0f * s6);
-      const float coef = (12.0f * fmaf(-s6, s6, s6)) * inv;
+      const float s2 = p.rm2 * __builtin_amdgcn_rcpf(r2);      // (rm/r)^2
+      const float s6 = s2 * s2 * s2;
+      e += fmaf(s6, s6, -2.0f * s6);                             // (rm/r)^12 - 2 (rm/r)^6, per pair (less cancellation)
+      const float ts = s6 * s2;
+      const float coef = fmaf(-s6, ts, ts);                      // (s^6 - s^12) s^2 = e'(r)/r * rm^2/(12 eps)
       fr[i * 3] = fmaf(coef, d0, fr[i * 3]); fr[i * 3 + 1] = fmaf(coef, d1, fr[i * 3 + 1]); fr[i * 3 + 2] = fmaf(coef, d2, fr[i * 3 + 2]);
       fr[j * 3] = fmaf(-coef, d0, fr[j * 3]); fr[j * 3 + 1] = fmaf(-coef, d1, fr[j * 3 + 1]); fr[j * 3 + 2] = fmaf(-coef, d2, fr[j * 3 + 2]);
     }
@@ -162,21 +163,23 @@ __device__ __forceinline__ void lj13_body(const float* __restrict__ xw, float* _
   m0 /= (float)N; m1 /= (float)N; m2 /= (float)N;
   const float oscw = first ? p.osc_scale : 0.f;
   const float pair_w = 2.0f * p.energy_factor * p.eps;  // every unordered pair counts twice in the reference sum
+  const float force_w = pair_w * 12.0f / p.rm2;         // undo the scaling of `coef`
   float osc = 0.f;
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     const int pk = ((MULT * k) % N) * 3;
     const float c0 = xw[pk] - m0, c1 = xw[pk + 1] - m1, c2 = xw[pk + 2] - m2;
     osc = fmaf(c0, c0, fmaf(c1, c1, fmaf(c2, c2, osc)));
-    fr[k * 3] = -p.inv_T * fmaf(pair_w, fr[k * 3], oscw * c0);
-    fr[k * 3 + 1] = -p.inv_T * fmaf(pair_w, fr[k * 3 + 1], oscw * c1);
-    fr[k * 3 + 2] = -p.inv_T * fmaf(pair_w, fr[k * 3 + 2], oscw * c2);
+    fr[k * 3] = -p.inv_T * fmaf(force_w, fr[k * 3], oscw * c0);
+    fr[k * 3 + 1] = -p.inv_T * fmaf(force_w, fr[k * 3 + 1], oscw * c1);
+    fr[k * 3 + 2] = -p.inv_T * fmaf(force_w, fr[k * 3 + 2], oscw * c2);
   }
   // pin the results before the barrier: otherwise the compiler sinks ALL the arithmetic below it (its only
   // users are the guarded stores) while the 39 coordinate loads must stay above -> everything spills
 #pragma unroll
   for (int q = 0; q < 39; ++q) asm volatile("" : "+v"(fr[q]));
-  asm volatile("" : "+v"(e), "+v"(osc));
+  float e_pin = e;
+  asm volatile("" : "+v"(e_pin), "+v"(osc));
   __syncthreads();  // all coordinate reads of the block are done: the stage may be overwritten with forces
   if (act) {
 #pragma unroll
@@ -184,7 +187,7 @@ __device__ __forceinline__ void lj13_body(const float* __restrict__ xw, float* _
       const int pk = ((MULT * k) % N) * 3;
       fw[pk] = fr[k * 3]; fw[pk + 1] = fr[k * 3 + 1]; fw[pk + 2] = fr[k * 3 + 2];
     }
-    *e_out = fmaf(pair_w, e, 0.5f * oscw * osc);
+    *e_out = fmaf(pair_w, e_pin, 0.5f * oscw * osc);
   }
 }
 
