@@ -37,6 +37,17 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 d
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak
 
 
+def pmc_traffic(key):
+    """HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (collected with this same
+    command under rocprofv3 and corrected as MI355X_MICROARCH.md prescribes; see profiles/r01_pmc_traffic.json).  PMC
+    collection cannot run inside the timed bench itself, so the live JSON carries the last committed measurement."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return json.load(f)[key]["traffic_bytes"]
+    except Exception:
+        return None
+
+
 def build_model(pa, seed=12345):
     torch.manual_seed(seed)
     net = pa.EGNN_dynamics(13, 3, hidden_nf=32, n_layers=3, recurrent=True, tanh=True, attention=True,
@@ -156,24 +167,54 @@ def main():
     launch_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(n_launch)]
     assert torch.isfinite(x).all(), "sampler produced non-finite walkers"
 
-    # ---- pairwise-force kernel roofline (HBM-bound), separately timed
+    # ---- pairwise-force kernel roofline (HBM-bound), separately timed: at the workload's 65 536 walkers, at a
+    #      streaming-size batch (2^21 walkers, 663 MB per launch) and next to a plain device copy of the same bytes
     force_rl = None
     if rank == 0 and args.force_evals > 0:
-        logp, force = energy(x, return_force=True)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         L = pita_amd._lib.lib()
         sp = pita_amd._lib.stream_ptr(dev)
-        e0.record()
-        for _ in range(args.force_evals):
-            L.pita_lj_logp_force(x.data_ptr(), logp.data_ptr(), force.data_ptr(), B, 13, 3, 1.0, 1.0, 1e-6, 1.0, 1.0, 1.0, sp)
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / args.force_evals
+
+        def time_force(xb, reps):
+            nb = xb.shape[0]
+            lp, fo = torch.empty(nb, device=dev), torch.empty_like(xb)
+            for _ in range(3):
+                L.pita_lj_logp_force(xb.data_ptr(), lp.data_ptr(), fo.data_ptr(), nb, 13, 3, 1.0, 1.0, 1e-6, 1.0, 1.0, 1.0, sp)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                L.pita_lj_logp_force(xb.data_ptr(), lp.data_ptr(), fo.data_ptr(), nb, 13, 3, 1.0, 1.0, 1e-6, 1.0, 1.0, 1.0, sp)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / reps
+
+        def time_copy(nfloat, reps):
+            a, b = torch.empty(nfloat, device=dev), torch.empty(nfloat, device=dev)
+            for _ in range(3):
+                b.copy_(a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                b.copy_(a)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / reps
+
+        us = time_force(x, args.force_evals)
         gbs = B * LJ13_BYTES_PER_EVAL / (us * 1e-6) / 1e9
-        force_rl = {"kernel": "pair_energy_kernel<3,LJ> (LJ13 logp+force)", "bound": "hbm", "achieved": gbs,
-                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
-                    "us_per_launch": us, "walker_evals_per_s": B / (us * 1e-6), "launches": args.force_evals}
+        BIG = 1 << 21
+        xbig = x.repeat(BIG // B + 1, 1)[:BIG].contiguous()
+        us_big = time_force(xbig, 20)
+        gbs_big = BIG * LJ13_BYTES_PER_EVAL / (us_big * 1e-6) / 1e9
+        us_copy = time_copy(B * 39, args.force_evals)  # a device copy moving the same 2 x 10.2 MB
+        force_rl = {"kernel": "lj13_kernel<2> (LJ13 logp+force, 65 536 walkers)", "bound": "hbm", "achieved": gbs,
+                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                    "traffic": pmc_traffic("lj13_kernel<2> @65536 walkers") if B == 65536 else None,
+                    "us_per_launch": us, "walker_evals_per_s": B / (us * 1e-6), "launches": args.force_evals,
+                    "same_bytes_device_copy_us": us_copy,
+                    "same_bytes_device_copy_GBs": 2 * B * 39 * 4 / (us_copy * 1e-6) / 1e9,
+                    "large_batch": {"kernel": "lj13_kernel<1>", "walkers": BIG, "us_per_launch": us_big,
+                                    "achieved": gbs_big, "frac": gbs_big / PEAK_HBM_GBS}}
+        del xbig
 
     if rank == 0:
         avg_ms = float(np.mean(launch_ms))
@@ -195,9 +236,14 @@ def main():
                                    "not-debiased, resampling off, Elucidating(0.05,80,7), gamma=4/3, beta=1",
                        "walkers_per_gpu": B, "global_walkers": world * B, "steps_per_launch": chunk,
                        "parallelism": f"walker-sharded x{world}, final all_gather only"},
-            "roofline": {"kernel": "egnn_kernel<13,3,7,4> (fused EGNN score + EM step)", "bound": "mfma",
+            "roofline": {"kernel": "egnn_kernel<13,3,7,4,1,true> (fused EGNN score + EM step)", "bound": "mfma",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": pmc_traffic("egnn_kernel<13,3,7,4,1> @65536 walkers x 100 steps")
+                         if (B == 65536 and chunk == 100) else None,
+                         "note": "fp32-accurate dense layers run as exact 3-way bf16 splits on the bf16 matrix pipe; "
+                                 "algorithmic flops count the reference's un-split first edge layer, so frac can exceed 1; "
+                                 "the kernel is VALU-issue-bound (activations + operand splits), see DESIGN.md",
                          "algorithmic_flop_per_walker_step": FLOP_PER_WALKER_STEP, "ms_per_launch": avg_ms,
                          "launches": n_launch},
             "roofline_force": force_rl,

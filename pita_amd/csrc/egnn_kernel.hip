@@ -224,8 +224,11 @@ struct EgnnCfg {
   }
 };
 
-template <int N, int DIM, int G, int WAVES, int PREC>
+// SAMPLER = true: mode 3 only (per-step scalars are wave-uniform -> SGPRs); false: modes 0-2 (per-walker t / h / beta).
+// Separate instantiations keep the fused sampler's register budget free of the forward modes' per-column scalars.
+template <int N, int DIM, int G, int WAVES, int PREC, bool SAMPLER>
 __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
+  const int mode = SAMPLER ? 3 : p.mode;
   using C = EgnnCfg<N, DIM, G, WAVES>;
   constexpr int NT = C::NT;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -269,17 +272,17 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
       wid[T] = walker0 + w;
       valid[T] = (col[T] < ncol);
       if (!valid[T]) wid[T] = p.B - 1;  // clamp for safe (unused) parameter loads
-      const float* src = (p.mode == 3 ? p.x : p.x_in);
+      const float* src = (mode == 3 ? p.x : p.x_in);
 #pragma unroll
       for (int k = 0; k < DIM; ++k) xcur[T][k] = valid[T] ? src[(walker0 * N + col[T]) * DIM + k] : 0.0f;
     }
 
-    const int nsteps = (p.mode == 3) ? p.n_steps : 1;
+    const int nsteps = (mode == 3) ? p.n_steps : 1;
     for (int step = 0; step < nsteps; ++step) {
       // ---- per-column scalars of this evaluation
       float c_s[NT], c_in[NT], c_out[NT], tfeat[NT], hval[NT], bfeat[NT];
       float g2 = 0.f, gamma = 0.f, dt = 0.f, noise_scale = 0.f, sqrt_dt = 0.f;
-      if (p.mode == 3) {
+      if (mode == 3) {
         const float* st = p.step_tab + (size_t)step * PITA_STEP_STRIDE;
 #pragma unroll
         for (int T = 0; T < NT; ++T) {
@@ -293,7 +296,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
         for (int T = 0; T < NT; ++T) {
           float tv = p.t[wid[T]];
           bfeat[T] = p.beta ? p.beta[wid[T]] : 0.0f;
-          if (p.mode == 0) {
+          if (mode == 0) {
             c_s[T] = 0.f; c_in[T] = 1.f; c_out[T] = 1.f; tfeat[T] = tv; hval[T] = 1.f;
           } else {  // score_net.py:26-29
             hval[T] = tv;
@@ -312,7 +315,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
       for (int T = 0; T < NT; ++T) {
 #pragma unroll
         for (int k = 0; k < DIM; ++k) {
-          posi[T][k] = (p.mode == 0) ? xcur[T][k] : c_in[T] * xcur[T][k];
+          posi[T][k] = (mode == 0) ? xcur[T][k] : c_in[T] * xcur[T][k];
           p0i[T][k] = posi[T][k];
           if (hh == 0) {
             pos0[col[T] * DIM + k] = posi[T][k];
@@ -462,15 +465,15 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
       }
       wave_lds_fence();
 
-      if (p.mode != 3) {
+      if (mode != 3) {
 #pragma unroll
         for (int T = 0; T < NT; ++T)
 #pragma unroll
           for (int k = 0; k < DIM; ++k) {
             float o = F[T][k];
-            if (p.mode >= 1) {
+            if (mode >= 1) {
               o = c_s[T] * xcur[T][k] + c_out[T] * F[T][k];           // denoiser (score_net.py:31-33)
-              if (p.mode == 2) o = (o - xcur[T][k]) / hval[T];        // score (:19)
+              if (mode == 2) o = (o - xcur[T][k]) / hval[T];        // score (:19)
             }
             if (valid[T] && hh == 0) p.out[(walker0 * N + col[T]) * DIM + k] = o;
           }
@@ -519,7 +522,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
       }
     }  // steps
 
-    if (p.mode == 3) {
+    if (mode == 3) {
 #pragma unroll
       for (int T = 0; T < NT; ++T)
 #pragma unroll
@@ -534,7 +537,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
 
 struct EgnnShape {
   int n, dim, G, waves;
-  void (*kernel[2])(EgnnParams);  // [PREC]
+  void (*kernel[2][2])(EgnnParams);  // [PREC][SAMPLER]
   size_t (*lds_bytes)(int);
 };
 
@@ -542,7 +545,9 @@ template <int N, int DIM, int G, int WAVES>
 static size_t lds_bytes_of(int L) { return EgnnCfg<N, DIM, G, WAVES>::lds_bytes(L); }
 
 #define PITA_EGNN_SHAPE(N, DIM, G, WAVES) \
-  EgnnShape { N, DIM, G, WAVES, {egnn_kernel<N, DIM, G, WAVES, 0>, egnn_kernel<N, DIM, G, WAVES, 1>}, lds_bytes_of<N, DIM, G, WAVES> }
+  EgnnShape { N, DIM, G, WAVES, {{egnn_kernel<N, DIM, G, WAVES, 0, false>, egnn_kernel<N, DIM, G, WAVES, 0, true>}, \
+                                 {egnn_kernel<N, DIM, G, WAVES, 1, false>, egnn_kernel<N, DIM, G, WAVES, 1, true>}}, \
+              lds_bytes_of<N, DIM, G, WAVES> }
 
 // Instantiated (n_particles, n_dim) shapes: DW4, LJ13, alanine dipeptide (22 atoms), LJ55.
 static const EgnnShape kShapes[] = {
@@ -709,11 +714,11 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
     net->n_cu = prop.multiProcessorCount;
   // opt in to the LDS the kernel needs (static limit is 64 KiB)
   size_t lds = shape->lds_bytes(L);
-  hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(shape->kernel[0]),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e3 == hipSuccess)
-    e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(shape->kernel[1]),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e3 = hipSuccess;
+  for (int a = 0; a < 2 && e3 == hipSuccess; ++a)
+    for (int b = 0; b < 2 && e3 == hipSuccess; ++b)
+      e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(shape->kernel[a][b]),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e3 != hipSuccess) {
     pita_egnn_destroy(net);
     return fail(PITA_EHIP, "pita_egnn_create: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e3));
@@ -752,7 +757,7 @@ static int egnn_launch(pita_egnn_t* net, EgnnParams& p, void* stream) {
   unsigned grid = (unsigned)(want < cap ? want : cap);
   if (p.mode != 3) grid = (unsigned)want;
   const int prec = net->cfg.precision == 1 ? 1 : 0;
-  hipLaunchKernelGGL(s->kernel[prec], dim3(grid), dim3(s->waves * 64), lds, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(s->kernel[prec][p.mode == 3 ? 1 : 0], dim3(grid), dim3(s->waves * 64), lds, (hipStream_t)stream, p);
   PITA_LAUNCH_CHECK();
   return PITA_OK;
 }
