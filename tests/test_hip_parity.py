@@ -356,3 +356,66 @@ def test_full_size_lj13_properties(pa, golden):
     lpp, fp = e(xp, return_force=True)
     np.testing.assert_allclose(lpp.cpu().numpy(), lp.cpu().numpy(), rtol=2e-5, atol=3e-5)
     assert rel(fp, f.reshape(B, 13, 3)[:, perm.cuda()].reshape(B, 39)) < 1e-5
+
+
+def _one_step_vs_oracle(pa, golden, n, d, B, sigma_min, subset=24, seed=0):
+    """One fused sampler step at full batch; a random subset of walkers is re-computed by the oracle."""
+    w = golden("egnn_weights_trainedlike.npz")
+    net = make_net(pa, n, d, w)
+    sched = pa.ElucidatingNoiseSchedule(sigma_min=sigma_min, sigma_max=80.0, rho=7)
+    gam = pa.ConstantAnnealingFactorSchedule(4 / 3)
+    N = 50
+    k0 = 37  # a mid-trajectory step (h ~ 1e2)
+    times = torch.linspace(1.0, 0.0, N + 1)[:-1]
+    tab = pa.sde_integration.build_step_table(sched, gam, times, 1.0 / N, 1.0, 1.0)
+    gen = torch.Generator().manual_seed(seed)
+    h_k = float(tab[k0, pa._lib.ST_H])
+    x0 = O.remove_mean(torch.randn(B, n * d, generator=gen) * (1.0 + h_k) ** 0.5, n, d)
+    noise = torch.randn(1, B, n * d, generator=gen)
+    x = x0.cuda().clone()
+    drift = torch.empty_like(x)
+    net.sampler_run(x, tab[k0:k0 + 1].cuda().contiguous(), 1, noise=noise.cuda(), drift_out=drift)
+    assert torch.isfinite(x).all()
+    assert abs(x.reshape(B, n, d).mean(1)).max() < 1e-4 * (1 + x.abs().max().item())
+    idx = torch.randint(0, B, (subset,), generator=gen)
+    wt = {k: T(v) for k, v in w.items()}
+    bb = lambda cn, xs, b: O.egnn_forward(wt, cn, xs, b, n, d)
+    osched, ogam = O.Elucidating(sigma_min, 80.0, 7), O.GammaConstant(4 / 3)
+    t = times[k0]
+    terms = O.f_not_debiased(bb, osched, ogam, t, x0[idx], 1.0)
+    tb = t * torch.ones(subset)
+    xo = x0[idx] + (terms.drift_X * (1.0 / N) + (osched.g(tb)[:, None] * noise[0, idx]) * np.sqrt(1.0 / N))
+    xo = O.remove_mean(xo, n, d)
+    assert rel(drift[idx.cuda()], terms.drift_X) < 1e-4
+    assert rel(x[idx.cuda()], xo) < 1e-5
+    return net, tab, x
+
+
+def test_full_size_dw4_config(pa, golden):
+    """BASELINE config C2: DW4 (4 particles x 2D), EGNN score net, 65 536 walkers."""
+    B = 65536
+    net, tab, x = _one_step_vs_oracle(pa, golden, 4, 2, B, 0.01)
+    e = pa.MultiDoubleWellEnergy()
+    lp, f = e(x, return_force=True)
+    assert torch.isfinite(lp).all() and torch.isfinite(f).all()
+    idx = torch.arange(0, B, 997)
+    lpo, fo = O.dw4_logp_force(x[idx.cuda()].cpu().double())
+    np.testing.assert_allclose(lp[idx.cuda()].cpu().numpy(), lpo.numpy(), rtol=2e-5, atol=2e-4)
+    assert rel(f[idx.cuda()], fo) < 2e-5
+    assert abs(f.reshape(B, 4, 2).sum(1)).max() < 1e-2 * f.abs().max().item()  # no net force on the centre of mass
+
+
+def test_full_size_lj55_config(pa, golden):
+    """BASELINE config C5 per-GPU shard: LJ55 (55 x 3D), EGNN score net, 32 768 walkers."""
+    B = 32768
+    net, tab, x = _one_step_vs_oracle(pa, golden, 55, 3, B, 0.05, subset=6)
+    g = golden("lj55_logp_force.npz")
+    base = T(g["x"][:48])
+    gen = torch.Generator().manual_seed(9)
+    xe = (base[torch.randint(0, 48, (B,), generator=gen)] + 0.02 * torch.randn(B, 165, generator=gen)).cuda()
+    e = pa.LennardJonesEnergy(165, 55, 3)
+    lp, f = e(xe, return_force=True)
+    idx = torch.arange(0, B, 4099)
+    lpo, fo = O.lj_logp_force(xe[idx.cuda()].cpu().double(), 55, 3)
+    np.testing.assert_allclose(lp[idx.cuda()].cpu().numpy(), lpo.numpy(), rtol=2e-5, atol=1e-3)
+    assert rel(f[idx.cuda()], fo) < 2e-5
