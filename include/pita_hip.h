@@ -114,6 +114,16 @@ int pita_egnn_forward(pita_egnn_t* net, const float* t, const float* x, const fl
 int pita_egnn_edm(pita_egnn_t* net, int what, const float* h, const float* x, const float* beta,
                   float* out, int64_t B, void* stream);
 
+/* Forward-mode derivative of the denoiser D(h, x) = c_s x + c_out F(c_noise(h), c_in(h) x, beta), one tangent
+ * direction per launch:  dout = J_x D . vx + dD/dh . vh   (and out = D when out != NULL).
+ * vx: device [B, D] or NULL; when NULL the direction is the unit vector e_dir of every walker (0 <= dir < D) or
+ * zero (dir = -1).  vh: device [B] or NULL (= 0).
+ * Building block of the debiased Feynman-Kac regime (sdes.py:151-239): div_x s_theta (utils.py:30-51),
+ * grad_x E_theta (energy_net.py:51-62) and dE_theta/dt (sdes.py:218) are linear in these JVPs -- the reference
+ * gets them from torch.func.jacrev / autograd. */
+int pita_egnn_jvp(pita_egnn_t* net, const float* h, const float* x, const float* beta, const float* vx,
+                  int dir, const float* vh, float* out /*nullable*/, float* dout, int64_t B, void* stream);
+
 /* ---------------------------------------------------------------- fused sampler (K5+K7+K8)
  * Runs n_steps Euler-Maruyama steps of the NOT-debiased reverse VE-SDE in ONE launch, walkers
  * resident on chip for the whole trajectory.  replaces, per step,

@@ -1,0 +1,172 @@
+// Device helpers shared by the EGNN kernels (forward / fused sampler: egnn_kernel.hip; forward-mode
+// derivative: egnn_jvp_kernel.hip) and the native handle behind pita_egnn_t.
+#pragma once
+#include <cstdlib>
+
+#include "common.h"
+
+namespace pita {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int EH = 32;       // hidden_nf
+constexpr int PBS = 36;      // LDS row stride (floats) of the partner table
+constexpr int MAT_F = 1024;  // floats per packed 32x32 matrix
+enum { M_WA = 0, M_WB, M_W2, M_WC1, M_WN1A, M_WN1B, M_WN2, M_COUNT };
+enum { V_WRE = 0 /* 64 floats: w_r[out] | w_e[out], natural order */, V_B1 = 2, V_B2, V_WATT, V_BC1, V_WC2, V_BN1,
+       V_BN2, V_COUNT };
+constexpr int VEC_EMB_F = 96;                    // emb_w0, emb_w1, emb_b
+constexpr int VEC_LAYER_F = V_COUNT * EH + 4;    // vectors (fragment order unless noted) + b_att (+pad)
+
+
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS operations of one wave execute in order; this only stops the compiler from moving
+  // LDS accesses across the hand-off and drains outstanding reads.
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+__device__ __forceinline__ void load_frag(const float* __restrict__ pack, int lane, float (&wf)[16]) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(pack) + lane;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 v = p[q * 64];
+    wf[4 * q + 0] = v.x; wf[4 * q + 1] = v.y; wf[4 * q + 2] = v.z; wf[4 * q + 3] = v.w;
+  }
+}
+
+__device__ __forceinline__ f32x16 lds_vec16(const float* v) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(v);
+  f32x4 a = p[0], b = p[1], c = p[2], d = p[3];
+  f32x16 r;
+  r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w;
+  r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+  r[8] = c.x; r[9] = c.y; r[10] = c.z; r[11] = c.w;
+  r[12] = d.x; r[13] = d.y; r[14] = d.z; r[15] = d.w;
+  return r;
+}
+
+// ---- 32x32 dense layer  out[o][col] = acc[o][col] + sum_k W[o][k] in[k][col]  in two arithmetic modes.
+//
+// PREC 0: 16 chained v_mfma_f32_32x32x2_f32 -- bit-exact fp32 (k-ordered fmaf chain).  On gfx950 the
+//   f32-input MFMA runs at the fp32 VECTOR rate and (measured: SQ_VALU_MFMA_COEXEC_CYCLES = 0,
+//   MFMA-busy + VALU-active = wave residency) does not overlap with VALU work on the same SIMD.
+// PREC 1: the bf16 matrix pipe with an EXACT three-way split.  Every fp32 operand is cut by
+//   truncation into three bf16 pieces x = x1 + x2 + x3 (8+8+8 significand bits, no rounding); the six
+//   products W1X1, W1X2, W2X1, W1X3, W3X1, W2X2 (each exact in the fp32 accumulator) are summed by
+//   12 v_mfma_f32_32x32x16_bf16; the dropped terms are <= 2^-24 |w||x|, i.e. the result is
+//   fp32-equivalent (same error level as PREC 0, different rounding).  16x the MAC rate of PREC 0 and it
+//   co-executes with the VALU (activations) of the partner wave.  Weight pieces are cut on the host.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int MAT_W = 1536;  // 32-bit words per bf16-split packed matrix: [piece 3][kstep 2][lane 64][4]
+
+template <int PREC>
+struct WFrag;
+
+template <>
+struct WFrag<0> {
+  float wf[16];
+  __device__ __forceinline__ void load(const float* __restrict__ m32, const unsigned* __restrict__, int mat, int lane) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(m32 + (size_t)mat * MAT_F) + lane;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = p[q * 64];
+      wf[4 * q + 0] = v.x; wf[4 * q + 1] = v.y; wf[4 * q + 2] = v.z; wf[4 * q + 3] = v.w;
+    }
+  }
+  __device__ __forceinline__ f32x16 mul(const f32x16& in, f32x16 acc) const {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[r], in[r], acc, 0, 0, 0);
+    return acc;
+  }
+};
+
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+template <>
+struct WFrag<1> {
+  u32x4 w[3][2];  // [piece][k-step], 8 bf16 each
+  __device__ __forceinline__ void load(const float* __restrict__, const unsigned* __restrict__ m16, int mat, int lane) {
+    const u32x4* p = reinterpret_cast<const u32x4*>(m16 + (size_t)mat * MAT_W) + lane;
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) w[pc][st] = p[(pc * 2 + st) * 64];
+  }
+  __device__ __forceinline__ f32x16 mul(const f32x16& in, f32x16 acc) const {
+    u32x4 x[3][2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned a = __float_as_uint(in[8 * st + 2 * q]), b = __float_as_uint(in[8 * st + 2 * q + 1]);
+        const unsigned a1 = a & 0xFFFF0000u, b1 = b & 0xFFFF0000u;
+        const unsigned ar = __float_as_uint(__uint_as_float(a) - __uint_as_float(a1));  // exact
+        const unsigned br = __float_as_uint(__uint_as_float(b) - __uint_as_float(b1));
+        const unsigned a2 = ar & 0xFFFF0000u, b2 = br & 0xFFFF0000u;
+        const unsigned a3 = __float_as_uint(__uint_as_float(ar) - __uint_as_float(a2));  // exact; truncated on packing
+        const unsigned b3 = __float_as_uint(__uint_as_float(br) - __uint_as_float(b2));
+        x[0][st][q] = __builtin_amdgcn_perm(b1, a1, 0x07060302u);  // {hi16(b), hi16(a)}
+        x[1][st][q] = __builtin_amdgcn_perm(b2, a2, 0x07060302u);
+        x[2][st][q] = __builtin_amdgcn_perm(b3, a3, 0x07060302u);
+      }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {  // smallest terms first
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w[2][st]), as_bf16x8(x[0][st]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w[0][st]), as_bf16x8(x[2][st]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w[1][st]), as_bf16x8(x[1][st]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w[1][st]), as_bf16x8(x[0][st]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w[0][st]), as_bf16x8(x[1][st]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w[0][st]), as_bf16x8(x[0][st]), acc, 0, 0, 0);
+    }
+    return acc;
+  }
+};
+
+// ---- packed fp32 helpers.  Measured on gfx950: a wave64 VALU instruction occupies its SIMD's issue for 4 cycles
+// (8 for v_exp/v_rcp) whether it is v_mul_f32 or v_pk_mul_f32, so packed math (2 lanes-worth of fp32 per
+// instruction) halves the issue cost of every mul/add/fma around the transcendentals.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 silu2(f32x2 v) {
+  const f32x2 t = v * -1.44269504088896341f;
+  f32x2 e;
+  e.x = __builtin_amdgcn_exp2f(t.x);
+  e.y = __builtin_amdgcn_exp2f(t.y);
+  const f32x2 d = e + 1.0f;
+  f32x2 r;
+  r.x = __builtin_amdgcn_rcpf(d.x);
+  r.y = __builtin_amdgcn_rcpf(d.y);
+  return v * r;
+}
+__device__ __forceinline__ void silu16(f32x16& m) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const f32x2 y = silu2(f32x2{m[2 * q], m[2 * q + 1]});
+    m[2 * q] = y.x;
+    m[2 * q + 1] = y.y;
+  }
+}
+__device__ __forceinline__ float dot16(const f32x16& w, const f32x16& m) {
+  f32x2 acc = {0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    acc = __builtin_elementwise_fma(f32x2{w[2 * q], w[2 * q + 1]}, f32x2{m[2 * q], m[2 * q + 1]}, acc);
+  return acc.x + acc.y;
+}
+
+__device__ __forceinline__ float xhalf_sum(float v) {
+  // add the value held by the partner lane (l ^ 32): the other 16 features of the same column
+  return v + __shfl_xor(v, 32, 64);
+}
+
+}  // namespace pita
+
+struct pita_egnn {
+  pita_egnn_config cfg;
+  unsigned* d_mats16 = nullptr;  // [L][M_COUNT][3][2][64][4]  bf16-split fragments
+  float* d_mats = nullptr;       // [L][M_COUNT][4][64][4]     f32 fragments
+  float* d_vecs = nullptr;       // [VEC_EMB_F + L*VEC_LAYER_F]
+  const void* shape = nullptr;   // pita::EgnnShape of egnn_kernel.hip
+  int n_cu = 256;
+};

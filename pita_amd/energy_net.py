@@ -1,9 +1,8 @@
 """Energy view of the score backbone (mirror of pita/src/models/components/energy_net.py).
 
 ``forward_energy`` (E_theta built from <F_theta(c_in x), c_in x>, :14-49) needs only backbone
-FORWARDS and is implemented.  ``forward`` (grad_x E_theta via autograd, :51-62) and
-``denoiser_and_energy`` need derivatives of the backbone, which the HIP EGNN does not provide
-yet: they raise.
+FORWARDS.  ``forward`` (grad_x E_theta, autograd in the reference :51-62) is assembled from the dim
+forward-mode derivatives of the HIP backbone (``EGNN_dynamics.jvp``).
 """
 from typing import Optional
 
@@ -34,9 +33,21 @@ class EnergyNet(nn.Module):
         return E
 
     def forward(self, ht, xt, beta, pin=False, t=None, energy_function=None):
-        raise NotImplementedError(
-            "EnergyNet.forward (grad_x E_theta, energy_net.py:51-62) needs backbone derivatives; the HIP path "
-            "implements the not-debiased sampler this round (debias_inference=False)")
+        """grad_x E_theta = ((1 + c_s) x - D - J_x D^T x)/h with D the denoiser of this backbone."""
+        if pin or self.precondition_beta or not hasattr(self.net, "jvp"):
+            raise NotImplementedError("EnergyNet.forward: needs the HIP EGNN backbone, pin=False, precondition_beta=False")
+        B, D = xt.shape
+        jtx = torch.empty(B, D, device=xt.device)
+        Dx = None
+        for k in range(D):
+            out, dk = self.net.jvp(ht, xt, beta, direction=k, want_primal=(k == 0))
+            Dx = out if k == 0 else Dx
+            jtx[:, k] = (xt * dk).sum(dim=1)
+        c_s = 1 / (1 + ht)
+        return ((1 + c_s)[:, None] * xt - Dx - jtx) / ht[:, None]
+
+    def denoiser(self, h_t, x_t, beta):
+        return x_t - h_t[:, None] * self.forward(h_t, x_t, beta)
 
     def reinitialize(self, score_net: nn.Module):
         self.net = score_net

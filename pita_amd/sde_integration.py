@@ -141,8 +141,6 @@ class WeightedSDEIntegrator:
                       annealing_factor_score=1.0, resampling_interval=None, noise=None, resample_u=None):
         """``noise``: optional [N, B, D] device normals (global batch); ``resample_u``: optional
         iterable of float64 uniforms, one per resampling event (parity hooks)."""
-        if getattr(self.sde, "debias_inference", False):
-            raise NotImplementedError("debias_inference=True is not built on the HIP path (SURVEY section 8(f) N1)")
         if resampling_interval is None:
             resampling_interval = self.resampling_interval
         N = self.num_integration_steps
@@ -178,6 +176,10 @@ class WeightedSDEIntegrator:
         num_unique_idxs = [Bg] * N
         sde_terms_all = []
         model = self._backbone()
+        if getattr(self.sde, "debias_inference", False):
+            return self._integrate_debiased(x, comm, tab_h, times, noise, key, off, Bl, Bg, n, d, mean_free,
+                                            energy_function, annealing_factor_schedule, inverse_temperature,
+                                            resampling_interval, u_iter)
 
         s = start
         bounds = events + [N - 1]
@@ -225,6 +227,78 @@ class WeightedSDEIntegrator:
             x, acceptance_rate_list = fn(x, energy_function, return_acceptance_rate=True, **kw)
         x = comm.all_gather(x)  # X1: the only collective on the resampling-free path
         return x, logweights, num_unique_idxs, sde_terms_all, acceptance_rate_list
+
+    # ------------------------------------------------------------------ debiased regime (per step; section 8(f) N1)
+    def _integrate_debiased(self, x, comm, tab_h, times, noise, key, off, Bl, Bg, n, d, mean_free, energy_function,
+                            gamma_schedule, beta, resampling_interval, u_iter):
+        """Feynman-Kac weighted integration (sde_integration.py:131-152,214-297 with sdes.py:151-239): per step the
+        drift of x and of the log-weights a per inference chunk, Euler-Maruyama update, window gates, global
+        systematic resampling when due.  Resampling is global like the reference's: weights and walkers are
+        all-gathered at every resampling event."""
+        N = self.num_integration_steps
+        dev = x.device
+        L = _lib.lib()
+        a = torch.zeros(Bl, device=dev)
+        logweights, num_unique_idxs, sde_terms_all = [], [], []
+        bs = self.batch_size or Bl
+        for step in range(N):
+            t = times[step].to(dev)
+            row = tab_h[step]
+            if step < self.start_resampling_step:  # walkers frozen, weights zero (:278-280)
+                a = torch.zeros_like(a)
+                logweights.append(comm.all_gather(a))
+                num_unique_idxs.append(Bg)
+                continue
+            chunks = [self.sde.f(t, x[lo:lo + bs], beta, gamma_schedule, None, energy_function, resampling_interval)
+                      for lo in range(0, Bl, bs)]
+            terms = SDETerms.concatenate(chunks)
+            drift = terms.drift_X.contiguous()
+            nz = noise[step].contiguous() if noise is not None else None
+            _lib.check(L.pita_em_step(x.data_ptr(), drift.data_ptr(), _lib.ptr(nz), Bl, n, d, float(row[_lib.ST_DT]),
+                                      float(row[_lib.ST_NOISE_SCALE]), float(row[_lib.ST_SQRT_DT]), key, off, step, 0,
+                                      _lib.stream_ptr(dev)), "pita_em_step")
+            a = a + terms.drift_A * float(row[_lib.ST_DT])
+            if step >= self.end_resampling_step:
+                a = torch.zeros_like(a)
+            n_unique = Bg
+            due = not (resampling_interval == -1 or (step + 1) % resampling_interval != 0
+                       or step >= self.end_resampling_step)
+            if due:
+                xg, ag = comm.all_gather(x), comm.all_gather(a)
+                u = next(u_iter) if u_iter is not None else None
+                ids, _ = sample_cat_sys(xg.shape[0], ag, u)
+                xg = gather_rows(xg, ids)
+                n_unique = int(torch.unique(ids).numel())
+                x = xg[off:off + Bl].clone()
+                a = torch.zeros_like(a)
+            if mean_free:
+                x = remove_mean(x, n, d)
+            logweights.append(comm.all_gather(a))
+            num_unique_idxs.append(n_unique)
+            if self.record_terms:
+                sde_terms_all.append(terms)
+        logweights = torch.stack(logweights)
+        did_resampling = resampling_interval != -1 and resampling_interval < N
+        if self.resample_at_end and did_resampling:  # :158-183
+            t_end = times[min(self.end_resampling_step, N - 1)]
+            xg, ag = comm.all_gather(x), comm.all_gather(a)
+            tb = torch.full((xg.shape[0],), float(t_end), device=dev)
+            model_energy = self.sde.energy_net.forward_energy(self.sde.noise_schedule.h(tb), xg, beta)
+            a_next = energy_function(xg) + model_energy * _scalar(gamma_schedule.gamma(t_end)) + ag
+            a_next = torch.clamp(a_next, max=torch.quantile(a_next, 0.9))
+            u = next(u_iter) if u_iter is not None else None
+            ids, _ = sample_cat_sys(xg.shape[0], a_next, u)
+            x = gather_rows(xg, ids)[off:off + Bl].clone()
+            logweights = torch.cat([logweights, a_next[None]])
+            num_unique_idxs.append(int(torch.unique(ids).numel()))
+        if self.num_negative_time_steps > 0:
+            x = self.negative_time_descent(x, energy_function, walker_offset=off)
+        acceptance_rate_list = []
+        if self.post_mcmc_steps > 0:
+            fn = self.metropolis_hastings_mala_adaptive if self.adaptive_mcmc else self.metropolis_hastings_mala
+            kw = dict(dt_init=self.dt_negative_time) if self.adaptive_mcmc else {}
+            x, acceptance_rate_list = fn(x, energy_function, return_acceptance_rate=True, **kw)
+        return comm.all_gather(x), logweights, num_unique_idxs, sde_terms_all, acceptance_rate_list
 
     # ------------------------------------------------------------------ A2-A4 steps [s0, s1)
     def _run_steps(self, model, x, tab, tab_h, s0, s1, noise, key, off, n, d, mean_free, beta, sde_terms_all):

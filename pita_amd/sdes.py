@@ -1,11 +1,15 @@
 """Reverse VE-SDE terms (mirror of pita/src/models/components/sdes.py).
 
-``VEReverseSDE.f`` returns the ``SDETerms`` of one step.  Implemented: the NOT-debiased regime
-(``debias_inference=False`` -> ``f_not_debiased``, sdes.py:117-128), i.e. drift_X = gamma(t) *
-s_theta(h(t), x, beta) * g(t)^2, drift_A = 0.  The debiased Feynman-Kac regime (:151-239) needs
-grad_x / divergence / d/dt of the backbone and is the next tier: it raises.
-The fused HIP sampler does not call ``f`` per step -- ``WeightedSDEIntegrator`` hands the whole
-trajectory to pita_egnn_sampler_run; ``f`` serves the per-step (recording / plug-in) path.
+``VEReverseSDE.f`` returns the ``SDETerms`` of one step.
+* NOT-debiased regime (``debias_inference=False`` -> ``f_not_debiased``, sdes.py:117-128):
+  drift_X = gamma(t) s_theta(h(t), x, beta) g(t)^2, drift_A = 0.  The fused HIP sampler does not call ``f`` per
+  step in this regime -- ``WeightedSDEIntegrator`` hands whole trajectories to pita_egnn_sampler_run; ``f`` serves
+  the per-step (recording / plug-in) path.
+* Debiased Feynman-Kac regime (sdes.py:151-239): drift_X = -gamma grad_x E_theta g^2/2 + gamma s_theta g^2/2 and the
+  log-weight drift  gamma^2 <-grad E, b> + gamma div b + gamma dE/dt + gamma'(t) E, clamped at its 0.9 quantile.
+  The reference obtains grad_x E (autograd), div s (vmap(jacrev)) and dE/dt (autograd through h(t)); here all three
+  are assembled from forward-mode derivatives of the two denoisers computed by the HIP kernel pita_egnn_jvp
+  (csrc/egnn_jvp_kernel.hip): dim + 1 tangent directions for the energy net, dim for the score net, per step.
 """
 from dataclasses import dataclass
 from typing import Optional
@@ -69,9 +73,62 @@ class VEReverseSDE:
             gamma_energy = gamma_energy.to(x.device)
         if not self.debias_inference:
             return self.f_not_debiased(t, x, beta, gamma_energy)
-        raise NotImplementedError(
-            "VEReverseSDE.f with debias_inference=True (Feynman-Kac weights, sdes.py:151-239) is not built on the "
-            "HIP path yet; construct VEReverseSDE(..., debias_inference=False)")
+        return self.f_debiased(t, x, beta, gamma_energy, gamma_energy_schedule)
+
+    # ------------------------------------------------------------------ debiased regime (sdes.py:151-239)
+    def _denoiser_jacobian_terms(self, model, ht, x, beta, want_h_direction):
+        """From dim (+1) JVP launches of one backbone: D, trace(J_x D), J_x D^T x and (optionally) dD/dh."""
+        if not hasattr(model, "jvp"):
+            raise NotImplementedError(
+                "debias_inference=True needs a backbone with a forward-mode derivative (the HIP EGNN_dynamics.jvp)")
+        B, D = x.shape
+        trace = torch.zeros(B, device=x.device)
+        jtx = torch.empty(B, D, device=x.device)
+        Dx = None
+        for k in range(D):
+            out, dk = model.jvp(ht, x, beta, direction=k, want_primal=(k == 0))
+            if k == 0:
+                Dx = out
+            trace += dk[:, k]
+            jtx[:, k] = (x * dk).sum(dim=1)
+        dDh = None
+        if want_h_direction:
+            _, dDh = model.jvp(ht, x, beta, direction=-1, vh=torch.ones(B, device=x.device), want_primal=False)
+        return Dx, trace, jtx, dDh
+
+    def f_debiased(self, t, x, beta, gamma_energy, gamma_energy_schedule):
+        assert self.energy_net is not None
+        if self.pin_energy or getattr(self.energy_net, "precondition_beta", False) or (
+                self.score_net is not None and getattr(self.score_net, "precondition_beta", False)):
+            raise NotImplementedError("debiased HIP path: pin_energy / precondition_beta are not built")
+        B, D = x.shape
+        ht = self.noise_schedule.h(t)
+        g2 = self.g(t).pow(2)
+        gamma = gamma_energy
+        dgamma = gamma_energy_schedule.dgamma_dt(t)
+        dgamma = dgamma.to(x.device) if isinstance(dgamma, torch.Tensor) else dgamma
+        c_s = 1 / (1 + ht)
+        x2 = (x * x).sum(dim=1)
+        # energy net: E = (1+c_s)|x|^2/(2h) - <D_E, x>/h  (== energy_net.py:32-36 with F = (D - c_s x)/c_out)
+        D_E, _, jtx_E, dDh_E = self._denoiser_jacobian_terms(self.energy_net.net, ht, x, beta, True)
+        DEx = (D_E * x).sum(dim=1)
+        Ut = (1 + c_s) / (2 * ht) * x2 - DEx / ht
+        nabla_Ut = ((1 + c_s)[:, None] * x - D_E - jtx_E) / ht[:, None]
+        dq_dh = (-2 * ht * ht - 8 * ht - 4) / (2 * ht + 2 * ht * ht) ** 2  # d/dh [(1+c_s)/(2h)]
+        dU_dh = dq_dh * x2 + DEx / (ht * ht) - (dDh_E * x).sum(dim=1) / ht
+        dUt_dt = dU_dh * g2  # dh/dt = g(t)^2
+        if self.score_net is not None:
+            D_S, trace_S, _, _ = self._denoiser_jacobian_terms(self.score_net.model, ht, x, beta, False)
+            s_t = (D_S - x) / ht[:, None]
+            bt = s_t * g2.unsqueeze(-1) / 2
+            div_bt = ((trace_S - D) / ht) * g2 / 2
+        else:
+            raise NotImplementedError("debiased HIP path without a score net (Laplacian of E_theta) is not built")
+        drift_X = gamma * -nabla_Ut * g2.unsqueeze(-1) / 2 + gamma * bt  # gamma_score == gamma_energy (sdes.py:143)
+        inner_prod = (-nabla_Ut * bt).sum(-1)
+        drift_A = gamma * gamma * inner_prod + gamma * div_bt + gamma * dUt_dt + dgamma * Ut
+        drift_A = torch.clamp(drift_A, max=torch.quantile(drift_A, 0.9))  # per inference chunk (sdes.py:230)
+        return SDETerms(drift_X=drift_X, drift_A=drift_A, divergence_score=div_bt, cross_term=inner_prod, dUt_dt=dUt_dt)
 
     def diffusion(self, t, x, diffusion_scale):
         t = _per_walker(t, x)

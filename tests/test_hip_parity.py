@@ -419,3 +419,66 @@ def test_full_size_lj55_config(pa, golden):
     lpo, fo = O.lj_logp_force(xe[idx.cuda()].cpu().double(), 55, 3)
     np.testing.assert_allclose(lp[idx.cuda()].cpu().numpy(), lpo.numpy(), rtol=2e-5, atol=1e-3)
     assert rel(f[idx.cuda()], fo) < 2e-5
+
+
+# ------------------------------------------------------------------------------- debiased regime (section 8(f) N1)
+def test_jvp_vs_oracle(pa, golden):
+    """pita_egnn_jvp against torch.func.jvp of the fp64 oracle denoiser: x-directions, the h-direction, mixed."""
+    from torch.func import jvp
+
+    w = golden("egnn_weights_trainedlike.npz")
+    wt = {k: T(v).double() for k, v in w.items()}
+    for n, d, B in ((13, 3, 23), (4, 2, 40)):
+        net = make_net(pa, n, d, w)
+        gen = torch.Generator().manual_seed(n)
+        h = torch.tensor([0.01, 0.3, 2.0, 40.0, 900.0])[torch.arange(B) % 5]
+        x = O.remove_mean(torch.randn(B, n * d, generator=gen) * (1 + h.sqrt())[:, None], n, d)
+        beta = torch.rand(B, generator=gen) + 0.7
+        vx = torch.randn(B, n * d, generator=gen)
+        vh = torch.randn(B, generator=gen) * h
+        bb = lambda cn, xs, b: O.egnn_forward(wt, cn, xs, b, n, d)
+        fn = lambda hh, xx: O.denoiser(bb, hh, xx, beta.double())
+        for tag, (tx, th) in {"x": (vx, torch.zeros(B)), "h": (torch.zeros(B, n * d), vh), "xh": (vx, vh)}.items():
+            Dref, dref = jvp(fn, (h.double(), x.double()), (th.double(), tx.double()))
+            Dh, dDh = net.jvp(h.cuda(), x.cuda(), beta.cuda(), vx=tx.cuda(), vh=th.cuda())
+            assert rel(Dh, Dref) < 2e-6, tag
+            assert rel(dDh, dref) < 2e-5, (tag, rel(dDh, dref))
+        # unit directions
+        for k in (0, n * d - 1, 5):
+            e = torch.zeros(B, n * d)
+            e[:, k] = 1
+            _, dref = jvp(fn, (h.double(), x.double()), (torch.zeros(B).double(), e.double()))
+            _, dk = net.jvp(h.cuda(), x.cuda(), beta.cuda(), direction=k, want_primal=False)
+            assert rel(dk, dref) < 2e-5, k
+
+
+def test_debiased_terms_and_trajectory_golden(pa, golden):
+    """Feynman-Kac drift terms at identical inputs and the 8-step weighted trajectory with resampling, against the
+    reference run stored in em_traj_lj13_debias.npz (autograd + vmap(jacrev) there, HIP JVPs here)."""
+    import copy
+
+    g = golden("em_traj_lj13_debias.npz")
+    w = golden("egnn_weights_trainedlike.npz")
+    net = make_net(pa, 13, 3, w)
+    sched = pa.ElucidatingNoiseSchedule(sigma_min=0.05, sigma_max=80.0, rho=7)
+    from pita_amd.energy_net import EnergyNet
+
+    sde = pa.VEReverseSDE(noise_schedule=sched, score_net=pa.ScoreNet(net), energy_net=EnergyNet(copy.deepcopy(net)),
+                          debias_inference=True)
+    gam = pa.ConstantAnnealingFactorSchedule(4 / 3)
+    x1 = cu(g["x1"])
+    terms = sde.f(torch.tensor(1.0).cuda(), x1, 1.0, gam, None, None, resampling_interval=2)
+    assert rel(terms.drift_X, g["drift_X"][0]) < 2e-4
+    np.testing.assert_allclose(terms.divergence_score.cpu().numpy(), g["divergence_score"][0], rtol=3e-3, atol=2e-2)
+    np.testing.assert_allclose(terms.cross_term.cpu().numpy(), g["cross_term"][0], rtol=3e-3, atol=2e-2)
+    np.testing.assert_allclose(terms.dUt_dt.cpu().numpy(), g["dUt_dt"][0], rtol=3e-3, atol=2e-2)
+    np.testing.assert_allclose(terms.drift_A.cpu().numpy(), g["drift_A"][0], rtol=3e-3, atol=2e-2)
+    N = int(g["N"])
+    integ = pa.WeightedSDEIntegrator(sde=sde, num_integration_steps=N, start_resampling_step=1, end_resampling_step=7,
+                                     resampling_interval=2, num_negative_time_steps=0, post_mcmc_steps=0, batch_size=12)
+    e = pa.LennardJonesEnergy(39, 13, 3)
+    x, logw, uniq, _, _ = integ.integrate_sde(x1, e, gam, inverse_temperature=1.0, noise=cu(g["noise"]),
+                                              resample_u=[float(u[0]) for u in g["u"]])
+    assert uniq == list(g["num_unique"])
+    assert rel(x, g["x_final"]) < 3e-3
+    np.testing.assert_allclose(logw.cpu().numpy(), g["logweights"], rtol=1e-2, atol=1e-2)
