@@ -122,7 +122,22 @@ int pita_egnn_edm(pita_egnn_t* net, int what, const float* h, const float* x, co
  * grad_x E_theta (energy_net.py:51-62) and dE_theta/dt (sdes.py:218) are linear in these JVPs -- the reference
  * gets them from torch.func.jacrev / autograd. */
 int pita_egnn_jvp(pita_egnn_t* net, const float* h, const float* x, const float* beta, const float* vx,
-                  int dir, const float* vh, float* out /*nullable*/, float* dout, int64_t B, void* stream);
+                  int dir, const float* vh, float* out /*nullable*/, float* dout /*nullable*/,
+                  float* dot_out /*nullable: dot_out[b*dot_stride + dot_off] = <x_b, dD_b>*/, int64_t dot_stride,
+                  int64_t dot_off, float* diag_acc /*nullable: diag_acc[b] += dD[b, dir]*/, int64_t B, void* stream);
+
+/* Feynman-Kac drift assembly per walker from those reductions (replaces the torch/autograd expressions of
+ * sdes.py:157-227): with E = (1+c_s)|x|^2/(2h) - <D_E,x>/h,
+ *   grad E = ((1+c_s) x - D_E - jtx_E)/h,  b = (D_S - x)/h * g2/2,  drift_X = gamma (-grad E) g2/2 + gamma b,
+ *   drift_A = gamma^2 <-grad E, b> + gamma (trace_S - D)/h g2/2 + gamma dE/dt + dgamma E   (NOT yet clamped).
+ * All arrays are device pointers: x, D_E, jtx_E, D_S, drift_X [B,D]; the rest [B]. */
+int pita_fk_assemble(const float* x, const float* h, const float* g2, const float* D_E, const float* jtx_E,
+                     const float* dot_h, const float* D_S, const float* trace_S, float gamma, float dgamma,
+                     float* drift_X, float* drift_A, float* div_bt, float* cross, float* dUdt, float* Ut,
+                     int64_t B, int D, void* stream);
+/* K11: in place a[c] = min(a[c], quantile_q(a over its chunk)), chunks of `chunk` consecutive walkers, linear
+ * interpolation like torch.quantile (sdes.py:230; sde_integration.py:179). */
+int pita_quantile_clamp(float* a, int64_t B, int64_t chunk, float q, void* stream);
 
 /* ---------------------------------------------------------------- fused sampler (K5+K7+K8)
  * Runs n_steps Euler-Maruyama steps of the NOT-debiased reverse VE-SDE in ONE launch, walkers

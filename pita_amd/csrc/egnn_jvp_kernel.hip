@@ -40,7 +40,10 @@ struct JvpParams {
   int dir;             // used when vx == null: unit direction e_dir (0 <= dir < D), or -1 for vx = 0
   const float* vh;     // [B] tangent of h, or null (= 0)
   float* out;          // [B, D] denoiser D (nullable)
-  float* dout;         // [B, D] JVP of D
+  float* dout;         // [B, D] JVP of D (nullable)
+  float* dot_out;      // [B] <x, dD> (nullable; strided by dot_stride, offset by dot_off: writes dot_out[b*stride+off])
+  long long dot_stride, dot_off;
+  float* diag_acc;     // [B] += dD[b, dir] (nullable; only for unit directions)
 };
 
 template <int N, int DIM, int G, int WAVES>
@@ -313,11 +316,32 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_jvp_kernel(JvpParams p) {
         if (valid[T] && hh == 0) {
           const long long gi = (walker0 * N + col[T]) * DIM + k;
           if (p.out) p.out[gi] = Dv;
-          p.dout[gi] = dDv;
+          if (p.dout) p.dout[gi] = dDv;
+          if (p.diag_acc && !p.vx && nodei[T] * DIM + k == p.dir) p.diag_acc[walker0 + col[T] / N] += dDv;
         }
+        dF[T][k] = dDv;  // keep for the <x, dD> reduction
       }
     }
     wave_lds_fence();
+    if (p.dot_out) {  // per-walker <x, dD>: column partials through LDS, first column of each walker sums
+#pragma unroll
+      for (int T = 0; T < NT; ++T) {
+        float part = 0.f;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) part = fmaf(xin[T][k], dF[T][k], part);
+        if (hh == 0) scr[col[T]] = part;
+      }
+      wave_lds_fence();
+#pragma unroll
+      for (int T = 0; T < NT; ++T) {
+        if (valid[T] && hh == 0 && nodei[T] == 0) {
+          float s = 0.f;
+          for (int q = 0; q < N; ++q) s += scr[col[T] + q];
+          p.dot_out[(walker0 + col[T] / N) * p.dot_stride + p.dot_off] = s;
+        }
+      }
+      wave_lds_fence();
+    }
   }
 }
 
@@ -342,10 +366,11 @@ static const JvpShape kJvpShapes[] = {
 using namespace pita;
 
 extern "C" int pita_egnn_jvp(pita_egnn_t* net, const float* h, const float* x, const float* beta, const float* vx,
-                             int dir, const float* vh, float* out, float* dout, int64_t B, void* stream) {
+                             int dir, const float* vh, float* out, float* dout, float* dot_out, int64_t dot_stride,
+                             int64_t dot_off, float* diag_acc, int64_t B, void* stream) {
   PITA_REQUIRE(net && B >= 0, "pita_egnn_jvp: bad argument");
   if (B == 0) return PITA_OK;
-  PITA_REQUIRE(h && x && dout, "pita_egnn_jvp: null argument");
+  PITA_REQUIRE(h && x && (dout || dot_out || diag_acc || out), "pita_egnn_jvp: null argument");
   PITA_REQUIRE(beta || net->cfg.in_node_nf == 1, "pita_egnn_jvp: beta required for in_node_nf=2");
   const int D = net->cfg.n_particles * net->cfg.n_dim;
   PITA_REQUIRE(vx || (dir >= -1 && dir < D), "pita_egnn_jvp: dir out of range");
@@ -358,6 +383,7 @@ extern "C" int pita_egnn_jvp(pita_egnn_t* net, const float* h, const float* x, c
   p.attention = net->cfg.attention; p.tanh_on = net->cfg.tanh; p.feature_layout = net->cfg.feature_layout;
   p.coord_scale = net->cfg.coords_range / (float)net->cfg.n_layers;
   p.B = B; p.h = h; p.x = x; p.beta = beta; p.vx = vx; p.dir = dir; p.vh = vh; p.out = out; p.dout = dout;
+  p.dot_out = dot_out; p.dot_stride = dot_stride > 0 ? dot_stride : 1; p.dot_off = dot_off; p.diag_acc = diag_acc;
   const size_t lds = s->lds_bytes(p.n_layers);
   static thread_local const void* configured = nullptr;
   if (configured != (const void*)s->kernel) {

@@ -1,0 +1,140 @@
+// Feynman-Kac weight-drift assembly and the per-chunk quantile clamp (K11) for gfx950.
+//
+// Replaces (paths relative to /root/reference/pita/src/models/components/):
+//   sdes.py:157-227   nabla_Ut, s_t, b_t, drift_X, <-nabla U, b>, div b, dU/dt, drift_A   (torch ops + autograd)
+//   sdes.py:230       drift_A = clamp(drift_A, max = quantile(drift_A, 0.9))   (per inference chunk)
+// Inputs are the reductions produced by pita_egnn_jvp (csrc/egnn_jvp_kernel.hip).
+#include "common.h"
+
+namespace pita {
+
+struct FkParams {
+  const float *x, *h, *g2;           // [B,D], [B], [B]
+  const float *D_E, *jtx_E, *dot_h;  // energy net: denoiser, J^T x, <x, dD/dh>
+  const float *D_S, *trace_S;        // score net: denoiser, trace of J_x D
+  float gamma, dgamma;
+  float *drift_X, *drift_A, *div_bt, *cross, *dUdt, *Ut;
+  long long B;
+  int D;
+};
+
+// One thread per walker (rows are 4*D contiguous bytes; the data are tiny next to the JVP passes).
+__global__ void __launch_bounds__(256) fk_assemble_kernel(FkParams p) {
+  for (long long b = (long long)blockIdx.x * 256 + threadIdx.x; b < p.B; b += (long long)gridDim.x * 256) {
+    const float h = p.h[b], g2 = p.g2[b];
+    const float c_s = 1.0f / (1.0f + h);
+    const float* x = p.x + b * p.D;
+    const float* DE = p.D_E + b * p.D;
+    const float* JE = p.jtx_E + b * p.D;
+    const float* DS = p.D_S + b * p.D;
+    float* dX = p.drift_X + b * p.D;
+    float x2 = 0.f, DEx = 0.f, inner = 0.f;
+    for (int k = 0; k < p.D; ++k) {
+      const float xv = x[k];
+      x2 = fmaf(xv, xv, x2);
+      DEx = fmaf(DE[k], xv, DEx);
+      const float nab = (fmaf(1.0f + c_s, xv, -DE[k]) - JE[k]) / h;   // grad_x E_theta
+      const float bt = ((DS[k] - xv) / h) * g2 * 0.5f;                 // b_t = s_theta g^2 / 2
+      dX[k] = p.gamma * (-nab) * g2 * 0.5f + p.gamma * bt;             // sdes.py:172-174 (gamma_score = gamma_energy)
+      inner = fmaf(-nab, bt, inner);
+    }
+    const float Ut = (1.0f + c_s) / (2.0f * h) * x2 - DEx / h;
+    const float den = 2.0f * h + 2.0f * h * h;
+    const float dq = (-2.0f * h * h - 8.0f * h - 4.0f) / (den * den);  // d/dh [(1 + c_s)/(2h)]
+    const float dUdt = (dq * x2 + DEx / (h * h) - p.dot_h[b] / h) * g2;  // dh/dt = g^2
+    const float div_bt = ((p.trace_S[b] - (float)p.D) / h) * g2 * 0.5f;
+    p.drift_A[b] = p.gamma * p.gamma * inner + p.gamma * div_bt + p.gamma * dUdt + p.dgamma * Ut;  // :222-227
+    p.div_bt[b] = div_bt;
+    p.cross[b] = inner;
+    p.dUdt[b] = dUdt;
+    p.Ut[b] = Ut;
+  }
+}
+
+// ---- K11: per-chunk quantile (linear interpolation, torch.quantile semantics) + clamp, one block per chunk.
+// The two order statistics come from an exact 4-pass radix select over order-preserving integer keys.
+constexpr int QT = 1024;
+__device__ __forceinline__ unsigned f2key(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+__device__ float radix_select(const float* __restrict__ a, long long n, long long k, unsigned* hist, unsigned* sh) {
+  unsigned prefix = 0, mask = 0;
+  for (int pass = 3; pass >= 0; --pass) {
+    for (int i = threadIdx.x; i < 256; i += QT) hist[i] = 0;
+    __syncthreads();
+    const int shift = pass * 8;
+    for (long long i = threadIdx.x; i < n; i += QT) {
+      const unsigned key = f2key(a[i]);
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      long long cum = 0;
+      unsigned bin = 0;
+      for (; bin < 256; ++bin) {
+        if (cum + hist[bin] > (unsigned long long)k) break;
+        cum += hist[bin];
+      }
+      sh[0] = bin;
+      sh[1] = (unsigned)cum;
+    }
+    __syncthreads();
+    prefix |= sh[0] << shift;
+    mask |= 255u << shift;
+    k -= sh[1];
+    __syncthreads();
+  }
+  return key2f(prefix);
+}
+
+__global__ void __launch_bounds__(QT) quantile_clamp_kernel(float* __restrict__ a, long long B, long long chunk, float q) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned sh[2];
+  const long long lo = (long long)blockIdx.x * chunk;
+  const long long n = (B - lo) < chunk ? (B - lo) : chunk;
+  if (n <= 0) return;
+  float* ac = a + lo;
+  const float rank = q * (float)(n - 1);
+  const long long klo = (long long)floorf(rank);
+  const long long khi = (klo + 1 < n) ? (long long)ceilf(rank) : klo;
+  const float w = rank - (float)klo;
+  const float vlo = radix_select(ac, n, klo, hist, sh);
+  const float vhi = (khi == klo) ? vlo : radix_select(ac, n, khi, hist, sh);
+  const float diff = vhi - vlo;
+  const float quant = (w < 0.5f) ? fmaf(w, diff, vlo) : vhi - diff * (1.0f - w);  // at::lerp
+  for (long long i = threadIdx.x; i < n; i += QT) ac[i] = fminf(ac[i], quant);
+}
+
+}  // namespace pita
+
+using namespace pita;
+
+extern "C" int pita_fk_assemble(const float* x, const float* h, const float* g2, const float* D_E, const float* jtx_E,
+                                const float* dot_h, const float* D_S, const float* trace_S, float gamma, float dgamma,
+                                float* drift_X, float* drift_A, float* div_bt, float* cross, float* dUdt, float* Ut,
+                                int64_t B, int D, void* stream) {
+  PITA_REQUIRE(B >= 0 && D >= 1, "pita_fk_assemble: bad shape");
+  if (B == 0) return PITA_OK;
+  PITA_REQUIRE(x && h && g2 && D_E && jtx_E && dot_h && D_S && trace_S && drift_X && drift_A && div_bt && cross && dUdt && Ut,
+               "pita_fk_assemble: null argument");
+  FkParams p{x, h, g2, D_E, jtx_E, dot_h, D_S, trace_S, gamma, dgamma, drift_X, drift_A, div_bt, cross, dUdt, Ut, B, D};
+  const long long nb = (B + 255) / 256;
+  hipLaunchKernelGGL(fk_assemble_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, (hipStream_t)stream, p);
+  PITA_LAUNCH_CHECK();
+  return PITA_OK;
+}
+
+extern "C" int pita_quantile_clamp(float* a, int64_t B, int64_t chunk, float q, void* stream) {
+  PITA_REQUIRE(B >= 0 && chunk >= 1 && q >= 0.f && q <= 1.f, "pita_quantile_clamp: bad argument");
+  if (B == 0) return PITA_OK;
+  PITA_REQUIRE(a, "pita_quantile_clamp: null argument");
+  const long long nchunk = (B + chunk - 1) / chunk;
+  hipLaunchKernelGGL(quantile_clamp_kernel, dim3((unsigned)nchunk), dim3(QT), 0, (hipStream_t)stream, a, (long long)B,
+                     (long long)chunk, q);
+  PITA_LAUNCH_CHECK();
+  return PITA_OK;
+}

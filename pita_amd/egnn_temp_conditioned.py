@@ -139,10 +139,13 @@ class EGNN_dynamics(nn.Module):
                                             out.data_ptr(), B, _lib.stream_ptr(x_t.device)), "pita_egnn_edm")
         return out
 
-    def jvp(self, h_t, x_t, beta, vx=None, direction=-1, vh=None, want_primal=True):
+    def jvp(self, h_t, x_t, beta, vx=None, direction=-1, vh=None, want_primal=True, want_tangent=True, dot_out=None,
+            dot_col=0, diag_acc=None):
         """(D, dD): the denoiser D_theta(h, x) and its forward-mode derivative along ONE tangent direction:
         dD = J_x D . vx + dD/dh . vh.  ``vx``: [B, D] tensor, or None for the unit direction ``direction`` of
-        every walker (-1 = zero).  ``vh``: [B] tensor or None.  (pita_egnn_jvp; fp32-accurate bf16x3 arithmetic.)"""
+        every walker (-1 = zero).  ``vh``: [B] tensor or None.  Optional in-kernel reductions:
+        ``dot_out[:, dot_col] = <x, dD>`` and ``diag_acc += dD[:, direction]``.
+        (pita_egnn_jvp; fp32-accurate bf16x3 arithmetic.)"""
         x_t = _lib.dev_tensor(x_t, "x_t")
         B = x_t.shape[0]
         h_t = _lib.dev_tensor(h_t, "h_t").reshape(-1).expand(B).contiguous()
@@ -152,10 +155,15 @@ class EGNN_dynamics(nn.Module):
         if vh is not None:
             vh = _lib.dev_tensor(vh, "vh").reshape(-1).expand(B).contiguous()
         out = torch.empty_like(x_t) if want_primal else None
-        dout = torch.empty_like(x_t)
+        dout = torch.empty_like(x_t) if want_tangent else None
+        stride = 1
+        if dot_out is not None:
+            assert dot_out.is_cuda and dot_out.dtype == torch.float32 and dot_out.is_contiguous()
+            stride = dot_out.shape[1] if dot_out.dim() == 2 else 1
         _lib.check(_lib.lib().pita_egnn_jvp(self._native(x_t.device), h_t.data_ptr(), x_t.data_ptr(), _lib.ptr(b),
-                                            _lib.ptr(vx), int(direction), _lib.ptr(vh), _lib.ptr(out), dout.data_ptr(),
-                                            B, _lib.stream_ptr(x_t.device)), "pita_egnn_jvp")
+                                            _lib.ptr(vx), int(direction), _lib.ptr(vh), _lib.ptr(out), _lib.ptr(dout),
+                                            _lib.ptr(dot_out), stride, int(dot_col), _lib.ptr(diag_acc), B,
+                                            _lib.stream_ptr(x_t.device)), "pita_egnn_jvp")
         return out, dout
 
     def sampler_run(self, x, step_tab, n_steps, noise=None, seed=0, walker_offset=0, step0=0, remove_mean=True,

@@ -40,9 +40,9 @@ class EnergyNet(nn.Module):
         jtx = torch.empty(B, D, device=xt.device)
         Dx = None
         for k in range(D):
-            out, dk = self.net.jvp(ht, xt, beta, direction=k, want_primal=(k == 0))
+            out, _ = self.net.jvp(ht, xt, beta, direction=k, want_primal=(k == 0), want_tangent=False, dot_out=jtx,
+                                  dot_col=k)
             Dx = out if k == 0 else Dx
-            jtx[:, k] = (xt * dk).sum(dim=1)
         c_s = 1 / (1 + ht)
         return ((1 + c_s)[:, None] * xt - Dx - jtx) / ht[:, None]
 

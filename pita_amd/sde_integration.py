@@ -33,6 +33,14 @@ def _scalar(v):
     return float(v.reshape(-1)[0]) if isinstance(v, torch.Tensor) else float(v)
 
 
+def _quantile_clamp(a, q):
+    """clamp(a, max=quantile(a, q)) over the whole vector through the K11 kernel (sde_integration.py:179)."""
+    a = _lib.dev_tensor(a, "a").clone()
+    _lib.check(_lib.lib().pita_quantile_clamp(a.data_ptr(), a.shape[0], a.shape[0], float(q), _lib.stream_ptr(a.device)),
+               "pita_quantile_clamp")
+    return a
+
+
 def build_step_table(noise_schedule, annealing_factor_schedule, times, dt, diffusion_scale, inverse_temperature):
     """[N, 16] float32 host table of per-step scalars in the reference's fp32 op order
     (score_net.py:26-29; sdes.py:119-122,140,250; sde_integration.py:347)."""
@@ -210,7 +218,7 @@ class WeightedSDEIntegrator:
             h_t = self.sde.noise_schedule.h(tb)
             model_energy = self.sde.energy_net.forward_energy(h_t, xg, inverse_temperature)
             a_next = target_logprob - (-model_energy * _scalar(annealing_factor_schedule.gamma(t_end)))
-            a_next = torch.clamp(a_next, max=torch.quantile(a_next, 0.9))
+            a_next = _quantile_clamp(a_next, 0.9)
             u = next(u_iter) if u_iter is not None else None
             ids, _ = sample_cat_sys(xg.shape[0], a_next, u)
             xg = gather_rows(xg, ids)
@@ -285,7 +293,7 @@ class WeightedSDEIntegrator:
             tb = torch.full((xg.shape[0],), float(t_end), device=dev)
             model_energy = self.sde.energy_net.forward_energy(self.sde.noise_schedule.h(tb), xg, beta)
             a_next = energy_function(xg) + model_energy * _scalar(gamma_schedule.gamma(t_end)) + ag
-            a_next = torch.clamp(a_next, max=torch.quantile(a_next, 0.9))
+            a_next = _quantile_clamp(a_next, 0.9)
             u = next(u_iter) if u_iter is not None else None
             ids, _ = sample_cat_sys(xg.shape[0], a_next, u)
             x = gather_rows(xg, ids)[off:off + Bl].clone()

@@ -77,7 +77,8 @@ class VEReverseSDE:
 
     # ------------------------------------------------------------------ debiased regime (sdes.py:151-239)
     def _denoiser_jacobian_terms(self, model, ht, x, beta, want_h_direction):
-        """From dim (+1) JVP launches of one backbone: D, trace(J_x D), J_x D^T x and (optionally) dD/dh."""
+        """From dim (+1) launches of pita_egnn_jvp on one backbone: D, trace(J_x D), J_x D^T x and <x, dD/dh>.
+        The per-walker reductions happen inside the kernel; only [B] / [B, D] results touch memory."""
         if not hasattr(model, "jvp"):
             raise NotImplementedError(
                 "debias_inference=True needs a backbone with a forward-mode derivative (the HIP EGNN_dynamics.jvp)")
@@ -86,49 +87,45 @@ class VEReverseSDE:
         jtx = torch.empty(B, D, device=x.device)
         Dx = None
         for k in range(D):
-            out, dk = model.jvp(ht, x, beta, direction=k, want_primal=(k == 0))
-            if k == 0:
-                Dx = out
-            trace += dk[:, k]
-            jtx[:, k] = (x * dk).sum(dim=1)
-        dDh = None
+            out, _ = model.jvp(ht, x, beta, direction=k, want_primal=(k == 0), want_tangent=False, dot_out=jtx,
+                               dot_col=k, diag_acc=trace)
+            Dx = out if k == 0 else Dx
+        dot_h = None
         if want_h_direction:
-            _, dDh = model.jvp(ht, x, beta, direction=-1, vh=torch.ones(B, device=x.device), want_primal=False)
-        return Dx, trace, jtx, dDh
+            dot_h = torch.empty(B, device=x.device)
+            model.jvp(ht, x, beta, direction=-1, vh=torch.ones(B, device=x.device), want_primal=False,
+                      want_tangent=False, dot_out=dot_h)
+        return Dx, trace, jtx, dot_h
 
     def f_debiased(self, t, x, beta, gamma_energy, gamma_energy_schedule):
         assert self.energy_net is not None
         if self.pin_energy or getattr(self.energy_net, "precondition_beta", False) or (
                 self.score_net is not None and getattr(self.score_net, "precondition_beta", False)):
             raise NotImplementedError("debiased HIP path: pin_energy / precondition_beta are not built")
-        B, D = x.shape
-        ht = self.noise_schedule.h(t)
-        g2 = self.g(t).pow(2)
-        gamma = gamma_energy
-        dgamma = gamma_energy_schedule.dgamma_dt(t)
-        dgamma = dgamma.to(x.device) if isinstance(dgamma, torch.Tensor) else dgamma
-        c_s = 1 / (1 + ht)
-        x2 = (x * x).sum(dim=1)
-        # energy net: E = (1+c_s)|x|^2/(2h) - <D_E, x>/h  (== energy_net.py:32-36 with F = (D - c_s x)/c_out)
-        D_E, _, jtx_E, dDh_E = self._denoiser_jacobian_terms(self.energy_net.net, ht, x, beta, True)
-        DEx = (D_E * x).sum(dim=1)
-        Ut = (1 + c_s) / (2 * ht) * x2 - DEx / ht
-        nabla_Ut = ((1 + c_s)[:, None] * x - D_E - jtx_E) / ht[:, None]
-        dq_dh = (-2 * ht * ht - 8 * ht - 4) / (2 * ht + 2 * ht * ht) ** 2  # d/dh [(1+c_s)/(2h)]
-        dU_dh = dq_dh * x2 + DEx / (ht * ht) - (dDh_E * x).sum(dim=1) / ht
-        dUt_dt = dU_dh * g2  # dh/dt = g(t)^2
-        if self.score_net is not None:
-            D_S, trace_S, _, _ = self._denoiser_jacobian_terms(self.score_net.model, ht, x, beta, False)
-            s_t = (D_S - x) / ht[:, None]
-            bt = s_t * g2.unsqueeze(-1) / 2
-            div_bt = ((trace_S - D) / ht) * g2 / 2
-        else:
+        if self.score_net is None:
             raise NotImplementedError("debiased HIP path without a score net (Laplacian of E_theta) is not built")
-        drift_X = gamma * -nabla_Ut * g2.unsqueeze(-1) / 2 + gamma * bt  # gamma_score == gamma_energy (sdes.py:143)
-        inner_prod = (-nabla_Ut * bt).sum(-1)
-        drift_A = gamma * gamma * inner_prod + gamma * div_bt + gamma * dUt_dt + dgamma * Ut
-        drift_A = torch.clamp(drift_A, max=torch.quantile(drift_A, 0.9))  # per inference chunk (sdes.py:230)
-        return SDETerms(drift_X=drift_X, drift_A=drift_A, divergence_score=div_bt, cross_term=inner_prod, dUt_dt=dUt_dt)
+        from . import _lib
+
+        x = _lib.dev_tensor(x, "x")
+        B, D = x.shape
+        ht = _lib.dev_tensor(self.noise_schedule.h(t), "h(t)").contiguous()
+        g2 = _lib.dev_tensor(self.g(t).pow(2), "g(t)^2").contiguous()
+        gamma = float(gamma_energy.reshape(-1)[0]) if isinstance(gamma_energy, torch.Tensor) else float(gamma_energy)
+        dg = gamma_energy_schedule.dgamma_dt(t)
+        dgamma = float(dg.reshape(-1)[0]) if isinstance(dg, torch.Tensor) else float(dg)
+        D_E, _, jtx_E, dot_h = self._denoiser_jacobian_terms(self.energy_net.net, ht, x, beta, True)
+        D_S, trace_S, _, _ = self._denoiser_jacobian_terms(self.score_net.model, ht, x, beta, False)
+        drift_X = torch.empty_like(x)
+        drift_A, div_bt, cross, dUdt, Ut = (torch.empty(B, device=x.device) for _ in range(5))
+        _lib.check(_lib.lib().pita_fk_assemble(
+            x.data_ptr(), ht.data_ptr(), g2.data_ptr(), D_E.data_ptr(), jtx_E.data_ptr(), dot_h.data_ptr(),
+            D_S.data_ptr(), trace_S.data_ptr(), gamma, dgamma, drift_X.data_ptr(), drift_A.data_ptr(),
+            div_bt.data_ptr(), cross.data_ptr(), dUdt.data_ptr(), Ut.data_ptr(), B, D, _lib.stream_ptr(x.device)),
+            "pita_fk_assemble")
+        # 0.9-quantile clamp of the weight drift over this inference chunk (sdes.py:230), K11
+        _lib.check(_lib.lib().pita_quantile_clamp(drift_A.data_ptr(), B, B, 0.9, _lib.stream_ptr(x.device)),
+                   "pita_quantile_clamp")
+        return SDETerms(drift_X=drift_X, drift_A=drift_A, divergence_score=div_bt, cross_term=cross, dUt_dt=dUdt)
 
     def diffusion(self, t, x, diffusion_scale):
         t = _per_walker(t, x)

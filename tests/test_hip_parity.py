@@ -482,3 +482,18 @@ def test_debiased_terms_and_trajectory_golden(pa, golden):
     assert uniq == list(g["num_unique"])
     assert rel(x, g["x_final"]) < 3e-3
     np.testing.assert_allclose(logw.cpu().numpy(), g["logweights"], rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("n,chunk", [(12, 12), (1000, 1000), (65536, 512), (65536, 65536), (777, 100), (5, 1)])
+def test_quantile_clamp_kernel(pa, n, chunk):
+    """K11 against torch.quantile (CPU) per chunk: exact order statistics, torch's lerp."""
+    gen = torch.Generator().manual_seed(n + chunk)
+    a = torch.randn(n, generator=gen) * 10
+    a[::7] = a[0]  # ties
+    want = a.clone()
+    for lo in range(0, n, chunk):
+        c = want[lo:lo + chunk]
+        want[lo:lo + chunk] = torch.clamp(c, max=torch.quantile(c, 0.9))
+    got = a.cuda().clone()
+    pa._lib.check(pa._lib.lib().pita_quantile_clamp(got.data_ptr(), n, chunk, 0.9, pa._lib.stream_ptr()))
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-6, atol=1e-6)
