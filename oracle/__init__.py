@@ -1,0 +1,1 @@
+"""CPU oracle of the PITA sampling path (test infrastructure only; see pita_oracle.py)."""
