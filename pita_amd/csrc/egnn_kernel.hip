@@ -590,7 +590,9 @@ static int egnn_launch(pita_egnn_t* net, EgnnParams& p, void* stream) {
   if (p.B == 0) return PITA_OK;
   const long long ngroups = (p.B + s->G - 1) / s->G;
   const size_t lds = s->lds_bytes(p.n_layers);
-  const int blocks_per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
+  // resident blocks per CU: limited by LDS and by the 256-VGPR budget (2 waves per SIMD = two 4-wave blocks)
+  int blocks_per_cu = (int)((160 * 1024) / lds);
+  blocks_per_cu = blocks_per_cu < 1 ? 1 : (blocks_per_cu > 2 ? 2 : blocks_per_cu);
   long long want = (ngroups + s->waves - 1) / s->waves;
   long long cap = (long long)net->n_cu * blocks_per_cu;
   // forward modes: one group per wave (plain grid); sampler mode: persistent grid-stride
