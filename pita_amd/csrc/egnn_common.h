@@ -128,11 +128,14 @@ struct WFrag<1> {
 // (8 for v_exp/v_rcp) whether it is v_mul_f32 or v_pk_mul_f32, so packed math (2 lanes-worth of fp32 per
 // instruction) halves the issue cost of every mul/add/fma around the transcendentals.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// SiLU on PRE-SCALED pre-activations: the host folds kS = -log2(e) into the weights that produce a SiLU input
+// (egnn_kernel.hip: pita_egnn_create), so v = kS z, exp(-z) = exp2(v) and the result v / (1 + exp2(v)) = kS silu(z)
+// (the 1/kS is folded into the consumers).  Saves one multiply per activation in the VALU-bound edge loop.
+constexpr float SILU_PRESCALE = -1.44269504088896341f;
 __device__ __forceinline__ f32x2 silu2(f32x2 v) {
-  const f32x2 t = v * -1.44269504088896341f;
   f32x2 e;
-  e.x = __builtin_amdgcn_exp2f(t.x);
-  e.y = __builtin_amdgcn_exp2f(t.y);
+  e.x = __builtin_amdgcn_exp2f(v.x);
+  e.y = __builtin_amdgcn_exp2f(v.y);
   const f32x2 d = e + 1.0f;
   f32x2 r;
   r.x = __builtin_amdgcn_rcpf(d.x);

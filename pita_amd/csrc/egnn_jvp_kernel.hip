@@ -60,11 +60,12 @@ struct JvpCfg {
   }
 };
 
-// silu and its derivative factor: y = z s, g = s (1 + z (1 - s)) with s = sigmoid(z)
-__device__ __forceinline__ void silu_dsilu(float z, float& y, float& g) {
-  const float s = fast_sigmoid(z);
-  y = z * s;
-  g = s * fmaf(z, 1.0f - s, 1.0f);
+// silu on pre-scaled pre-activations (v = kS z, see egnn_common.h) and the derivative factor of the scaled map:
+// y' = kS silu(z) = v s, dy' = g dv with g = silu'(z) = s (1 + z (1 - s)), s = sigmoid(z) = 1/(1 + exp2(v)), z = v / kS
+__device__ __forceinline__ void silu_dsilu(float v, float& y, float& g) {
+  const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v));
+  y = v * s;
+  g = s * fmaf(v * (1.0f / SILU_PRESCALE), 1.0f - s, 1.0f);
 }
 
 template <int N, int DIM, int G, int WAVES>

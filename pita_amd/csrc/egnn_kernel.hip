@@ -453,23 +453,29 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
       h_vecs[32 + hh * 16 + r] = (nf == 2) ? emb_w[f * nf + 1] : 0.f;
       h_vecs[64 + hh * 16 + r] = emb_b[f];
     }
-  auto pack_mat = [&](float* dst, const float* M, int ld, int col0) {
+  // SiLU pre-activations are kept in the scaled form z' = kS z (kS = -log2 e): then exp(-z) = exp2(z') needs no
+  // multiply and y' = z' / (1 + exp2(z')) = kS silu(z).  The scale is folded into the weights once, here:
+  //   producers of a SiLU input (Wa, Wb, w_r, w_e, b1, b2, bc1, Wn1a, bn1)      x kS
+  //   linear consumers of a SiLU output that do NOT feed another SiLU (w_att, w_c2, Wn2)   x 1/kS
+  //   W2, Wc1, Wn1b (SiLU output -> SiLU input) and the node features h stay unscaled.
+  const float kS = SILU_PRESCALE, kSi = 1.0f / SILU_PRESCALE;
+  auto pack_mat = [&](float* dst, const float* M, int ld, int col0, float sc) {
     for (int qd = 0; qd < 4; ++qd)
       for (int lane = 0; lane < 64; ++lane)
         for (int s = 0; s < 4; ++s)
-          dst[(qd * 64 + lane) * 4 + s] = M[(lane & 31) * ld + col0 + kfeat(4 * qd + s, lane >> 5)];
+          dst[(qd * 64 + lane) * 4 + s] = sc * M[(lane & 31) * ld + col0 + kfeat(4 * qd + s, lane >> 5)];
   };
   // bf16 three-way truncation split of the same fragments: word q of (piece, kstep st, lane) packs the
   // pieces of elements r = 8 st + 2q (low half) and r + 1 (high half)
   auto trunc16 = [](float v) { unsigned u; memcpy(&u, &v, 4); u &= 0xFFFF0000u; float o; memcpy(&o, &u, 4); return o; };
   auto hi16 = [](float v) { unsigned u; memcpy(&u, &v, 4); return u >> 16; };
-  auto pack_mat16 = [&](unsigned* dst, const float* M, int ld, int col0) {
+  auto pack_mat16 = [&](unsigned* dst, const float* M, int ld, int col0, float sc) {
     for (int lane = 0; lane < 64; ++lane)
       for (int st = 0; st < 2; ++st)
         for (int qd = 0; qd < 4; ++qd) {
           unsigned pcs[2][3];
           for (int e = 0; e < 2; ++e) {
-            const float w = M[(lane & 31) * ld + col0 + kfeat(8 * st + 2 * qd + e, lane >> 5)];
+            const float w = sc * M[(lane & 31) * ld + col0 + kfeat(8 * st + 2 * qd + e, lane >> 5)];
             const float w1 = trunc16(w), r1 = w - w1, w2 = trunc16(r1), r2 = r1 - w2;
             pcs[e][0] = hi16(w1); pcs[e][1] = hi16(w2); pcs[e][2] = hi16(r2);
           }
@@ -477,9 +483,9 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
             dst[(((size_t)pc * 2 + st) * 64 + lane) * 4 + qd] = pcs[0][pc] | (pcs[1][pc] << 16);
         }
   };
-  auto pack_vec = [&](float* dst, const float* v, int stride) {
+  auto pack_vec = [&](float* dst, const float* v, int stride, float sc) {
     for (int hh = 0; hh < 2; ++hh)
-      for (int r = 0; r < 16; ++r) dst[hh * 16 + r] = v[kfeat(r, hh) * stride];
+      for (int r = 0; r < 16; ++r) dst[hh * 16 + r] = sc * v[kfeat(r, hh) * stride];
   };
   for (int l = 0; l < L; ++l) {
     float* mats = h_mats + (size_t)l * M_COUNT * MAT_F;
@@ -498,31 +504,31 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
     const float* aw = nullptr; const float* ab = nullptr;
     if (cfg->attention) { aw = q; q += H; ab = q; q += 1; }
     unsigned* m16 = h_mats16 + (size_t)l * M_COUNT * MAT_W;
-    pack_mat16(m16 + M_WA * MAT_W, e0w, 2 * H + 2, 0);
-    pack_mat16(m16 + M_WB * MAT_W, e0w, 2 * H + 2, H);
-    pack_mat16(m16 + M_W2 * MAT_W, e2w, H, 0);
-    pack_mat16(m16 + M_WC1 * MAT_W, c0w, H, 0);
-    pack_mat16(m16 + M_WN1A * MAT_W, n0w, 2 * H, 0);
-    pack_mat16(m16 + M_WN1B * MAT_W, n0w, 2 * H, H);
-    pack_mat16(m16 + M_WN2 * MAT_W, n2w, H, 0);
-    pack_mat(mats + M_WA * MAT_F, e0w, 2 * H + 2, 0);
-    pack_mat(mats + M_WB * MAT_F, e0w, 2 * H + 2, H);
-    pack_mat(mats + M_W2 * MAT_F, e2w, H, 0);
-    pack_mat(mats + M_WC1 * MAT_F, c0w, H, 0);
-    pack_mat(mats + M_WN1A * MAT_F, n0w, 2 * H, 0);
-    pack_mat(mats + M_WN1B * MAT_F, n0w, 2 * H, H);
-    pack_mat(mats + M_WN2 * MAT_F, n2w, H, 0);
+    pack_mat16(m16 + M_WA * MAT_W, e0w, 2 * H + 2, 0, kS);
+    pack_mat16(m16 + M_WB * MAT_W, e0w, 2 * H + 2, H, kS);
+    pack_mat16(m16 + M_W2 * MAT_W, e2w, H, 0, 1.0f);
+    pack_mat16(m16 + M_WC1 * MAT_W, c0w, H, 0, 1.0f);
+    pack_mat16(m16 + M_WN1A * MAT_W, n0w, 2 * H, 0, kS);
+    pack_mat16(m16 + M_WN1B * MAT_W, n0w, 2 * H, H, 1.0f);
+    pack_mat16(m16 + M_WN2 * MAT_W, n2w, H, 0, kSi);
+    pack_mat(mats + M_WA * MAT_F, e0w, 2 * H + 2, 0, kS);
+    pack_mat(mats + M_WB * MAT_F, e0w, 2 * H + 2, H, kS);
+    pack_mat(mats + M_W2 * MAT_F, e2w, H, 0, 1.0f);
+    pack_mat(mats + M_WC1 * MAT_F, c0w, H, 0, 1.0f);
+    pack_mat(mats + M_WN1A * MAT_F, n0w, 2 * H, 0, kS);
+    pack_mat(mats + M_WN1B * MAT_F, n0w, 2 * H, H, 1.0f);
+    pack_mat(mats + M_WN2 * MAT_F, n2w, H, 0, kSi);
     for (int o = 0; o < H; ++o) {
-      vecs[V_WRE * EH + o] = e0w[o * (2 * H + 2) + 2 * H];          // w_r[out]  (k = 0: radial)
-      vecs[V_WRE * EH + H + o] = e0w[o * (2 * H + 2) + 2 * H + 1];  // w_e[out]  (k = 1: edge_attr)
+      vecs[V_WRE * EH + o] = kS * e0w[o * (2 * H + 2) + 2 * H];          // w_r[out]  (k = 0: radial)
+      vecs[V_WRE * EH + H + o] = kS * e0w[o * (2 * H + 2) + 2 * H + 1];  // w_e[out]  (k = 1: edge_attr)
     }
-    pack_vec(vecs + V_B1 * EH, e0b, 1);
-    pack_vec(vecs + V_B2 * EH, e2b, 1);
-    if (aw) pack_vec(vecs + V_WATT * EH, aw, 1);
-    pack_vec(vecs + V_BC1 * EH, c0b, 1);
-    pack_vec(vecs + V_WC2 * EH, c2w, 1);
-    pack_vec(vecs + V_BN1 * EH, n0b, 1);
-    pack_vec(vecs + V_BN2 * EH, n2b, 1);
+    pack_vec(vecs + V_B1 * EH, e0b, 1, kS);
+    pack_vec(vecs + V_B2 * EH, e2b, 1, kS);
+    if (aw) pack_vec(vecs + V_WATT * EH, aw, 1, kSi);
+    pack_vec(vecs + V_BC1 * EH, c0b, 1, kS);
+    pack_vec(vecs + V_WC2 * EH, c2w, 1, kSi);
+    pack_vec(vecs + V_BN1 * EH, n0b, 1, kS);
+    pack_vec(vecs + V_BN2 * EH, n2b, 1, 1.0f);
     vecs[V_COUNT * EH] = ab ? ab[0] : 0.f;
   }
   pita_egnn* net = new pita_egnn();
