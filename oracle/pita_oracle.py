@@ -309,7 +309,7 @@ def egnn_edges(n: int) -> Tuple[Tensor, Tensor]:
     return torch.tensor(rows, dtype=torch.long), torch.tensor(cols, dtype=torch.long)
 
 
-def egnn_node_features(t: Tensor, beta: Optional[Tensor], n: int) -> Tensor:
+def egnn_node_features(t: Tensor, beta: Optional[Tensor], n: int, layout: str = "pita") -> Tensor:
     """Initial node features ``h0[B*n, in_nf]``.
 
     With temperature conditioning the reference concatenates two ``[B,n]`` tensors along
@@ -321,6 +321,8 @@ def egnn_node_features(t: Tensor, beta: Optional[Tensor], n: int) -> Tensor:
     if beta is None:
         return h.reshape(B * n, 1)
     hb = torch.ones(B, n, dtype=t.dtype) * beta[:, None]
+    if layout == "correct":  # (t, beta) on every node -- what egnn_aldp.py:157-167 does; NOT the LJ reference behaviour
+        return torch.stack([h, hb], dim=-1).reshape(B * n, 2)
     return torch.cat([h, hb], dim=-1).reshape(B * n, 2)
 
 
@@ -330,7 +332,7 @@ def _silu(v: Tensor) -> Tensor:
 
 def egnn_forward(p: Dict[str, Tensor], t: Tensor, x: Tensor, beta: Optional[Tensor], n: int, d: int,
                  n_layers: int = 3, coords_range: float = 15.0, tanh: bool = True, attention: bool = True,
-                 return_h0: bool = False):
+                 return_h0: bool = False, feature_layout: str = "pita"):
     """EGNN_dynamics.forward: velocity ``x_final - x`` made mean-free.
 
     ``p`` is the reference ``state_dict`` (keys ``egnn.embedding.weight`` ...).  Materialises
@@ -347,7 +349,7 @@ def egnn_forward(p: Dict[str, Tensor], t: Tensor, x: Tensor, beta: Optional[Tens
     col = (col1[None] + off).reshape(-1)
     pos = x.reshape(B * n, d).clone()
     pos0 = pos
-    h = egnn_node_features(t, beta, n)
+    h = egnn_node_features(t, beta, n, feature_layout)
     h0 = h
     edge_attr = ((pos[row] - pos[col]) ** 2).sum(dim=1, keepdim=True)  # :79 (frozen, quirk Q10)
     h = h @ P["egnn.embedding.weight"].T + P["egnn.embedding.bias"]  # :179

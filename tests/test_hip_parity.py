@@ -153,8 +153,14 @@ def test_egnn_notemp_and_layouts(pa, golden):
     x = torch.randn(9, 39, generator=gen)
     t, b = torch.randn(9, generator=gen), torch.rand(9, generator=gen) + 0.5
     out = netc(t.cuda(), x.cuda(), b.cuda())
-    assert torch.isfinite(out).all()
+    ref = O.egnn_forward({k: T(v) for k, v in w2.items()}, t, x, b, 13, 3, feature_layout="correct")
+    assert rel(out, ref) < 2e-5
     assert abs(out.reshape(9, 13, 3).mean(1)).max() < 1e-5  # mean-free output
+    # with the "correct" layout the network is permutation equivariant (the reference's quirk breaks this)
+    perm = torch.randperm(13, generator=gen)
+    xp = x.reshape(9, 13, 3)[:, perm].reshape(9, 39)
+    outp = netc(t.cuda(), xp.cuda(), b.cuda())
+    assert rel(outp, out.reshape(9, 13, 3)[:, perm.cuda()].reshape(9, 39)) < 2e-5
 
 
 @pytest.mark.parametrize("B", [1, 6, 7, 8, 100, 1001])
