@@ -257,9 +257,8 @@ class WeightedSDEIntegrator:
                 logweights.append(comm.all_gather(a))
                 num_unique_idxs.append(Bg)
                 continue
-            chunks = [self.sde.f(t, x[lo:lo + bs], beta, gamma_schedule, None, energy_function, resampling_interval)
-                      for lo in range(0, Bl, bs)]
-            terms = SDETerms.concatenate(chunks)
+            # one set of launches for the rank's whole shard; the quantile clamp keeps its per-chunk meaning
+            terms = self.sde.f(t, x, beta, gamma_schedule, None, energy_function, resampling_interval, clamp_chunk=bs)
             drift = terms.drift_X.contiguous()
             nz = noise[step].contiguous() if noise is not None else None
             _lib.check(L.pita_em_step(x.data_ptr(), drift.data_ptr(), _lib.ptr(nz), Bl, n, d, float(row[_lib.ST_DT]),

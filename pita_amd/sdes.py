@@ -66,14 +66,18 @@ class VEReverseSDE:
         drift_X = gamma_energy * (score * self.g(t).pow(2).unsqueeze(-1))
         return SDETerms(drift_X=drift_X.detach(), drift_A=torch.zeros(x.shape[0], device=x.device))
 
-    def f(self, t, x, beta, gamma_energy_schedule, gamma_score, energy_function, resampling_interval=-1):
+    def f(self, t, x, beta, gamma_energy_schedule, gamma_score, energy_function, resampling_interval=-1,
+          clamp_chunk=None):
+        """``clamp_chunk`` (extension): evaluate the whole batch in one set of launches but apply the 0.9-quantile
+        clamp of the weight drift per chunk of that many walkers -- what the reference gets by calling ``f`` once per
+        inference chunk (sde_integration.py:312-343, sdes.py:230), without its per-chunk launch overhead."""
         gamma_energy = gamma_energy_schedule.gamma(t)  # gamma_score is overwritten by it (sdes.py:142-143)
         t = _per_walker(t, x)
         if isinstance(gamma_energy, torch.Tensor):
             gamma_energy = gamma_energy.to(x.device)
         if not self.debias_inference:
             return self.f_not_debiased(t, x, beta, gamma_energy)
-        return self.f_debiased(t, x, beta, gamma_energy, gamma_energy_schedule)
+        return self.f_debiased(t, x, beta, gamma_energy, gamma_energy_schedule, clamp_chunk)
 
     # ------------------------------------------------------------------ debiased regime (sdes.py:151-239)
     def _denoiser_jacobian_terms(self, model, ht, x, beta, want_h_direction):
@@ -97,7 +101,7 @@ class VEReverseSDE:
                       want_tangent=False, dot_out=dot_h)
         return Dx, trace, jtx, dot_h
 
-    def f_debiased(self, t, x, beta, gamma_energy, gamma_energy_schedule):
+    def f_debiased(self, t, x, beta, gamma_energy, gamma_energy_schedule, clamp_chunk=None):
         assert self.energy_net is not None
         if self.pin_energy or getattr(self.energy_net, "precondition_beta", False) or (
                 self.score_net is not None and getattr(self.score_net, "precondition_beta", False)):
@@ -123,8 +127,8 @@ class VEReverseSDE:
             div_bt.data_ptr(), cross.data_ptr(), dUdt.data_ptr(), Ut.data_ptr(), B, D, _lib.stream_ptr(x.device)),
             "pita_fk_assemble")
         # 0.9-quantile clamp of the weight drift over this inference chunk (sdes.py:230), K11
-        _lib.check(_lib.lib().pita_quantile_clamp(drift_A.data_ptr(), B, B, 0.9, _lib.stream_ptr(x.device)),
-                   "pita_quantile_clamp")
+        _lib.check(_lib.lib().pita_quantile_clamp(drift_A.data_ptr(), B, int(clamp_chunk or B), 0.9,
+                                                  _lib.stream_ptr(x.device)), "pita_quantile_clamp")
         return SDETerms(drift_X=drift_X, drift_A=drift_A, divergence_score=div_bt, cross_term=cross, dUt_dt=dUdt)
 
     def diffusion(self, t, x, diffusion_scale):

@@ -488,6 +488,13 @@ def test_debiased_terms_and_trajectory_golden(pa, golden):
     assert uniq == list(g["num_unique"])
     assert rel(x, g["x_final"]) < 3e-3
     np.testing.assert_allclose(logw.cpu().numpy(), g["logweights"], rtol=1e-2, atol=1e-2)
+    # whole-batch evaluation with a per-chunk clamp == one call per chunk (the reference's loop)
+    xa = pa.Prior(scale=3.0, n_particles=13, spatial_dim=3, seed=4).sample(24)
+    t = torch.tensor(0.4).cuda()
+    whole = sde.f(t, xa, 1.0, gam, None, None, clamp_chunk=8)
+    parts = [sde.f(t, xa[lo:lo + 8], 1.0, gam, None, None) for lo in range(0, 24, 8)]
+    assert torch.equal(whole.drift_A, torch.cat([p_.drift_A for p_ in parts]))
+    assert torch.equal(whole.drift_X, torch.cat([p_.drift_X for p_ in parts]))
 
 
 @pytest.mark.parametrize("n,chunk", [(12, 12), (1000, 1000), (65536, 512), (65536, 65536), (777, 100), (5, 1)])
