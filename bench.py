@@ -92,6 +92,54 @@ def cpu_baseline(n_walkers, n_steps, seed=12345):
             f"torch-CPU fp32, {dt:.1f} s with {nthr} threads (host has {os.cpu_count()} logical CPUs)"}
 
 
+def debiased_leg(pita_amd, net, dev, B, with_cpu):
+    """Secondary number: the debiased Feynman-Kac regime (PITA's default; sdes.py:151-239): drift of x and of the
+    log-weights through 79 forward-mode launches (pita_egnn_jvp) + assembly + quantile clamp, then the EM update."""
+    import copy
+
+    from pita_amd.energy_net import EnergyNet
+
+    sched = pita_amd.ElucidatingNoiseSchedule(sigma_min=0.05, sigma_max=80.0, rho=7)
+    gam = pita_amd.ConstantAnnealingFactorSchedule(4 / 3)
+    sde = pita_amd.VEReverseSDE(noise_schedule=sched, score_net=pita_amd.ScoreNet(net),
+                                energy_net=EnergyNet(copy.deepcopy(net)), debias_inference=True)
+    x = pita_amd.Prior(scale=3.0, n_particles=13, spatial_dim=3, device=dev, seed=7).sample(B)
+    t = torch.tensor(0.5, device=dev)
+    L = pita_amd._lib.lib()
+
+    def step():
+        terms = sde.f(t, x, 1.0, gam, None, None, clamp_chunk=512)
+        L.pita_em_step(x.data_ptr(), terms.drift_X.data_ptr(), 0, B, 13, 3, 1e-3, 0.1, float(np.sqrt(1e-3)), 1, 0, 0, 1,
+                       pita_amd._lib.stream_ptr(dev))
+        return terms
+
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 2
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    out = {"metric": "walker-steps/s, debiased (Feynman-Kac) regime, LJ13", "value": B / dt, "walkers": B,
+           "ms_per_step": dt * 1e3, "launches_per_step": 79 + 3}
+    if with_cpu:
+        from oracle import pita_oracle as O
+
+        w = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        bb = lambda cn, xs, b: O.egnn_forward(w, cn, xs, b, 13, 3)
+        osched, ogam = O.Elucidating(0.05, 80.0, 7), O.GammaConstant(4 / 3)
+        nb = 48
+        xc = x[:nb].cpu()
+        torch.set_num_threads(min(16, torch.get_num_threads()))
+        t0 = time.perf_counter()
+        O.f_debiased(bb, bb, osched, ogam, torch.tensor(0.5), xc, 1.0)
+        dtc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": nb / dtc, "unit": "walker-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"oracle f_debiased (autograd + vmap(jacrev)), {nb} walkers x 1 step, {dtc:.1f} s"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,6 +149,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="SDE steps per kernel launch (default gcd(steps, warmup))")
     ap.add_argument("--force-evals", type=int, default=200, help="LJ13 force-kernel launches for its roofline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-debiased", action="store_true", help="skip the secondary debiased-regime measurement")
     ap.add_argument("--cpu-walkers", type=int, default=512)
     ap.add_argument("--cpu-steps", type=int, default=60)
     args = ap.parse_args()
@@ -252,6 +301,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_walkers, args.cpu_steps)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not args.no_debiased:
+            out["debiased"] = debiased_leg(pita_amd, net, dev, B, with_cpu=not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

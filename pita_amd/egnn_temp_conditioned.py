@@ -82,10 +82,14 @@ class EGNN_dynamics(nn.Module):
                                int(e.attention), int(e.tanh), e.coords_range, self.feature_layout, self.precision)
 
     def _native(self, device):
-        params = list(self.state_dict().values())
-        key = (device.index, self.precision) + tuple((p.data_ptr(), p._version) for p in params)
+        # cheap staleness check on every call: (storage pointer, version counter) of every parameter/buffer
+        tensors = self.__dict__.get("_tensor_list")
+        if tensors is None:
+            tensors = self.__dict__["_tensor_list"] = list(self.parameters()) + list(self.buffers())
+        key = (device.index, self.precision) + tuple((p.data_ptr(), p._version) for p in tensors)
         if self._handle is None or key != self._handle_key:
             self._release()
+            params = list(self.state_dict().values())
             flat = torch.cat([p.detach().to("cpu", torch.float32).reshape(-1) for p in params]).contiguous().numpy()
             cfg = self._config()
             h = ctypes.c_void_p()
@@ -95,6 +99,13 @@ class EGNN_dynamics(nn.Module):
                            "pita_egnn_create")
             self._handle, self._handle_key = h, key
         return self._handle
+
+    def __getstate__(self):
+        """The native handle is a per-process device resource: copies / pickles start without one."""
+        state = self.__dict__.copy()
+        state["_handle"], state["_handle_key"] = None, None
+        state.pop("_tensor_list", None)
+        return state
 
     def _release(self):
         if self._handle is not None:

@@ -43,10 +43,13 @@ class _HipMLP(nn.Module):
         return torch.exp(-w * torch.arange(half)).contiguous()
 
     def _native(self, device):
-        params = list(self.state_dict().values())
-        key = (device.index,) + tuple((p.data_ptr(), p._version) for p in params)
+        tensors = self.__dict__.get("_tensor_list")
+        if tensors is None:
+            tensors = self.__dict__["_tensor_list"] = list(self.parameters()) + list(self.buffers())
+        key = (device.index,) + tuple((p.data_ptr(), p._version) for p in tensors)
         if self._handle is None or key != self._handle_key:
             self._release()
+            params = list(self.state_dict().values())
             flat = torch.cat([p.detach().to("cpu", torch.float32).reshape(-1) for p in params]).contiguous().numpy()
             fr = self._freqs().numpy()
             cfg = _lib.MlpConfig(self.input_dim, self.out_dim, self.hidden_size, self.hidden_layers, self.emb_size,
@@ -58,6 +61,13 @@ class _HipMLP(nn.Module):
                                                       fr.ctypes.data_as(ctypes.c_void_p)), "pita_mlp_create")
             self._handle, self._handle_key = h, key
         return self._handle
+
+    def __getstate__(self):
+        """The native handle is a per-process device resource: copies / pickles start without one."""
+        state = self.__dict__.copy()
+        state["_handle"], state["_handle_key"] = None, None
+        state.pop("_tensor_list", None)
+        return state
 
     def _release(self):
         if self._handle is not None:
