@@ -71,6 +71,28 @@ int pita_gmm_logp_force(const float* x, float* logp, float* force /*nullable*/, 
                         const float* means, const float* scales, int K, float temperature,
                         void* stream);
 
+/* Table-driven classical force field (K4): bonds, angles, periodic torsions, LJ + Coulomb over all atom pairs with
+ * exceptions and the optional CutoffNonPeriodic reaction field -- the functional forms of OpenMM's HarmonicBondForce,
+ * HarmonicAngleForce, PeriodicTorsionForce and NonbondedForce.  Stands in for the arithmetic ALPEnergy.__call__
+ * (pita/src/energies/alp_energy.py:122-149) delegates to OpenMM; the GB-OBC1 term is not implemented and the real
+ * amber14 parameters are outside the reference tree (parity unpinned).  All table pointers are HOST pointers copied at
+ * creation.  Units: nm, kJ/mol, elementary charges; x_model * length_scale = nm; logp = -E/kT. */
+typedef struct pita_ff pita_ff_t;
+typedef struct {
+  int n_atoms;
+  int n_bonds;      const int* bond_idx;  /* [n_bonds][2] */      const float* bond_par;  /* [n_bonds][2]: r0, k */
+  int n_angles;     const int* angle_idx; /* [n_angles][3] */     const float* angle_par; /* [n_angles][2]: theta0, k */
+  int n_torsions;   const int* tors_idx;  /* [n_torsions][4] */   const float* tors_par;  /* [n_torsions][3]: periodicity, phase, k */
+  const float* charge; const float* sigma; const float* epsilon;  /* per atom; Lorentz-Berthelot mixing */
+  int n_exceptions; const int* exc_idx;   /* [n_exceptions][2] */ const float* exc_par;   /* [n][3]: chargeProd, sigma, epsilon */
+  int use_cutoff; float cutoff; float rf_dielectric;              /* CutoffNonPeriodic reaction field (78.3 in OpenMM) */
+  float length_scale;                                              /* 0.1640 for the reference's normalised ALDP (energy/aldp.yaml:11) */
+  float kT;                                                        /* kJ/mol */
+} pita_ff_config;
+int pita_ff_create(pita_ff_t** out, const pita_ff_config* cfg);
+int pita_ff_destroy(pita_ff_t* ff);
+int pita_ff_logp_force(pita_ff_t* ff, const float* x, float* logp, float* force /*nullable*/, int64_t B, void* stream);
+
 /* ---------------------------------------------------------------- EGNN backbone (K5, K7)
  * replaces EGNN_dynamics.forward (pita/src/models/components/egnn_temp_conditioned.py:56-93,
  * egnn.py:50-80), EGNN.forward (:172-194), E_GCL (:197-356) and the EDM wrappers

@@ -682,3 +682,88 @@ def w2_1d(a: np.ndarray, b: np.ndarray) -> float:
     ia = np.minimum(np.searchsorted(qa, q - 1e-15), len(a) - 1)
     ib = np.minimum(np.searchsorted(qb, q - 1e-15), len(b) - 1)
     return float(np.sqrt(np.sum(w * (a[ia] - b[ib]) ** 2)))
+
+
+# --------------------------------------------------------------------------------------
+# A14 classical force field (PARITY UNPINNED).  The reference evaluates alanine dipeptide with OpenMM
+# (amber14-all + implicit/obc1, CutoffNonPeriodic 2 nm) through bgflow (alp_energy.py:93-149); neither OpenMM nor
+# the PDB / force-field XML are in the tree, so only the published functional forms of OpenMM's standard forces are
+# restated here (HarmonicBondForce, HarmonicAngleForce, PeriodicTorsionForce, NonbondedForce with Lorentz-Berthelot
+# mixing, exceptions and the CutoffNonPeriodic reaction field).  The GB-OBC1 implicit-solvent term is NOT restated.
+# --------------------------------------------------------------------------------------
+
+ONE_4PI_EPS0 = 138.935456  # kJ nm / (mol e^2), OpenMM's constant
+
+
+def ff_energy(x: Tensor, ff: Dict[str, Tensor], length_scale: float = 1.0, cutoff: Optional[float] = None,
+              rf_dielectric: float = 78.3) -> Tensor:
+    """Potential energy [kJ/mol] per walker of a table-driven molecular force field.
+    x: [B, 3n] in model units (x * length_scale = nm).  ff: index / parameter tables:
+      bond_idx[nb,2], bond_par[nb,2]=(r0,k)            E = 1/2 k (r - r0)^2
+      angle_idx[na,3], angle_par[na,2]=(th0,k)         E = 1/2 k (theta - th0)^2
+      tors_idx[nt,4], tors_par[nt,3]=(n,phase,k)       E = k (1 + cos(n phi - phase))
+      charge[n], sigma[n], epsilon[n]                  LJ 4 eps ((s/r)^12 - (s/r)^6), s=(si+sj)/2, eps=sqrt(ei ej); Coulomb
+      exc_idx[ne,2], exc_par[ne,3]=(qq,sigma,eps)      pairs that replace the mixed parameters (exclusions: zeros)
+    cutoff (nm): None = all pairs, plain Coulomb; else pairs beyond it are dropped and the non-exception Coulomb term is
+    the reaction-field form qq (1/r + k_rf r^2 - c_rf)."""
+    B = x.shape[0]
+    n = ff["charge"].shape[0]
+    r = (x * length_scale).reshape(B, n, 3)
+    dt = r.dtype
+    E = torch.zeros(B, dtype=dt)
+    if ff["bond_idx"].numel():
+        i, j = ff["bond_idx"][:, 0], ff["bond_idx"][:, 1]
+        d = (r[:, i] - r[:, j]).norm(dim=-1)
+        E = E + (0.5 * ff["bond_par"][:, 1].to(dt) * (d - ff["bond_par"][:, 0].to(dt)) ** 2).sum(-1)
+    if ff["angle_idx"].numel():
+        i, j, k = ff["angle_idx"].T
+        a, b = r[:, i] - r[:, j], r[:, k] - r[:, j]
+        cosv = (a * b).sum(-1) / (a.norm(dim=-1) * b.norm(dim=-1))
+        th = torch.acos(cosv.clamp(-1.0, 1.0))
+        E = E + (0.5 * ff["angle_par"][:, 1].to(dt) * (th - ff["angle_par"][:, 0].to(dt)) ** 2).sum(-1)
+    if ff["tors_idx"].numel():
+        i, j, k, l = ff["tors_idx"].T
+        b1, b2, b3 = r[:, j] - r[:, i], r[:, k] - r[:, j], r[:, l] - r[:, k]
+        n1, n2 = torch.cross(b1, b2, dim=-1), torch.cross(b2, b3, dim=-1)
+        yv = (b1 * n2).sum(-1) * b2.norm(dim=-1)
+        xv = (n1 * n2).sum(-1)
+        phi = torch.atan2(yv, xv)
+        per, ph, kk = (ff["tors_par"][:, c].to(dt) for c in range(3))
+        E = E + (kk * (1 + torch.cos(per * phi - ph))).sum(-1)
+    # nonbonded: all i<j pairs, exceptions override
+    iu = torch.triu_indices(n, n, offset=1)
+    q, sg, ep = ff["charge"].to(dt), ff["sigma"].to(dt), ff["epsilon"].to(dt)
+    qq = q[iu[0]] * q[iu[1]]
+    s = 0.5 * (sg[iu[0]] + sg[iu[1]])
+    e = torch.sqrt(ep[iu[0]] * ep[iu[1]])
+    is_exc = torch.zeros(iu.shape[1], dtype=torch.bool)
+    if ff["exc_idx"].numel():
+        lut = {(int(a), int(b)): t for t, (a, b) in enumerate(zip(iu[0], iu[1]))}
+        for t, (a, b) in enumerate(ff["exc_idx"].tolist()):
+            p = lut[(min(a, b), max(a, b))]
+            is_exc[p] = True
+            qq[p], s[p], e[p] = ff["exc_par"][t, 0].to(dt), ff["exc_par"][t, 1].to(dt), ff["exc_par"][t, 2].to(dt)
+    d = (r[:, iu[0]] - r[:, iu[1]]).norm(dim=-1)
+    sr6 = (s / d) ** 6
+    lj = 4 * e * (sr6 * sr6 - sr6)
+    if cutoff is None:
+        coul = ONE_4PI_EPS0 * qq / d
+        E = E + (lj + coul).sum(-1)
+    else:
+        krf = (1.0 / cutoff**3) * (rf_dielectric - 1) / (2 * rf_dielectric + 1)
+        crf = (1.0 / cutoff) * (3 * rf_dielectric) / (2 * rf_dielectric + 1)
+        coul_rf = ONE_4PI_EPS0 * qq * (1 / d + krf * d * d - crf)
+        coul_plain = ONE_4PI_EPS0 * qq / d
+        coul = torch.where(is_exc, coul_plain, coul_rf)
+        inside = (d < cutoff).to(dt)
+        E = E + ((lj + coul) * inside).sum(-1)
+    return E
+
+
+def ff_logp_force(x: Tensor, ff: Dict[str, Tensor], kT: float, length_scale: float = 1.0, cutoff: Optional[float] = None,
+                  rf_dielectric: float = 78.3) -> Tuple[Tensor, Tensor]:
+    """(logp, d logp / dx) with logp = -E/kT; forces by autograd (the test-side ground truth)."""
+    xg = x.detach().clone().requires_grad_(True)
+    lp = -ff_energy(xg, ff, length_scale, cutoff, rf_dielectric) / kT
+    (g,) = torch.autograd.grad(lp.sum(), xg)
+    return lp.detach(), g

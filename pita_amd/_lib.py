@@ -26,6 +26,17 @@ class EgnnConfig(ctypes.Structure):
                 ("feature_layout", c_int), ("precision", c_int)]
 
 
+class FfConfig(ctypes.Structure):
+    _fields_ = [("n_atoms", c_int),
+                ("n_bonds", c_int), ("bond_idx", c_void_p), ("bond_par", c_void_p),
+                ("n_angles", c_int), ("angle_idx", c_void_p), ("angle_par", c_void_p),
+                ("n_torsions", c_int), ("tors_idx", c_void_p), ("tors_par", c_void_p),
+                ("charge", c_void_p), ("sigma", c_void_p), ("epsilon", c_void_p),
+                ("n_exceptions", c_int), ("exc_idx", c_void_p), ("exc_par", c_void_p),
+                ("use_cutoff", c_int), ("cutoff", c_float), ("rf_dielectric", c_float),
+                ("length_scale", c_float), ("kT", c_float)]
+
+
 class MlpConfig(ctypes.Structure):
     _fields_ = [("input_dim", c_int), ("out_dim", c_int), ("hidden_size", c_int), ("hidden_layers", c_int),
                 ("emb_size", c_int), ("temperature_conditioned", c_int)]
@@ -41,6 +52,9 @@ _PROTOS = {
                                    c_float, c_float, c_void_p]),
     "pita_gmm_logp_force": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_float,
                                     c_void_p]),
+    "pita_ff_create": (c_int, [POINTER(c_void_p), POINTER(FfConfig)]),
+    "pita_ff_destroy": (c_int, [c_void_p]),
+    "pita_ff_logp_force": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "pita_egnn_create": (c_int, [POINTER(c_void_p), POINTER(EgnnConfig), c_void_p, c_int64]),
     "pita_egnn_destroy": (c_int, [c_void_p]),
     "pita_egnn_num_weights": (c_int64, [POINTER(EgnnConfig)]),

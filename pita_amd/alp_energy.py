@@ -1,0 +1,76 @@
+"""Molecular force-field target (alanine-dipeptide class) on the HIP kernel.
+
+Stands in for ``ALPEnergy`` (pita/src/energies/alp_energy.py:24-149): same call contract --
+``energy(samples[B, 3n], return_force=False) -> logp`` (and force), samples in the reference's normalised Cartesian
+coordinates (``x * data_normalization_factor`` = nm, 0.1640 for ALDP), log-density ``-E/kT`` at the integrator
+temperature.  The reference obtains E from OpenMM (amber14-all + implicit/obc1) through bgflow; here the standard
+bonded + nonbonded terms are evaluated by ``pita_ff_logp_force`` from parameter TABLES the caller supplies (e.g.
+exported from the OpenMM ``System`` the reference itself serialises, generate_md.py:105-106).  The GB-OBC1
+implicit-solvent term is not implemented and no amber parameters ship with the reference tree, so this target is
+parity-unpinned.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .base_energy_function import BaseMoleculeEnergy
+
+KB_KJ_PER_MOL_K = 8.314462618e-3
+
+
+class ForceFieldEnergy(BaseMoleculeEnergy):
+    def __init__(self, tables, n_particles, spatial_dim=3, temperature=300.0, data_normalization_factor=1.0,
+                 cutoff=None, rf_dielectric=78.3, device="cuda", is_molecule=True, **kwargs):
+        """tables: dict of numpy arrays / tensors: bond_idx[nb,2], bond_par[nb,2], angle_idx[na,3], angle_par[na,2],
+        tors_idx[nt,4], tors_par[nt,3], charge[n], sigma[n], epsilon[n], exc_idx[ne,2], exc_par[ne,3]."""
+        assert spatial_dim == 3
+        super().__init__(dimensionality=3 * n_particles, n_particles=n_particles, spatial_dim=3, data_path=None,
+                         device=device, is_molecule=is_molecule, temperature=temperature, should_normalize=False,
+                         data_normalization_factor=data_normalization_factor)
+        self.name = "forcefield"
+        self.kT = KB_KJ_PER_MOL_K * float(temperature)
+        self.length_scale = float(data_normalization_factor)
+        self.cutoff, self.rf_dielectric = cutoff, float(rf_dielectric)
+        f32 = lambda k, cols: np.ascontiguousarray(np.asarray(tables.get(k, np.zeros((0, cols))), dtype=np.float32).reshape(-1, cols))
+        i32 = lambda k, cols: np.ascontiguousarray(np.asarray(tables.get(k, np.zeros((0, cols))), dtype=np.int32).reshape(-1, cols))
+        self._t = dict(bond_idx=i32("bond_idx", 2), bond_par=f32("bond_par", 2), angle_idx=i32("angle_idx", 3),
+                       angle_par=f32("angle_par", 2), tors_idx=i32("tors_idx", 4), tors_par=f32("tors_par", 3),
+                       charge=f32("charge", 1), sigma=f32("sigma", 1), epsilon=f32("epsilon", 1),
+                       exc_idx=i32("exc_idx", 2), exc_par=f32("exc_par", 3))
+        assert self._t["charge"].shape[0] == n_particles
+        self._handle = None
+
+    def _native(self):
+        if self._handle is None:
+            t = self._t
+            P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+            cfg = _lib.FfConfig(self.n_particles, len(t["bond_idx"]), P(t["bond_idx"]), P(t["bond_par"]),
+                                len(t["angle_idx"]), P(t["angle_idx"]), P(t["angle_par"]),
+                                len(t["tors_idx"]), P(t["tors_idx"]), P(t["tors_par"]),
+                                P(t["charge"]), P(t["sigma"]), P(t["epsilon"]),
+                                len(t["exc_idx"]), P(t["exc_idx"]), P(t["exc_par"]),
+                                int(self.cutoff is not None), float(self.cutoff or 0.0), self.rf_dielectric,
+                                self.length_scale, self.kT)
+            h = ctypes.c_void_p()
+            _lib.check(_lib.lib().pita_ff_create(ctypes.byref(h), ctypes.byref(cfg)), "pita_ff_create")
+            self._handle = h
+        return self._handle
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                _lib.lib().pita_ff_destroy(self._handle)
+        except Exception:
+            pass
+
+    def __call__(self, samples: torch.Tensor, return_force=False):
+        x = _lib.dev_tensor(samples, "samples").reshape(-1, self._dimensionality)
+        B = x.shape[0]
+        logp = torch.empty(B, device=x.device, dtype=torch.float32)
+        force = torch.empty_like(x) if return_force else None
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().pita_ff_logp_force(self._native(), x.data_ptr(), logp.data_ptr(), _lib.ptr(force), B,
+                                                     _lib.stream_ptr(x.device)), "pita_ff_logp_force")
+        return (logp, force) if return_force else logp
