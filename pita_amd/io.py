@@ -1,0 +1,69 @@
+"""Weights and sample I/O at the edges of the sampling path.
+
+* ``load_reference_checkpoint`` maps a PITA Lightning checkpoint (``energyTempModule.state_dict()``) onto a
+  ``(ScoreNet, EnergyNet)`` pair built from pita_amd backbones.  Key layout of the reference
+  (pita/src/models/energytemp_module.py:94-111, components/ema.py:6-22): the score net is ``EMA(ScoreNet(h_theta))``,
+  so raw weights live under ``score_net.model.model.<backbone key>`` and EMA weights under
+  ``score_net.shadow_params.<i>`` (one entry per trainable parameter, in ``parameters()`` order); the energy net is
+  ``EMA(EnergyNet(deepcopy(h_theta)))`` -> ``energy_net.model.net.<backbone key>`` / ``energy_net.shadow_params.<i>``.
+  ``strict_loading = False`` in the reference (:57), so missing / extra keys are tolerated and reported.
+* ``save_samples`` / ``load_samples`` use the reference's ``torch.save`` of a [B, D] tensor
+  (``samples_temperature_*.pt``, energytemp_module.py:1040-1041); ``load_dataset`` reads the
+  ``{train,val,test}_split_<name><n>-10000.npy`` files (base_molecule_energy_function.py:48-94).
+"""
+import os
+
+import numpy as np
+import torch
+
+
+def _apply(backbone, raw_prefix, shadow_prefix, state, use_ema, report):
+    names = [n for n, p in backbone.named_parameters() if p.requires_grad]
+    own = backbone.state_dict()
+    new = {}
+    for k in own:
+        src = raw_prefix + k
+        if src in state:
+            new[k] = state[src]
+        else:
+            report["missing"].append(src)
+    if use_ema:
+        shadows = [state.get(f"{shadow_prefix}{i}") for i in range(len(names))]
+        if all(s is not None for s in shadows):
+            for n, s in zip(names, shadows):
+                new[n] = s
+            report["ema"].append(shadow_prefix.rstrip("."))
+        else:
+            report["missing"].append(shadow_prefix + "*")
+    backbone.load_state_dict({k: torch.as_tensor(v).to(own[k].dtype).reshape(own[k].shape) for k, v in new.items()},
+                             strict=False)
+
+
+def load_reference_checkpoint(ckpt, score_net=None, energy_net=None, use_ema=True):
+    """ckpt: path to a Lightning ``.ckpt`` / ``torch.save``d dict, or an already loaded state_dict.
+    Returns a report dict {"missing": [...], "ema": [...], "unused": [...]}."""
+    if isinstance(ckpt, (str, os.PathLike)):
+        ckpt = torch.load(ckpt, map_location="cpu", weights_only=False)
+    state = ckpt.get("state_dict", ckpt)
+    report = {"missing": [], "ema": [], "unused": []}
+    if score_net is not None:
+        _apply(score_net.model, "score_net.model.model.", "score_net.shadow_params.", state, use_ema, report)
+    if energy_net is not None:
+        _apply(energy_net.net, "energy_net.model.net.", "energy_net.shadow_params.", state, use_ema, report)
+    used = ("score_net.", "energy_net.")
+    report["unused"] = [k for k in state if not k.startswith(used)]
+    return report
+
+
+def save_samples(samples: torch.Tensor, path: str):
+    torch.save(samples.detach().cpu(), path)
+
+
+def load_samples(path: str, device="cuda") -> torch.Tensor:
+    return torch.load(path, map_location="cpu").to(device=device, dtype=torch.float32)
+
+
+def load_dataset(data_path: str, data_name: str, n_particles: int, temperature: float, split: str = "test", device="cuda"):
+    fmt = "{:0.1f}" if "LJ" in data_name else "{:0.2f}"
+    f = f"{data_path}{data_name}{n_particles}_temp_{fmt.format(temperature)}/{split}_split_{data_name}{n_particles}-10000.npy"
+    return torch.tensor(np.load(f, allow_pickle=True), device=device, dtype=torch.float32)
