@@ -569,3 +569,37 @@ def test_forcefield_vs_oracle(pa, cutoff):
     np.testing.assert_allclose(lp[idx.cuda()].cpu().numpy(), lpo.numpy(), rtol=2e-5, atol=2e-3)
     assert rel(f[idx.cuda()], fo) < 5e-5
     assert abs(f.reshape(B, 22, 3).sum(1)).max() < 1e-3 * f.abs().max().item()  # translation invariance
+
+
+@pytest.mark.parametrize("start,end,interval", [(0, 12, -1), (3, 12, -1), (2, 9, 3), (0, 12, 1), (5, 7, 2)])
+def test_integrator_window_and_resampling_semantics(pa, golden, start, end, interval):
+    """A2 gates (sde_integration.py:278-297): walkers frozen before start_resampling_step, resampling events only
+    inside the window when (step+1) % interval == 0; not-debiased weights are zero so every event resamples with
+    uniform weights.  Same noise and uniforms on both sides -> trajectories agree to fp32 rounding."""
+    w = golden("egnn_weights_trainedlike.npz")
+    net = make_net(pa, 13, 3, w)
+    N, B = 12, 21
+    sched = pa.ElucidatingNoiseSchedule(sigma_min=0.05, sigma_max=80.0, rho=7)
+    gam = pa.ConstantAnnealingFactorSchedule(4 / 3)
+    sde = pa.VEReverseSDE(noise_schedule=sched, score_net=pa.ScoreNet(net), debias_inference=False)
+    gen = torch.Generator().manual_seed(start * 100 + end * 10 + interval + 50)
+    x1 = O.remove_mean(torch.randn(B, 39, generator=gen) * 3, 13, 3)
+    noise = torch.randn(N, B, 39, generator=gen)
+    us = {s: float(torch.rand(1, generator=gen, dtype=torch.float64)) for s in range(N)}
+    events = [] if interval == -1 else [s for s in range(start, min(end, N)) if (s + 1) % interval == 0]
+    integ = pa.WeightedSDEIntegrator(sde=sde, num_integration_steps=N, start_resampling_step=start,
+                                     end_resampling_step=end, resampling_interval=interval, num_negative_time_steps=0,
+                                     post_mcmc_steps=0)
+    e = pa.LennardJonesEnergy(39, 13, 3)
+    x, logw, uniq, _, _ = integ.integrate_sde(x1.cuda(), e, gam, inverse_temperature=1.0, noise=noise.cuda(),
+                                              resample_u=[us[s] for s in events])
+    wt = {k: T(v) for k, v in w.items()}
+    bb = lambda cn, xs, b: O.egnn_forward(wt, cn, xs, b, 13, 3)
+    osched, ogam = O.Elucidating(0.05, 80.0, 7), O.GammaConstant(4 / 3)
+    cfg = O.IntegratorConfig(num_integration_steps=N, start_resampling_step=start, end_resampling_step=end,
+                             resampling_interval=interval)
+    ref = O.integrate_sde(cfg, x1, lambda t, xc: O.f_not_debiased(bb, osched, ogam, t, xc, 1.0), osched.g,
+                          lambda i, shp: noise[i], 13, 3, uniform_fn=lambda s: us[s])
+    assert rel(x, ref["x"]) < 2e-4
+    assert uniq == ref["num_unique"]
+    assert float(logw.abs().max()) == 0.0 and logw.shape == (N, B)
