@@ -63,6 +63,20 @@ int pita_dw_logp_force(const float* x, float* logp, float* force /*nullable*/, i
                        int n_particles, int n_dim, float temperature, float a, float b, float c,
                        float d0, void* stream);
 
+/* Fused descent on the target: nsteps of  x <- remove_mean(x + F(x) dt + (noise_scale xi) sqrt_dt)  in one launch,
+ * walkers resident in LDS throughout.  replaces WeightedSDEIntegrator.negative_time_descent
+ * (pita/src/models/components/sde_integration.py:353-360): dt = dt_negative_time, noise_scale = 1 and
+ * sqrt_dt = sqrt(2 dt) when do_langevin, else noise_scale = 0.  Bit-identical to pita_*_logp_force followed by
+ * pita_em_step, step after step.  noise: nullable device [nsteps, B, n*d]; NULL -> Philox keyed
+ * (seed, walker_offset + walker, step0 + s, particle). */
+int pita_lj_descent(float* x, const float* noise, int64_t B, int n_particles, int n_dim, float temperature,
+                    float energy_factor, float dist_eps, float eps, float rm, float osc_scale, int nsteps, float dt,
+                    float noise_scale, float sqrt_dt, uint64_t seed, uint64_t walker_offset, int64_t step0,
+                    int remove_mean, void* stream);
+int pita_dw_descent(float* x, const float* noise, int64_t B, int n_particles, int n_dim, float temperature, float a,
+                    float b, float c, float d0, int nsteps, float dt, float noise_scale, float sqrt_dt, uint64_t seed,
+                    uint64_t walker_offset, int64_t step0, int remove_mean, void* stream);
+
 /* Diagonal Gaussian mixture with equal weights.
  * replaces GMM.__call__ (pita/src/energies/gmm_energy.py:87-90) ->
  * fab GMM.log_prob (fab/fab/target_distributions/gmm.py:71-79,104).
@@ -225,6 +239,25 @@ int pita_remove_mean(float* x, int64_t B, int n_particles, int n_dim, void* stre
 /* standard normals [B, D] from the library's Philox stream (the generator used when noise==NULL) */
 int pita_fill_normal(float* out, int64_t B, int n_particles, int n_dim, uint64_t seed,
                      uint64_t walker_offset, int64_t step, void* stream);
+
+/* ---------------------------------------------------------------- MALA (K12)
+ * sde_integration.py:28-45 mala_proposal; :362-470 accept/reject and step-size adaptation.
+ * dt_dev: device double holding the step size (adapted in place by pita_mala_adapt, no host round trip).
+ *   propose: x_prop = (x + dt/2 * force) + sqrt(dt) * xi    (noise nullable -> Philox (seed, walker, step, particle))
+ *   accept : log q_f = -|x_prop - (x + dt/2 F)|^2 / 2dt, log q_b = -|x - (x_prop + dt/2 F_prop)|^2 / 2dt,
+ *            accept iff log u < (logp_prop - logp) + (log q_b - log q_f); x and logp are updated in place with the
+ *            reference's float blend a*new + (1-a)*old; optional mean removal (is_molecule); *acc_count += #accepted.
+ *            uniforms nullable -> Philox.
+ *   adapt  : rate = acc_count / total -> rate_out (nullable); adaptive: dt *= 1.1 if rate > 0.55 else dt /= 1.1;
+ *            acc_count is reset.  With several ranks all-reduce acc_count first and pass the global total. */
+int pita_mala_propose(const float* x, const float* force, float* x_prop, const float* noise, int64_t B,
+                      int n_particles, int n_dim, const double* dt_dev, uint64_t seed, uint64_t walker_offset,
+                      int64_t step, void* stream);
+int pita_mala_accept(float* x, float* logp, const float* force, const float* x_prop, const float* logp_prop,
+                     const float* force_prop, const float* uniforms, int64_t B, int n_particles, int n_dim,
+                     const double* dt_dev, uint64_t seed, uint64_t walker_offset, int64_t step, int remove_mean,
+                     int* acc_count, void* stream);
+int pita_mala_adapt(double* dt_dev, int* acc_count, int64_t total, int adaptive, float* rate_out, void* stream);
 
 /* ---------------------------------------------------------------- resampling (K10, K11)
  * K10 systematic resampling, replaces sample_cat_sys (utils.py:111-120): weights =

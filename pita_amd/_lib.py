@@ -50,6 +50,10 @@ _PROTOS = {
                                    c_float, c_float, c_float, c_void_p]),
     "pita_dw_logp_force": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_float, c_float,
                                    c_float, c_float, c_void_p]),
+    "pita_lj_descent": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int] + [c_float] * 6 + [c_int, c_float, c_float,
+                                c_float, c_uint64, c_uint64, c_int64, c_int, c_void_p]),
+    "pita_dw_descent": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int] + [c_float] * 5 + [c_int, c_float, c_float,
+                                c_float, c_uint64, c_uint64, c_int64, c_int, c_void_p]),
     "pita_gmm_logp_force": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_float,
                                     c_void_p]),
     "pita_ff_create": (c_int, [POINTER(c_void_p), POINTER(FfConfig)]),
@@ -76,6 +80,11 @@ _PROTOS = {
                                   c_void_p]),
     "pita_remove_mean": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p]),
     "pita_fill_normal": (c_int, [c_void_p, c_int64, c_int, c_int, c_uint64, c_uint64, c_int64, c_void_p]),
+    "pita_mala_propose": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_uint64,
+                                  c_uint64, c_int64, c_void_p]),
+    "pita_mala_accept": (c_int, [c_void_p] * 7 + [c_int64, c_int, c_int, c_void_p, c_uint64, c_uint64, c_int64, c_int,
+                                                  c_void_p, c_void_p]),
+    "pita_mala_adapt": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "pita_resample_workspace_bytes": (c_size_t, [c_int64]),
     "pita_systematic_resample": (c_int, [c_void_p, c_int64, c_double, c_void_p, c_void_p, c_void_p]),
     "pita_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),

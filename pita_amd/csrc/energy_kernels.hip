@@ -20,8 +20,62 @@ enum { E_LJ = 0, E_DW = 1 };
 
 struct PairParams {
   float inv_T, energy_factor, dist_eps, eps, rm2, osc_scale;  // LJ
+  float cw, co;  // LJ13 fast path: -inv_T * 24 ef eps / rm^2 (pair force weight), -inv_T * osc_scale
   float a, b, c, d0;                                          // DW
 };
+
+// logp-force of particle i of one walker whose coordinates xw[n*DIM] sit in LDS: f = d logp / d x_i,
+// e = this particle's share of the energy (ordered pairs for LJ, half of each unordered pair for DW).
+template <int DIM, int KIND>
+__device__ __forceinline__ void pair_force(const float* xw, int i, int n, const PairParams& p, float (&f)[DIM], float& e) {
+  float xi[DIM], mean[DIM];
+#pragma unroll
+  for (int k = 0; k < DIM; ++k) { f[k] = 0.f; mean[k] = 0.f; xi[k] = xw[i * DIM + k]; }
+  e = 0.f;
+  for (int j = 0; j < n; ++j) {
+    float d[DIM], r2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+      const float xj = xw[j * DIM + k];
+      mean[k] += xj;
+      d[k] = xi[k] - xj;
+      r2 = fmaf(d[k], d[k], r2);
+    }
+    if (j == i) continue;
+    if (KIND == E_LJ) {
+      r2 += p.dist_eps;
+      const float inv = __builtin_amdgcn_rcpf(r2);
+      const float s2 = p.rm2 * inv, s6 = s2 * s2 * s2;
+      const float t6 = fmaf(s6, s6, -2.0f * s6);  // s^12 - 2 s^6
+      e = fmaf(p.eps, t6, e);
+      const float coef = p.eps * (12.0f * fmaf(-s6, s6, s6)) * inv;  // e'(r)/r = eps*12*(s^6 - s^12)/r^2
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) f[k] = fmaf(coef, d[k], f[k]);
+    } else {
+      const float dist = sqrtf(r2);
+      const float u = dist - p.d0, u2 = u * u;
+      e += fmaf(p.a * u2, u2, fmaf(p.b, u2, p.c));
+      const float coef = (u * fmaf(4.0f * p.a, u2, 2.0f * p.b)) / dist;
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) f[k] = fmaf(coef, d[k], f[k]);
+    }
+  }
+  if (KIND == E_LJ) {
+    // E = ef * sum_{i != j} lj + 0.5*osc*sum |x - mean|^2 ; each unordered pair appears twice
+    float osc = 0.f;
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+      const float c = xi[k] - mean[k] / (float)n;
+      osc += c * c;
+      f[k] = -p.inv_T * (2.0f * p.energy_factor * f[k] + p.osc_scale * c);
+    }
+    e = p.energy_factor * e + 0.5f * p.osc_scale * osc;
+  } else {
+    e *= 0.5f;  // unordered pairs once
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) f[k] = -p.inv_T * f[k];
+  }
+}
 
 template <int DIM, int KIND>
 __global__ void __launch_bounds__(256) pair_energy_kernel(const float* __restrict__ x, float* __restrict__ logp,
@@ -41,56 +95,11 @@ __global__ void __launch_bounds__(256) pair_energy_kernel(const float* __restric
     __syncthreads();
     const int w = tid / n, i = tid - w * n;
     const bool act = w < nw;
-    float f[DIM], e = 0.f, xi[DIM], mean[DIM];
+    float f[DIM], e = 0.f;
 #pragma unroll
-    for (int k = 0; k < DIM; ++k) { f[k] = 0.f; mean[k] = 0.f; xi[k] = 0.f; }
+    for (int k = 0; k < DIM; ++k) f[k] = 0.f;
     if (act) {
-      const float* xw = xs + w * n * DIM;
-#pragma unroll
-      for (int k = 0; k < DIM; ++k) xi[k] = xw[i * DIM + k];
-      for (int j = 0; j < n; ++j) {
-        float d[DIM], r2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) {
-          const float xj = xw[j * DIM + k];
-          mean[k] += xj;
-          d[k] = xi[k] - xj;
-          r2 = fmaf(d[k], d[k], r2);
-        }
-        if (j == i) continue;
-        if (KIND == E_LJ) {
-          r2 += p.dist_eps;
-          const float inv = __builtin_amdgcn_rcpf(r2);
-          const float s2 = p.rm2 * inv, s6 = s2 * s2 * s2;
-          const float t6 = fmaf(s6, s6, -2.0f * s6);  // s^12 - 2 s^6
-          e = fmaf(p.eps, t6, e);
-          const float coef = p.eps * (12.0f * fmaf(-s6, s6, s6)) * inv;  // e'(r)/r = eps*12*(s^6 - s^12)/r^2
-#pragma unroll
-          for (int k = 0; k < DIM; ++k) f[k] = fmaf(coef, d[k], f[k]);
-        } else {
-          const float dist = sqrtf(r2);
-          const float u = dist - p.d0, u2 = u * u;
-          e += fmaf(p.a * u2, u2, fmaf(p.b, u2, p.c));
-          const float coef = (u * fmaf(4.0f * p.a, u2, 2.0f * p.b)) / dist;
-#pragma unroll
-          for (int k = 0; k < DIM; ++k) f[k] = fmaf(coef, d[k], f[k]);
-        }
-      }
-      if (KIND == E_LJ) {
-        // E = ef * sum_{i != j} lj + 0.5*osc*sum |x - mean|^2 ; each unordered pair appears twice
-        float osc = 0.f;
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) {
-          const float c = xi[k] - mean[k] / (float)n;
-          osc += c * c;
-          f[k] = -p.inv_T * (2.0f * p.energy_factor * f[k] + p.osc_scale * c);
-        }
-        e = p.energy_factor * e + 0.5f * p.osc_scale * osc;
-      } else {
-        e *= 0.5f;  // unordered pairs once
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) f[k] = -p.inv_T * f[k];
-      }
+      pair_force<DIM, KIND>(xs + w * n * DIM, i, n, p, f, e);
       es[w * n + i] = e;
     }
     __syncthreads();  // all reads of xs done; es complete
@@ -124,12 +133,10 @@ __global__ void __launch_bounds__(256) pair_energy_kernel(const float* __restric
 // k -> 2k mod 13, which maps {1,3,4} onto {2,6,8=-5}: exactly the other three circulant distances.
 // The partial force sets meet in LDS on the way to one fully coalesced float4 store.  At 65 536
 // walkers this doubles the waves per SIMD and halves the dependent VALU chain per wave.
-template <int P, int MULT>
-__device__ __forceinline__ void lj13_body(const float* __restrict__ xw, float* __restrict__ fw, float* __restrict__ e_out,
-                                          const PairParams& p, bool act, bool first) {
+template <int P, int MULT, bool OSC, bool WANT_E, bool UNIT_RM>
+__device__ __forceinline__ void lj13_partial(const float* __restrict__ xw, float (&fr)[39], float& e_out, const PairParams& p) {
   constexpr int N = 13, NDD = 6 / P;
   constexpr int DD[2][6] = {{1, 2, 3, 4, 5, 6}, {1, 3, 4, 0, 0, 0}};
-  float fr[39];
 #pragma unroll
   for (int q = 0; q < 39; ++q) fr[q] = 0.f;
   float e = 0.f;
@@ -147,39 +154,56 @@ __device__ __forceinline__ void lj13_body(const float* __restrict__ xw, float* _
       const int pj = ((MULT * j) % N) * 3;
       const float d0 = xi0 - xw[pj], d1 = xi1 - xw[pj + 1], d2 = xi2 - xw[pj + 2];
       const float r2 = fmaf(d2, d2, fmaf(d1, d1, fmaf(d0, d0, p.dist_eps)));
-      const float s2 = p.rm2 * __builtin_amdgcn_rcpf(r2);      // (rm/r)^2
+      const float inv = __builtin_amdgcn_rcpf(r2);
+      const float s2 = UNIT_RM ? inv : p.rm2 * inv;             // (rm/r)^2  (x * 1.0f is exact: same bits)
       const float s6 = s2 * s2 * s2;
-      e += fmaf(s6, s6, -2.0f * s6);                             // (rm/r)^12 - 2 (rm/r)^6, per pair (less cancellation)
+      if (WANT_E) e += fmaf(s6, s6, -2.0f * s6);                 // (rm/r)^12 - 2 (rm/r)^6, per pair (less cancellation)
       const float ts = s6 * s2;
       const float coef = fmaf(-s6, ts, ts);                      // (s^6 - s^12) s^2 = e'(r)/r * rm^2/(12 eps)
       fr[i * 3] = fmaf(coef, d0, fr[i * 3]); fr[i * 3 + 1] = fmaf(coef, d1, fr[i * 3 + 1]); fr[i * 3 + 2] = fmaf(coef, d2, fr[i * 3 + 2]);
       fr[j * 3] = fmaf(-coef, d0, fr[j * 3]); fr[j * 3 + 1] = fmaf(-coef, d1, fr[j * 3 + 1]); fr[j * 3 + 2] = fmaf(-coef, d2, fr[j * 3 + 2]);
     }
   }
-  // harmonic oscillator about the particle mean: counted once (by the first half)
-  float m0 = 0.f, m1 = 0.f, m2 = 0.f;
-#pragma unroll
-  for (int k = 0; k < N; ++k) { m0 += xw[k * 3]; m1 += xw[k * 3 + 1]; m2 += xw[k * 3 + 2]; }
-  m0 /= (float)N; m1 /= (float)N; m2 /= (float)N;
-  const float oscw = first ? p.osc_scale : 0.f;
   const float pair_w = 2.0f * p.energy_factor * p.eps;  // every unordered pair counts twice in the reference sum
-  const float force_w = pair_w * 12.0f / p.rm2;         // undo the scaling of `coef`
   float osc = 0.f;
+  if (OSC) {
+    // harmonic oscillator about the particle mean: counted once, by the half that does not apply the update in
+    // the fused descent kernel (this keeps the two halves' instruction counts level there)
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f;
 #pragma unroll
-  for (int k = 0; k < N; ++k) {
-    const int pk = ((MULT * k) % N) * 3;
-    const float c0 = xw[pk] - m0, c1 = xw[pk + 1] - m1, c2 = xw[pk + 2] - m2;
-    osc = fmaf(c0, c0, fmaf(c1, c1, fmaf(c2, c2, osc)));
-    fr[k * 3] = -p.inv_T * fmaf(force_w, fr[k * 3], oscw * c0);
-    fr[k * 3 + 1] = -p.inv_T * fmaf(force_w, fr[k * 3 + 1], oscw * c1);
-    fr[k * 3 + 2] = -p.inv_T * fmaf(force_w, fr[k * 3 + 2], oscw * c2);
+    for (int k = 0; k < N; ++k) { m0 += xw[k * 3]; m1 += xw[k * 3 + 1]; m2 += xw[k * 3 + 2]; }
+    m0 /= (float)N; m1 /= (float)N; m2 /= (float)N;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const int pk = ((MULT * k) % N) * 3;
+      const float c0 = xw[pk] - m0, c1 = xw[pk + 1] - m1, c2 = xw[pk + 2] - m2;
+      if (WANT_E) osc = fmaf(c0, c0, fmaf(c1, c1, fmaf(c2, c2, osc)));
+      fr[k * 3] = fmaf(p.cw, fr[k * 3], p.co * c0);  // d logp / dx = -(dE_pair/dx + osc (x - mean)) / T
+      fr[k * 3 + 1] = fmaf(p.cw, fr[k * 3 + 1], p.co * c1);
+      fr[k * 3 + 2] = fmaf(p.cw, fr[k * 3 + 2], p.co * c2);
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 39; ++q) fr[q] = p.cw * fr[q];
   }
-  // pin the results before the barrier: otherwise the compiler sinks ALL the arithmetic below it (its only
-  // users are the guarded stores) while the 39 coordinate loads must stay above -> everything spills
+  // pin the results: otherwise the compiler sinks ALL the arithmetic below the caller's barrier (its only
+  // users are guarded stores) while the 39 coordinate loads must stay above -> everything spills
 #pragma unroll
   for (int q = 0; q < 39; ++q) asm volatile("" : "+v"(fr[q]));
-  float e_pin = e;
-  asm volatile("" : "+v"(e_pin), "+v"(osc));
+  if (WANT_E) {
+    asm volatile("" : "+v"(e), "+v"(osc));
+    e_out = fmaf(pair_w, e, OSC ? 0.5f * p.osc_scale * osc : 0.f);
+  }
+}
+
+// fr is indexed by the RELABELLED particle k; the real particle is (MULT*k) mod 13
+template <int P, int MULT, bool UNIT_RM>
+__device__ __forceinline__ void lj13_body(const float* __restrict__ xw, float* __restrict__ fw, float* __restrict__ e_out,
+                                          const PairParams& p, bool act) {
+  constexpr int N = 13;
+  float fr[39], e;
+  lj13_partial<P, MULT, (P == 1 || MULT == 2), true, UNIT_RM>(xw, fr, e, p);
+  asm volatile("" : "+v"(e));
   __syncthreads();  // all coordinate reads of the block are done: the stage may be overwritten with forces
   if (act) {
 #pragma unroll
@@ -187,11 +211,11 @@ __device__ __forceinline__ void lj13_body(const float* __restrict__ xw, float* _
       const int pk = ((MULT * k) % N) * 3;
       fw[pk] = fr[k * 3]; fw[pk + 1] = fr[k * 3 + 1]; fw[pk + 2] = fr[k * 3 + 2];
     }
-    *e_out = fmaf(pair_w, e_pin, 0.5f * oscw * osc);
+    *e_out = e;
   }
 }
 
-template <int P>
+template <int P, bool UNIT_RM>
 __global__ void __launch_bounds__(256, 4) lj13_kernel(const float* __restrict__ x, float* __restrict__ logp,
                                                       float* __restrict__ force, long long B, PairParams p) {
   constexpr int D = 39, WPB = 256 / P;
@@ -213,8 +237,8 @@ __global__ void __launch_bounds__(256, 4) lj13_kernel(const float* __restrict__ 
     __syncthreads();
     const bool act = wl < nw;
     const int row = (act ? wl : 0) * D;
-    if (P == 1 || half == 0) lj13_body<P, 1>(&fb[0][row], &fb[0][row], &es[0][wl], p, act, true);
-    else lj13_body<P, 2>(&fb[0][row], &fb[P - 1][row], &es[P - 1][wl], p, act, false);
+    if (P == 1 || half == 0) lj13_body<P, 1, UNIT_RM>(&fb[0][row], &fb[0][row], &es[0][wl], p, act);
+    else lj13_body<P, 2, UNIT_RM>(&fb[0][row], &fb[P - 1][row], &es[P - 1][wl], p, act);
     __syncthreads();
     if (force) {
       float4* dst4 = reinterpret_cast<float4*>(force + w0 * D);
@@ -231,6 +255,201 @@ __global__ void __launch_bounds__(256, 4) lj13_kernel(const float* __restrict__ 
     if (tid < nw) logp[w0 + tid] = -p.inv_T * (es[0][tid] + (P == 2 ? es[P - 1][tid] : 0.f));
     __syncthreads();
   }
+}
+
+// ---------------------------------------------------------------------------- fused descent on the target
+// S steps of  x <- remove_mean(x + F(x) dt + noise_scale * sqrt_dt * xi)  in ONE launch
+// (sde_integration.py:353-360 negative_time_descent; ULA when noise_scale = 1).  The walkers of a block stay
+// in LDS for all S steps: HBM sees one read and one write of x per launch instead of per step, and the
+// per-step force array never exists.  Arithmetic and summation orders are those of pita_*_logp_force
+// followed by pita_em_step, so the fused and the per-step paths agree bit for bit.
+struct DescentParams {
+  float dt, noise_scale, sqrt_dt;
+  int nsteps, remove_mean;
+  unsigned long long seed, walker_offset;
+  long long step0;
+};
+
+template <int DIM, int KIND>
+__global__ void __launch_bounds__(256) pair_descent_kernel(float* __restrict__ x, const float* __restrict__ noise,
+                                                           long long B, int n, int WB, PairParams p, DescentParams q) {
+  extern __shared__ float sm[];  // [WB*n*DIM]
+  const int tid = threadIdx.x;
+  const long long nblk = (B + WB - 1) / WB;
+  for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const long long w0 = blk * WB;
+    const int nw = (int)((B - w0) < WB ? (B - w0) : WB);
+    const int nfl = nw * n * DIM;
+    float* gx = x + w0 * n * DIM;
+    for (int i = tid; i < nfl; i += 256) sm[i] = gx[i];
+    __syncthreads();
+    const int w = tid / n, i = tid - w * n;
+    const bool act = w < nw;
+    float* xw = sm + w * n * DIM;
+    for (int s = 0; s < q.nsteps; ++s) {
+      float f[DIM], e, v[DIM];
+      if (act) {
+        pair_force<DIM, KIND>(xw, i, n, p, f, e);
+        float xi[4] = {0.f, 0.f, 0.f, 0.f};
+        if (q.noise_scale != 0.f) {
+          if (noise) {
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) xi[k] = noise[(((long long)s * B + w0 + w) * n + i) * DIM + k];
+          } else {
+            philox_normal4(q.seed, q.walker_offset + (unsigned long long)(w0 + w), q.step0 + s, (uint32_t)i, xi);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) v[k] = xw[i * DIM + k] + (f[k] * q.dt + ((q.noise_scale * xi[k]) * q.sqrt_dt));
+      }
+      __syncthreads();  // every force of this step has read the old coordinates
+      if (act) {
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) xw[i * DIM + k] = v[k];
+      }
+      __syncthreads();
+      if (q.remove_mean) {
+        if (act) {
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) {
+            float sum = 0.f;
+            for (int j = 0; j < n; ++j) sum += xw[j * DIM + k];
+            v[k] -= sum / (float)n;
+          }
+        }
+        __syncthreads();
+        if (act) {
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) xw[i * DIM + k] = v[k];
+        }
+        __syncthreads();
+      }
+    }
+    for (int i2 = tid; i2 < nfl; i2 += 256) gx[i2] = sm[i2];
+    __syncthreads();
+  }
+}
+
+// LJ13: 128 walkers per 256-thread block, the two halves of lj13_kernel<2>.  Half 1 hands its partial
+// forces over through LDS; half 0 adds them to its own (still in registers), applies the update and the
+// centring for all 13 particles of its walker and writes the new coordinates back to the LDS stage.
+template <bool UNIT_RM>
+__global__ void __launch_bounds__(256, 2) lj13_descent_kernel(float* __restrict__ x, const float* __restrict__ noise,
+                                                              long long B, PairParams p, DescentParams q) {
+  constexpr int D = 39, WPB = 128, N = 13;
+  __shared__ __attribute__((aligned(16))) float xs[WPB * D];
+  __shared__ __attribute__((aligned(16))) float fb[WPB * D];
+  __shared__ float nzb[WPB * D];  // (noise_scale * xi) * sqrt_dt of the current step
+  const int tid = threadIdx.x;
+  const int half = tid / WPB, wl = tid - half * WPB;
+  const bool langevin = q.noise_scale != 0.f;
+  const long long nblk = (B + WPB - 1) / WPB;
+  for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const long long w0 = blk * WPB;
+    const int nw = (int)((B - w0) < WPB ? (B - w0) : WPB);
+    const int nfl = nw * D;
+    {
+      const float4* src4 = reinterpret_cast<const float4*>(x + w0 * D);
+      float4* dst4 = reinterpret_cast<float4*>(xs);
+      for (int i = tid; i < nfl / 4; i += 256) dst4[i] = src4[i];
+      for (int i = (nfl & ~3) + tid; i < nfl; i += 256) xs[i] = x[w0 * D + i];
+    }
+    __syncthreads();
+    const bool act = wl < nw;
+    const int row = (act ? wl : 0) * D;
+    for (int s = 0; s < q.nsteps; ++s) {
+      if (langevin) {  // both halves draw the step's noise (6 / 7 particles each) into LDS
+#pragma unroll 1
+        for (int k = half ? 6 : 0; k < (half ? N : 6); ++k) {
+          float xi[4] = {0.f, 0.f, 0.f, 0.f};
+          if (noise) {
+            const float* nz = noise + (((long long)s * B + w0 + (act ? wl : 0)) * D + k * 3);
+            xi[0] = nz[0]; xi[1] = nz[1]; xi[2] = nz[2];
+          } else {
+            philox_normal4(q.seed, q.walker_offset + (unsigned long long)(w0 + wl), q.step0 + s, (uint32_t)k, xi);
+          }
+          if (act) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) nzb[row + k * 3 + c] = (q.noise_scale * xi[c]) * q.sqrt_dt;
+          }
+        }
+      }
+      float fr[39], e;
+      if (half == 0) {
+        lj13_partial<2, 1, false, false, UNIT_RM>(xs + row, fr, e, p);
+      } else {
+        lj13_partial<2, 2, true, false, UNIT_RM>(xs + row, fr, e, p);
+        if (act) {
+#pragma unroll
+          for (int k = 0; k < N; ++k) {
+            const int pk = ((2 * k) % N) * 3;
+            fb[row + pk] = fr[k * 3]; fb[row + pk + 1] = fr[k * 3 + 1]; fb[row + pk + 2] = fr[k * 3 + 2];
+          }
+        }
+      }
+      __syncthreads();  // partial forces of half 1 are in LDS; nobody reads the old coordinates any more
+      if (half == 0) {
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+        if (langevin) {
+#pragma unroll
+          for (int k = 0; k < 39; ++k)
+            fr[k] = xs[row + k] + ((fr[k] + fb[row + k]) * q.dt + nzb[row + k]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 39; ++k) fr[k] = xs[row + k] + (fr[k] + fb[row + k]) * q.dt;
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) { m0 += fr[k * 3]; m1 += fr[k * 3 + 1]; m2 += fr[k * 3 + 2]; }
+        if (q.remove_mean) {
+          m0 /= (float)N; m1 /= (float)N; m2 /= (float)N;
+#pragma unroll
+          for (int k = 0; k < N; ++k) { fr[k * 3] -= m0; fr[k * 3 + 1] -= m1; fr[k * 3 + 2] -= m2; }
+        }
+        if (act) {
+#pragma unroll
+          for (int k = 0; k < 39; ++k) xs[row + k] = fr[k];
+        }
+      }
+      __syncthreads();
+    }
+    {
+      float4* dst4 = reinterpret_cast<float4*>(x + w0 * D);
+      const float4* src4 = reinterpret_cast<const float4*>(xs);
+      for (int i = tid; i < nfl / 4; i += 256) dst4[i] = src4[i];
+      for (int i = (nfl & ~3) + tid; i < nfl; i += 256) x[w0 * D + i] = xs[i];
+    }
+    __syncthreads();
+  }
+}
+
+template <int KIND>
+static int launch_descent(float* x, const float* noise, int64_t B, int n, int d, const PairParams& p, const DescentParams& q,
+                          void* stream) {
+  PITA_REQUIRE(B >= 0 && q.nsteps >= 0, "descent: negative batch or step count");
+  if (B == 0 || q.nsteps == 0) return PITA_OK;
+  PITA_REQUIRE(x, "descent: null argument");
+  PITA_REQUIRE(n >= 2 && n <= 256, "descent: n_particles must be in [2,256]");
+  PITA_REQUIRE(d >= 1 && d <= 3, "descent: n_dim must be 1, 2 or 3");
+  hipStream_t s = (hipStream_t)stream;
+  if (KIND == E_LJ && n == 13 && d == 3) {
+    const long long nblk = (B + 127) / 128;
+    const unsigned grid = (unsigned)(nblk < 256LL * 4 ? nblk : 256LL * 4);
+    if (p.rm2 == 1.0f) hipLaunchKernelGGL(lj13_descent_kernel<true>, dim3(grid), dim3(256), 0, s, x, noise, (long long)B, p, q);
+    else hipLaunchKernelGGL(lj13_descent_kernel<false>, dim3(grid), dim3(256), 0, s, x, noise, (long long)B, p, q);
+    PITA_LAUNCH_CHECK();
+    return PITA_OK;
+  }
+  const int WB = 256 / n;
+  const long long nblk = (B + WB - 1) / WB;
+  const unsigned grid = (unsigned)(nblk < 256LL * 16 ? nblk : 256LL * 16);
+  const size_t lds = sizeof(float) * (size_t)(WB * n * d);
+  switch (d) {
+    case 1: hipLaunchKernelGGL((pair_descent_kernel<1, KIND>), dim3(grid), dim3(256), lds, s, x, noise, B, n, WB, p, q); break;
+    case 2: hipLaunchKernelGGL((pair_descent_kernel<2, KIND>), dim3(grid), dim3(256), lds, s, x, noise, B, n, WB, p, q); break;
+    default: hipLaunchKernelGGL((pair_descent_kernel<3, KIND>), dim3(grid), dim3(256), lds, s, x, noise, B, n, WB, p, q); break;
+  }
+  PITA_LAUNCH_CHECK();
+  return PITA_OK;
 }
 
 template <int KIND>
@@ -317,6 +536,7 @@ extern "C" int pita_lj_logp_force(const float* x, float* logp, float* force, int
   PairParams p{};
   p.inv_T = 1.0f / temperature; p.energy_factor = energy_factor; p.dist_eps = dist_eps; p.eps = eps;
   p.rm2 = rm * rm; p.osc_scale = osc_scale;
+  p.cw = -p.inv_T * (2.0f * energy_factor * eps * 12.0f / p.rm2); p.co = -p.inv_T * osc_scale;
   if (n == 13 && d == 3 && B > 0) {
     PITA_REQUIRE(x && logp, "pita_lj_logp_force: null argument");
     // 2 lanes per walker while the batch cannot fill every SIMD twice with 1 lane per walker
@@ -324,8 +544,12 @@ extern "C" int pita_lj_logp_force(const float* x, float* logp, float* force, int
     const int WPB = two ? 128 : 256;
     const long long nblk = (B + WPB - 1) / WPB;
     const unsigned grid = (unsigned)(nblk < 256LL * 32 ? nblk : 256LL * 32);
-    if (two) hipLaunchKernelGGL(lj13_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, logp, force, (long long)B, p);
-    else hipLaunchKernelGGL(lj13_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, logp, force, (long long)B, p);
+    const bool unit = p.rm2 == 1.0f;
+    hipStream_t s = (hipStream_t)stream;
+    if (two && unit) hipLaunchKernelGGL((lj13_kernel<2, true>), dim3(grid), dim3(256), 0, s, x, logp, force, (long long)B, p);
+    else if (two) hipLaunchKernelGGL((lj13_kernel<2, false>), dim3(grid), dim3(256), 0, s, x, logp, force, (long long)B, p);
+    else if (unit) hipLaunchKernelGGL((lj13_kernel<1, true>), dim3(grid), dim3(256), 0, s, x, logp, force, (long long)B, p);
+    else hipLaunchKernelGGL((lj13_kernel<1, false>), dim3(grid), dim3(256), 0, s, x, logp, force, (long long)B, p);
     PITA_LAUNCH_CHECK();
     return PITA_OK;
   }
@@ -362,4 +586,35 @@ extern "C" int pita_gmm_logp_force(const float* x, float* logp, float* force, in
   }
   PITA_LAUNCH_CHECK();
   return PITA_OK;
+}
+
+static DescentParams descent_params(int nsteps, float dt, float noise_scale, float sqrt_dt, uint64_t seed,
+                                    uint64_t walker_offset, int64_t step0, int remove_mean) {
+  DescentParams q{};
+  q.dt = dt; q.noise_scale = noise_scale; q.sqrt_dt = sqrt_dt; q.nsteps = nsteps; q.remove_mean = remove_mean;
+  q.seed = seed; q.walker_offset = walker_offset; q.step0 = step0;
+  return q;
+}
+
+extern "C" int pita_lj_descent(float* x, const float* noise, int64_t B, int n, int d, float temperature, float energy_factor,
+                               float dist_eps, float eps, float rm, float osc_scale, int nsteps, float dt,
+                               float noise_scale, float sqrt_dt, uint64_t seed, uint64_t walker_offset, int64_t step0,
+                               int remove_mean, void* stream) {
+  PITA_REQUIRE(temperature > 0.f, "pita_lj_descent: temperature must be > 0");
+  PairParams p{};
+  p.inv_T = 1.0f / temperature; p.energy_factor = energy_factor; p.dist_eps = dist_eps; p.eps = eps;
+  p.rm2 = rm * rm; p.osc_scale = osc_scale;
+  p.cw = -p.inv_T * (2.0f * energy_factor * eps * 12.0f / p.rm2); p.co = -p.inv_T * osc_scale;
+  return launch_descent<E_LJ>(x, noise, B, n, d, p,
+                              descent_params(nsteps, dt, noise_scale, sqrt_dt, seed, walker_offset, step0, remove_mean), stream);
+}
+
+extern "C" int pita_dw_descent(float* x, const float* noise, int64_t B, int n, int d, float temperature, float a, float b,
+                               float c, float d0, int nsteps, float dt, float noise_scale, float sqrt_dt, uint64_t seed,
+                               uint64_t walker_offset, int64_t step0, int remove_mean, void* stream) {
+  PITA_REQUIRE(temperature > 0.f, "pita_dw_descent: temperature must be > 0");
+  PairParams p{};
+  p.inv_T = 1.0f / temperature; p.a = a; p.b = b; p.c = c; p.d0 = d0;
+  return launch_descent<E_DW>(x, noise, B, n, d, p,
+                              descent_params(nsteps, dt, noise_scale, sqrt_dt, seed, walker_offset, step0, remove_mean), stream);
 }

@@ -7,6 +7,8 @@
 //   energies/base_prior.py:77-83                   MeanFreePrior.sample
 //   models/components/utils.py:111-120             sample_cat_sys (systematic resampling)
 //   models/components/sde_integration.py:293       x = x[choice]
+//   models/components/sde_integration.py:28-45     mala_proposal
+//   models/components/sde_integration.py:379-398, 430-461   MALA accept/reject, step-size adaptation
 #include "common.h"
 
 namespace pita {
@@ -93,6 +95,120 @@ static int launch_elem(float* x, const float* drift, const float* noise, int64_t
   }
   PITA_LAUNCH_CHECK();
   return PITA_OK;
+}
+
+// ---------------------------------------------------------------------------- MALA
+// The step size lives on the device (double, like the Python float it replaces) so the adaptive chain
+// runs without a host round trip per step; the kernels round it to fp32 where torch would.
+template <int DIM>
+__global__ void __launch_bounds__(256) mala_propose_kernel(const float* __restrict__ x, const float* __restrict__ force,
+                                                           float* __restrict__ x_prop, const float* __restrict__ noise,
+                                                           long long B, int n, const double* __restrict__ dt_dev,
+                                                           ElemParams p) {
+  const float hdt = (float)(0.5 * dt_dev[0]), sdt = (float)sqrt(dt_dev[0]);
+  const long long total = B * n;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const long long w = t / n;
+    const int i = (int)(t - w * n);
+    const long long base = t * DIM;
+    float xi[4] = {0.f, 0.f, 0.f, 0.f};
+    if (noise) {
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) xi[k] = noise[base + k];
+    } else {
+      philox_normal4(p.seed, p.walker_offset + (unsigned long long)w, p.step, (uint32_t)i, xi);
+    }
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) x_prop[base + k] = (x[base + k] + hdt * force[base + k]) + sdt * xi[k];
+  }
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(256) mala_accept_kernel(float* __restrict__ x, float* __restrict__ logp,
+                                                          const float* __restrict__ force, const float* __restrict__ x_prop,
+                                                          const float* __restrict__ logp_prop,
+                                                          const float* __restrict__ force_prop,
+                                                          const float* __restrict__ uniforms, long long B, int n, int WB,
+                                                          const double* __restrict__ dt_dev, int* __restrict__ acc_count,
+                                                          ElemParams p) {
+  extern __shared__ float sm[];
+  float* xsel = sm;                      // [WB*n*DIM] accepted/kept coordinates
+  float* qf = sm + WB * n * DIM;         // [WB*n] partial |x' - fwd_mean|^2
+  float* qb = qf + WB * n;               // [WB*n] partial |x - bwd_mean|^2
+  float* flag = qb + WB * n;             // [WB]   1.0 = accepted
+  const float hdt = (float)(0.5 * dt_dev[0]), tdt = (float)(2.0 * dt_dev[0]);
+  const int tid = threadIdx.x;
+  const long long nblk = (B + WB - 1) / WB;
+  for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const long long w0 = blk * WB;
+    const int nw = (int)((B - w0) < WB ? (B - w0) : WB);
+    const int w = tid / n, i = tid - w * n;
+    const bool act = w < nw;
+    const long long base = ((w0 + w) * n + i) * DIM;
+    float xo[DIM], xp[DIM];
+    if (act) {
+      float sf = 0.f, sb = 0.f;
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) {
+        xo[k] = x[base + k];
+        xp[k] = x_prop[base + k];
+        const float df = xp[k] - (xo[k] + hdt * force[base + k]);
+        const float db = xo[k] - (xp[k] + hdt * force_prop[base + k]);
+        sf += df * df;
+        sb += db * db;
+      }
+      qf[w * n + i] = sf;
+      qb[w * n + i] = sb;
+    }
+    __syncthreads();
+    if (act && i == 0) {
+      float sf = 0.f, sb = 0.f;
+      for (int j = 0; j < n; ++j) { sf += qf[w * n + j]; sb += qb[w * n + j]; }
+      const float lqf = -sf / tdt, lqb = -sb / tdt;
+      const float lp = logp[w0 + w], lpp = logp_prop[w0 + w];
+      const float ratio = (lpp - lp) + (lqb - lqf);
+      const float u = uniforms ? uniforms[w0 + w]
+                               : philox_uniform(p.seed, p.walker_offset + (unsigned long long)(w0 + w), p.step, 0xFFFFFu);
+      const float af = (logf(u) < ratio) ? 1.0f : 0.0f;
+      logp[w0 + w] = af * lpp + (1.0f - af) * lp;
+      flag[w] = af;
+    }
+    __syncthreads();
+    float v[DIM];
+    if (act) {
+      const float af = flag[w];
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) {
+        v[k] = af * xp[k] + (1.0f - af) * xo[k];
+        xsel[(w * n + i) * DIM + k] = v[k];
+      }
+    }
+    if (tid == 0) {
+      int c = 0;
+      for (int j = 0; j < nw; ++j) c += flag[j] != 0.f;
+      if (c) atomicAdd(acc_count, c);
+    }
+    __syncthreads();
+    if (act) {
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) {
+        if (p.remove_mean) {
+          float s = 0.f;
+          for (int j = 0; j < n; ++j) s += xsel[(w * n + j) * DIM + k];
+          v[k] -= s / (float)n;
+        }
+        x[base + k] = v[k];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void mala_adapt_kernel(double* dt_dev, int* acc_count, long long total, int adaptive, float* rate_out) {
+  const float rate = (float)acc_count[0] / (float)total;
+  if (rate_out) rate_out[0] = rate;
+  if (adaptive) dt_dev[0] = ((double)rate > 0.55) ? dt_dev[0] * 1.1 : dt_dev[0] / 1.1;  // sde_integration.py:439-443
+  acc_count[0] = 0;
 }
 
 // ---------------------------------------------------------------------------- resampling
@@ -228,6 +344,60 @@ extern "C" int pita_gather_rows(const float* src, const int64_t* ids, float* out
   const long long nb = (B * D + 255) / 256;
   hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, (hipStream_t)stream, src,
                      (const long long*)ids, out, (long long)B, D);
+  PITA_LAUNCH_CHECK();
+  return PITA_OK;
+}
+
+extern "C" int pita_mala_propose(const float* x, const float* force, float* x_prop, const float* noise, int64_t B, int n,
+                                 int d, const double* dt_dev, uint64_t seed, uint64_t walker_offset, int64_t step,
+                                 void* stream) {
+  PITA_REQUIRE(B >= 0, "pita_mala_propose: negative batch");
+  if (B == 0) return PITA_OK;
+  PITA_REQUIRE(x && force && x_prop && dt_dev, "pita_mala_propose: null argument");
+  PITA_REQUIRE(n >= 1 && n <= 256 && d >= 1 && d <= 3, "pita_mala_propose: n_particles in [1,256], n_dim in [1,3]");
+  ElemParams p{};
+  p.seed = seed; p.walker_offset = walker_offset; p.step = step;
+  const long long nb = (B * n + 255) / 256;
+  const unsigned grid = (unsigned)(nb < 8192 ? nb : 8192);
+  hipStream_t s = (hipStream_t)stream;
+  switch (d) {
+    case 1: hipLaunchKernelGGL(mala_propose_kernel<1>, dim3(grid), dim3(256), 0, s, x, force, x_prop, noise, B, n, dt_dev, p); break;
+    case 2: hipLaunchKernelGGL(mala_propose_kernel<2>, dim3(grid), dim3(256), 0, s, x, force, x_prop, noise, B, n, dt_dev, p); break;
+    default: hipLaunchKernelGGL(mala_propose_kernel<3>, dim3(grid), dim3(256), 0, s, x, force, x_prop, noise, B, n, dt_dev, p); break;
+  }
+  PITA_LAUNCH_CHECK();
+  return PITA_OK;
+}
+
+extern "C" int pita_mala_accept(float* x, float* logp, const float* force, const float* x_prop, const float* logp_prop,
+                                const float* force_prop, const float* uniforms, int64_t B, int n, int d,
+                                const double* dt_dev, uint64_t seed, uint64_t walker_offset, int64_t step, int remove_mean,
+                                int* acc_count, void* stream) {
+  PITA_REQUIRE(B >= 0, "pita_mala_accept: negative batch");
+  if (B == 0) return PITA_OK;
+  PITA_REQUIRE(x && logp && force && x_prop && logp_prop && force_prop && dt_dev && acc_count,
+               "pita_mala_accept: null argument");
+  PITA_REQUIRE(n >= 1 && n <= 256 && d >= 1 && d <= 3, "pita_mala_accept: n_particles in [1,256], n_dim in [1,3]");
+  ElemParams p{};
+  p.seed = seed; p.walker_offset = walker_offset; p.step = step; p.remove_mean = remove_mean;
+  const int WB = 256 / n;
+  const long long nblk = (B + WB - 1) / WB;
+  const unsigned grid = (unsigned)(nblk < 256LL * 16 ? nblk : 256LL * 16);
+  const size_t lds = sizeof(float) * (size_t)(WB * n * d + 2 * WB * n + WB);
+  hipStream_t s = (hipStream_t)stream;
+  switch (d) {
+    case 1: hipLaunchKernelGGL(mala_accept_kernel<1>, dim3(grid), dim3(256), lds, s, x, logp, force, x_prop, logp_prop, force_prop, uniforms, B, n, WB, dt_dev, acc_count, p); break;
+    case 2: hipLaunchKernelGGL(mala_accept_kernel<2>, dim3(grid), dim3(256), lds, s, x, logp, force, x_prop, logp_prop, force_prop, uniforms, B, n, WB, dt_dev, acc_count, p); break;
+    default: hipLaunchKernelGGL(mala_accept_kernel<3>, dim3(grid), dim3(256), lds, s, x, logp, force, x_prop, logp_prop, force_prop, uniforms, B, n, WB, dt_dev, acc_count, p); break;
+  }
+  PITA_LAUNCH_CHECK();
+  return PITA_OK;
+}
+
+extern "C" int pita_mala_adapt(double* dt_dev, int* acc_count, int64_t total, int adaptive, float* rate_out, void* stream) {
+  PITA_REQUIRE(dt_dev && acc_count && total > 0, "pita_mala_adapt: bad argument");
+  hipLaunchKernelGGL(mala_adapt_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dt_dev, acc_count, (long long)total,
+                     adaptive, rate_out);
   PITA_LAUNCH_CHECK();
   return PITA_OK;
 }

@@ -36,3 +36,14 @@ class MultiDoubleWellEnergy(BaseMoleculeEnergy):
             float(self.temperature), self.a, self.b, self.c, self.offset, _lib.stream_ptr(x.device)),
             "pita_dw_logp_force")
         return (logp, force) if return_force else logp
+
+    def fused_descent(self, x, num_steps, dt, noise_scale, sqrt_dt, seed=0, walker_offset=0, step0=0, remove_mean=True,
+                      noise=None):
+        """See LennardJonesEnergy.fused_descent."""
+        if self.should_normalize:
+            return None
+        _lib.check(_lib.lib().pita_dw_descent(
+            x.data_ptr(), _lib.ptr(noise), x.shape[0], self.n_particles, self.n_spatial_dim, float(self.temperature),
+            self.a, self.b, self.c, self.offset, int(num_steps), float(dt), float(noise_scale), float(sqrt_dt), seed,
+            walker_offset, step0, int(remove_mean), _lib.stream_ptr(x.device)), "pita_dw_descent")
+        return x

@@ -45,3 +45,15 @@ class LennardJonesEnergy(BaseMoleculeEnergy):
             float(self.temperature), self.energy_factor, self.dist_eps, 1.0, 1.0, 1.0, _lib.stream_ptr(x.device)),
             "pita_lj_logp_force")
         return (logp, force) if return_force else logp
+
+    def fused_descent(self, x, num_steps, dt, noise_scale, sqrt_dt, seed=0, walker_offset=0, step0=0, remove_mean=True,
+                      noise=None):
+        """``num_steps`` of x <- remove_mean(x + F dt + noise_scale*sqrt_dt*xi) in ONE launch, in place
+        (negative_time_descent, sde_integration.py:353-360); None when the fused kernel does not apply."""
+        if self.should_normalize:
+            return None
+        _lib.check(_lib.lib().pita_lj_descent(
+            x.data_ptr(), _lib.ptr(noise), x.shape[0], self.n_particles, self.n_spatial_dim, float(self.temperature),
+            self.energy_factor, self.dist_eps, 1.0, 1.0, 1.0, int(num_steps), float(dt), float(noise_scale),
+            float(sqrt_dt), seed, walker_offset, step0, int(remove_mean), _lib.stream_ptr(x.device)), "pita_lj_descent")
+        return x

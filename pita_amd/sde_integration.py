@@ -232,7 +232,8 @@ class WeightedSDEIntegrator:
         if self.post_mcmc_steps > 0:
             fn = self.metropolis_hastings_mala_adaptive if self.adaptive_mcmc else self.metropolis_hastings_mala
             kw = dict(dt_init=self.dt_negative_time) if self.adaptive_mcmc else {}
-            x, acceptance_rate_list = fn(x, energy_function, return_acceptance_rate=True, **kw)
+            x, acceptance_rate_list = fn(x, energy_function, return_acceptance_rate=True, walker_offset=off, comm=comm,
+                                         **kw)
         x = comm.all_gather(x)  # X1: the only collective on the resampling-free path
         return x, logweights, num_unique_idxs, sde_terms_all, acceptance_rate_list
 
@@ -304,7 +305,8 @@ class WeightedSDEIntegrator:
         if self.post_mcmc_steps > 0:
             fn = self.metropolis_hastings_mala_adaptive if self.adaptive_mcmc else self.metropolis_hastings_mala
             kw = dict(dt_init=self.dt_negative_time) if self.adaptive_mcmc else {}
-            x, acceptance_rate_list = fn(x, energy_function, return_acceptance_rate=True, **kw)
+            x, acceptance_rate_list = fn(x, energy_function, return_acceptance_rate=True, walker_offset=off, comm=comm,
+                                         **kw)
         return comm.all_gather(x), logweights, num_unique_idxs, sde_terms_all, acceptance_rate_list
 
     # ------------------------------------------------------------------ A2-A4 steps [s0, s1)
@@ -333,60 +335,90 @@ class WeightedSDEIntegrator:
                 sde_terms_all.append(SDETerms(drift_X=drift, drift_A=torch.zeros(x.shape[0], device=x.device)))
 
     # ------------------------------------------------------------------ A16 post-processing
-    def negative_time_descent(self, x, energy_function, noise=None, walker_offset=0):
-        """x += F*dt (+ sqrt(2 dt) xi), remove_mean, repeated (sde_integration.py:353-360)."""
+    def negative_time_descent(self, x, energy_function, noise=None, walker_offset=0, fused=True):
+        """x += F*dt (+ sqrt(2 dt) xi), remove_mean, repeated (sde_integration.py:353-360).  Pair targets run all
+        steps in one launch (pita_lj_descent / pita_dw_descent, bit-identical to the per-step path below)."""
         n, d = self._geometry(x, energy_function)
         dt = float(self.dt_negative_time)
         key = self._key(1)
         L = _lib.lib()
-        x = x.clone()
-        for k in range(self.num_negative_time_steps):
+        x = _lib.dev_tensor(x, "x").clone()
+        ns, sq = (1.0 if self.do_langevin else 0.0), math.sqrt(2 * dt)
+        nsteps = int(self.num_negative_time_steps)
+        if noise is not None:
+            noise = _lib.dev_tensor(noise, "noise")
+        if fused and hasattr(energy_function, "fused_descent") and energy_function.fused_descent(
+                x, nsteps, dt, ns, sq, seed=key, walker_offset=walker_offset, step0=0,
+                remove_mean=self.should_mean_free, noise=noise) is not None:
+            return x
+        for k in range(nsteps):
             _, F = energy_function(x, return_force=True)
             nz = noise[k].contiguous() if noise is not None else None
-            _lib.check(L.pita_em_step(x.data_ptr(), F.data_ptr(), _lib.ptr(nz), x.shape[0], n, d, dt,
-                                      1.0 if self.do_langevin else 0.0, math.sqrt(2 * dt), key, walker_offset, k,
-                                      int(self.should_mean_free), _lib.stream_ptr(x.device)), "pita_em_step")
+            _lib.check(L.pita_em_step(x.data_ptr(), F.data_ptr(), _lib.ptr(nz), x.shape[0], n, d, dt, ns, sq, key,
+                                      walker_offset, k, int(self.should_mean_free), _lib.stream_ptr(x.device)),
+                       "pita_em_step")
         return x
 
-    def _mala(self, x, energy_function, adaptive, dt, noise=None, uniforms=None, return_acceptance_rate=False):
-        """MALA with the reference's finite-mask semantics (:362-470): non-finite-logp walkers are set
-        aside and re-appended AFTER the valid ones (order not preserved, quirk Q7)."""
+    def _mala(self, x, energy_function, adaptive, dt, noise=None, uniforms=None, return_acceptance_rate=False,
+              walker_offset=0, comm=None):
+        """MALA with the reference's finite-mask semantics (:362-470): non-finite-logp walkers are set aside and
+        re-appended AFTER the valid ones (order not preserved, quirk Q7).  Proposal, accept/reject and the step-size
+        adaptation run as HIP kernels with the step size on the device: no host synchronisation inside the chain.
+        With several ranks the acceptance count is all-reduced so the adaptation sees the global rate, as the
+        reference (which runs the chain on the gathered batch on every rank) does."""
         n, d = self._geometry(x, energy_function)
+        L = _lib.lib()
+        x = _lib.dev_tensor(x, "x")
+        dev = x.device
         logp_all = energy_function(x)
         valid = torch.isfinite(logp_all)
         x_valid, x_invalid = x[valid].contiguous(), x[~valid]
-        logp = logp_all[valid]
-        rates = []
-        for i in range(self.post_mcmc_steps):
-            if x_valid.shape[0] == 0:
-                break
-            _, grad = energy_function(x_valid, return_force=True)
-            xi = noise[i] if noise is not None else torch.randn_like(x_valid)
-            fwd_mean = x_valid + 0.5 * dt * grad
-            x_prop = fwd_mean + math.sqrt(dt) * xi  # mala_proposal :28-45
-            log_q_f = -((x_prop - fwd_mean) ** 2).sum(dim=1) / (2 * dt)
-            logp_prop, grad_prop = energy_function(x_prop, return_force=True)
-            bwd_mean = x_prop + 0.5 * dt * grad_prop
-            log_q_b = -((x_valid - bwd_mean) ** 2).sum(dim=1) / (2 * dt)
-            ratio = (logp_prop - logp) + (log_q_b - log_q_f)
-            uu = uniforms[i] if uniforms is not None else torch.rand_like(ratio)
-            acc = torch.log(uu) < ratio
-            rate = acc.float().mean().item()
-            if adaptive:  # :439-443
-                dt = dt * 1.1 if rate > 0.55 else dt / 1.1
-            rates.append(rate)
-            af = acc.float()
-            x_valid = af[:, None] * x_prop + (1 - af[:, None]) * x_valid
-            logp = af * logp_prop + (1 - af) * logp
-            if getattr(energy_function, "is_molecule", False):
-                x_valid = remove_mean(x_valid, n, d)
+        logp = logp_all[valid].contiguous()
+        Bv = x_valid.shape[0]
+        total = Bv
+        world = comm.world if comm is not None and torch.distributed.is_initialized() else 1
+        if world > 1:
+            tot = torch.tensor([Bv], device=dev, dtype=torch.int64)
+            torch.distributed.all_reduce(tot)
+            total = int(tot.item())
+        steps = int(self.post_mcmc_steps)
+        rates = torch.zeros(max(steps, 1), device=dev)
+        done = 0
+        if total > 0 and steps > 0:
+            dt_dev = torch.tensor([dt], device=dev, dtype=torch.float64)
+            count = torch.zeros(1, device=dev, dtype=torch.int32)
+            x_prop = torch.empty_like(x_valid)
+            key = self._key(2)
+            # :397-398 centres through maybe_remove_mean, the adaptive variant (:458-461) unconditionally
+            rm = int(bool(getattr(energy_function, "is_molecule", False)) and (adaptive or bool(self.should_mean_free)))
+            st = _lib.stream_ptr(dev)
+            for i in range(steps):
+                if Bv > 0:
+                    _, grad = energy_function(x_valid, return_force=True)
+                    nz = _lib.dev_tensor(noise[i], "noise") if noise is not None else None
+                    _lib.check(L.pita_mala_propose(x_valid.data_ptr(), grad.data_ptr(), x_prop.data_ptr(), _lib.ptr(nz),
+                                                   Bv, n, d, dt_dev.data_ptr(), key, walker_offset, i, st),
+                               "pita_mala_propose")
+                    logp_prop, grad_prop = energy_function(x_prop, return_force=True)
+                    uu = _lib.dev_tensor(uniforms[i], "uniforms") if uniforms is not None else None
+                    _lib.check(L.pita_mala_accept(x_valid.data_ptr(), logp.data_ptr(), grad.data_ptr(), x_prop.data_ptr(),
+                                                  logp_prop.data_ptr(), grad_prop.data_ptr(), _lib.ptr(uu), Bv, n, d,
+                                                  dt_dev.data_ptr(), key, walker_offset, i, rm, count.data_ptr(), st),
+                               "pita_mala_accept")
+                if world > 1:
+                    torch.distributed.all_reduce(count)
+                _lib.check(L.pita_mala_adapt(dt_dev.data_ptr(), count.data_ptr(), total, int(adaptive),
+                                             rates[i:].data_ptr(), st), "pita_mala_adapt")
+                done += 1
         out = torch.cat([x_valid, x_invalid], dim=0)
-        return (out, rates) if return_acceptance_rate else (out, None)
+        return (out, rates[:done].tolist()) if return_acceptance_rate else (out, None)
 
-    def metropolis_hastings_mala(self, x, energy_function, return_acceptance_rate=False, noise=None, uniforms=None):
+    def metropolis_hastings_mala(self, x, energy_function, return_acceptance_rate=False, noise=None, uniforms=None,
+                                 walker_offset=0, comm=None):
         return self._mala(x, energy_function, False, float(self.dt_negative_time), noise, uniforms,
-                          return_acceptance_rate)
+                          return_acceptance_rate, walker_offset, comm)
 
     def metropolis_hastings_mala_adaptive(self, x, energy_function, dt_init, return_acceptance_rate=False, noise=None,
-                                          uniforms=None):
-        return self._mala(x, energy_function, True, float(dt_init), noise, uniforms, return_acceptance_rate)
+                                          uniforms=None, walker_offset=0, comm=None):
+        return self._mala(x, energy_function, True, float(dt_init), noise, uniforms, return_acceptance_rate,
+                          walker_offset, comm)

@@ -283,6 +283,31 @@ def test_philox_normals(pa):
     assert abs(torch.corrcoef(v[:, :4].T)[0, 1].item()) < 1e-2
 
 
+def _philox_normals_host(seed, walkers, step, particles):
+    """Philox4x32-10 + Box-Muller as documented in include/pita_hip.h, in numpy (uint64 / float64)."""
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    w, pt = np.meshgrid(np.asarray(walkers, dtype=np.uint64), np.asarray(particles, dtype=np.uint64), indexing="ij")
+    mask = np.uint64(0xFFFFFFFF)
+    c = [w & mask, w >> np.uint64(32), np.full_like(w, step & 0xFFFFFFFF), pt ^ np.uint64(((step >> 32) << 20) & 0xFFFFFFFF)]
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    for _ in range(10):
+        p0, p1 = np.uint64(M0) * c[0], np.uint64(M1) * c[2]
+        c = [(p1 >> np.uint64(32)) ^ c[1] ^ np.uint64(k0), p1 & mask, (p0 >> np.uint64(32)) ^ c[3] ^ np.uint64(k1), p0 & mask]
+        k0, k1 = (k0 + W0) & 0xFFFFFFFF, (k1 + W1) & 0xFFFFFFFF
+    u = [((ci >> np.uint64(8)).astype(np.float64) + 0.5) / 16777216.0 for ci in c]
+    r0, r1 = np.sqrt(-2 * np.log(u[0])), np.sqrt(-2 * np.log(u[2]))
+    return np.stack([r0 * np.cos(2 * np.pi * u[1]), r0 * np.sin(2 * np.pi * u[1]), r1 * np.cos(2 * np.pi * u[3])], -1)
+
+
+def test_philox_matches_host_restatement(pa):
+    """The in-kernel generator is exactly the documented counter layout (walker, step, particle) -> 3 normals."""
+    B, off, step, seed = 1000, (1 << 33) + 5, (3 << 32) + 9, 0x1234567890ABCDEF
+    out = torch.empty(B, 39, device="cuda")
+    pa._lib.check(pa._lib.lib().pita_fill_normal(out.data_ptr(), B, 13, 3, seed, off, step, pa._lib.stream_ptr()))
+    want = _philox_normals_host(seed, off + np.arange(B), step, np.arange(13)).reshape(B, 39)
+    np.testing.assert_allclose(out.cpu().numpy(), want, atol=2e-5, rtol=1e-5)
+
+
 def test_elementwise_vs_oracle(pa, golden):
     g = golden("prior.npz")
     for n, d in ((13, 3), (4, 2)):
@@ -336,6 +361,43 @@ def test_post_processing_golden(pa, golden):
         uniforms=cu(g["mala_adaptive_u"]))
     np.testing.assert_allclose(acc, g["mala_adaptive_acc"], atol=1e-7)
     assert rel(xa, g["x_mala_adaptive"]) < 1e-5
+
+
+@pytest.mark.parametrize("target", ["lj13", "lj13_ragged", "lj55", "dw4"])
+@pytest.mark.parametrize("langevin", [False, True])
+def test_fused_descent_equals_per_step(pa, golden, target, langevin):
+    """pita_lj_descent / pita_dw_descent keep the walkers in LDS for all steps; they must reproduce the per-step
+    path (force kernel + pita_em_step) bit for bit, with injected and with Philox noise, and follow the oracle."""
+    gen = torch.Generator().manual_seed(7)
+    if target.startswith("lj13"):
+        e, n, d = pa.LennardJonesEnergy(39, 13, 3), 13, 3
+        x0 = cu(golden("post_lj13.npz")["x0"])
+        x0 = x0.repeat(9, 1)[: (577 if target.endswith("ragged") else 512)]
+        x0 = x0 + 0.01 * torch.randn(x0.shape, generator=gen).cuda()
+        lf = lambda x: O.lj_logp_force(x, 13, 3)
+    elif target == "lj55":
+        e, n, d = pa.LennardJonesEnergy(165, 55, 3), 55, 3
+        g = golden("lj55_logp_force.npz")
+        x0 = cu(g["x"][: int(g["n_cold"])]).repeat(3, 1)[:37]
+        lf = lambda x: O.lj_logp_force(x, 55, 3)
+    else:
+        e, n, d = pa.MultiDoubleWellEnergy(8, 4, 2), 4, 2
+        x0 = (torch.randn(1000, 8, generator=gen) * 1.5).cuda()
+        lf = lambda x: O.dw4_logp_force(x, 4, 2)
+    S, dt = 12, 1e-4
+    mk = lambda: pa.WeightedSDEIntegrator(sde=None, num_integration_steps=1, start_resampling_step=0,
+                                          end_resampling_step=1, num_negative_time_steps=S, dt_negative_time=dt,
+                                          do_langevin=langevin, seed=3)
+    xf = mk().negative_time_descent(x0, e, walker_offset=11)
+    xs = mk().negative_time_descent(x0, e, walker_offset=11, fused=False)
+    assert torch.equal(xf, xs)
+    assert not torch.equal(xf, x0)
+    nz = torch.randn(S, x0.shape[0], n * d, generator=gen)
+    xf = mk().negative_time_descent(x0, e, noise=nz.cuda())
+    xs = mk().negative_time_descent(x0, e, noise=nz.cuda(), fused=False)
+    assert torch.equal(xf, xs)
+    xo = O.negative_time_descent(x0.cpu(), lf, S, dt, n, d, do_langevin=langevin, noise_fn=lambda k, s: nz[k])
+    assert rel(xf, xo) < 1e-5
 
 
 # ------------------------------------------------------------------------------- full size (BASELINE configs)
