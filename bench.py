@@ -94,7 +94,8 @@ def cpu_baseline(n_walkers, n_steps, seed=12345):
 
 def debiased_leg(pita_amd, net, dev, B, with_cpu):
     """Secondary number: the debiased Feynman-Kac regime (PITA's default; sdes.py:151-239): drift of x and of the
-    log-weights through 79 forward-mode launches (pita_egnn_jvp) + assembly + quantile clamp, then the EM update."""
+    log-weights through 40 forward-mode launches (pita_egnn_jvp) + 1 reverse-mode launch (pita_egnn_vjp) + assembly +
+    quantile clamp, then the EM update."""
     import copy
 
     from pita_amd.energy_net import EnergyNet
@@ -122,7 +123,7 @@ def debiased_leg(pita_amd, net, dev, B, with_cpu):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     out = {"metric": "walker-steps/s, debiased (Feynman-Kac) regime, LJ13", "value": B / dt, "walkers": B,
-           "ms_per_step": dt * 1e3, "launches_per_step": 79 + 3}
+           "ms_per_step": dt * 1e3, "launches_per_step": 41 + 3}
     if with_cpu:
         from oracle import pita_oracle as O
 
@@ -255,6 +256,28 @@ def main():
         us_big = time_force(xbig, 20)
         gbs_big = BIG * LJ13_BYTES_PER_EVAL / (us_big * 1e-6) / 1e9
         us_copy = time_copy(B * 39, args.force_evals)  # a device copy moving the same 2 x 10.2 MB
+        # the force kernel where production uses it per step: negative-time descent (sde_integration.py:353-360),
+        # all steps of a launch with the walkers resident in LDS (pita_lj_descent); algorithmic bytes stay
+        # SURVEY 8(d)'s 316 B per walker-eval, actual HBM traffic is one read + one write of x per LAUNCH
+        S_DESC = 1000
+        xd = x.clone()
+
+        def run_descent(noise_scale):
+            pita_amd._lib.check(L.pita_lj_descent(xd.data_ptr(), 0, B, 13, 3, 1.0, 1.0, 1e-6, 1.0, 1.0, 1.0, S_DESC, 1e-7,
+                                                  noise_scale, math.sqrt(2e-7), 1, 0, 0, 1, sp), "pita_lj_descent")
+
+        def time_descent(noise_scale):
+            run_descent(noise_scale)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            run_descent(noise_scale)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / S_DESC
+
+        us_desc, us_ula = time_descent(0.0), time_descent(1.0)
+        assert torch.isfinite(xd).all(), "descent produced non-finite walkers"
+        gbs_desc = B * LJ13_BYTES_PER_EVAL / (us_desc * 1e-6) / 1e9
         force_rl = {"kernel": "lj13_kernel<2> (LJ13 logp+force, 65 536 walkers)", "bound": "hbm", "achieved": gbs,
                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                     "traffic": pmc_traffic("lj13_kernel<2> @65536 walkers") if B == 65536 else None,
@@ -262,7 +285,13 @@ def main():
                     "same_bytes_device_copy_us": us_copy,
                     "same_bytes_device_copy_GBs": 2 * B * 39 * 4 / (us_copy * 1e-6) / 1e9,
                     "large_batch": {"kernel": "lj13_kernel<1>", "walkers": BIG, "us_per_launch": us_big,
-                                    "achieved": gbs_big, "frac": gbs_big / PEAK_HBM_GBS}}
+                                    "achieved": gbs_big, "frac": gbs_big / PEAK_HBM_GBS},
+                    "in_descent_loop": {"kernel": "lj13_descent_kernel (force + update + centring, walkers LDS-resident)",
+                                        "walkers": B, "steps_per_launch": S_DESC, "us_per_step": us_desc,
+                                        "walker_evals_per_s": B / (us_desc * 1e-6), "achieved": gbs_desc,
+                                        "frac": gbs_desc / PEAK_HBM_GBS, "unit": "GB/s (algorithmic, 316 B/walker-eval)",
+                                        "hbm_bytes_per_launch": 2 * B * 39 * 4,
+                                        "us_per_step_with_langevin_noise": us_ula}}
         del xbig
 
     if rank == 0:

@@ -162,6 +162,13 @@ int pita_egnn_jvp(pita_egnn_t* net, const float* h, const float* x, const float*
                   float* dot_out /*nullable: dot_out[b*dot_stride + dot_off] = <x_b, dD_b>*/, int64_t dot_stride,
                   int64_t dot_off, float* diag_acc /*nullable: diag_acc[b] += dD[b, dir]*/, int64_t B, void* stream);
 
+/* Reverse-mode derivative of the denoiser:  vjp = J_x D(h, x)^T cot  (and out = D when out != NULL), one launch for
+ * all walkers.  cot: device [B, D] or NULL (= x).  With cot = x this is the only derivative grad_x E_theta needs
+ * (energy_net.py:33-62: E = (1+c_s)|x|^2/(2h) - <D, x>/h, so grad E = ((1+c_s) x - D - J^T x)/h), replacing the
+ * reference's torch.autograd.grad through the network.  Checkpoint scratch is owned by the handle. */
+int pita_egnn_vjp(pita_egnn_t* net, const float* h, const float* x, const float* beta, const float* cot /*nullable*/,
+                  float* out /*nullable*/, float* vjp, int64_t B, void* stream);
+
 /* Feynman-Kac drift assembly per walker from those reductions (replaces the torch/autograd expressions of
  * sdes.py:157-227): with E = (1+c_s)|x|^2/(2h) - <D_E,x>/h,
  *   grad E = ((1+c_s) x - D_E - jtx_E)/h,  b = (D_S - x)/h * g2/2,  drift_X = gamma (-grad E) g2/2 + gamma b,

@@ -13,9 +13,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int EH = 32;       // hidden_nf
 constexpr int PBS = 36;      // LDS row stride (floats) of the partner table
 constexpr int MAT_F = 1024;  // floats per packed 32x32 matrix
-enum { M_WA = 0, M_WB, M_W2, M_WC1, M_WN1A, M_WN1B, M_WN2, M_COUNT };
+// forward matrices (SiLU pre-scale folded in, see pita_egnn_create) followed by the TRANSPOSES of the unscaled
+// matrices, which the reverse-mode kernel (egnn_vjp_kernel.hip) multiplies adjoints with
+enum { M_WA = 0, M_WB, M_W2, M_WC1, M_WN1A, M_WN1B, M_WN2,
+       M_WAT, M_WBT, M_W2T, M_WC1T, M_WN1AT, M_WN1BT, M_WN2T, M_COUNT };
 enum { V_WRE = 0 /* 64 floats: w_r[out] | w_e[out], natural order */, V_B1 = 2, V_B2, V_WATT, V_BC1, V_WC2, V_BN1,
-       V_BN2, V_COUNT };
+       V_BN2, V_WRF /* unscaled w_r, fragment order */, V_WEF /* unscaled w_e, fragment order */, V_COUNT };
 constexpr int VEC_EMB_F = 96;                    // emb_w0, emb_w1, emb_b
 constexpr int VEC_LAYER_F = V_COUNT * EH + 4;    // vectors (fragment order unless noted) + b_att (+pad)
 
@@ -172,4 +175,6 @@ struct pita_egnn {
   float* d_vecs = nullptr;       // [VEC_EMB_F + L*VEC_LAYER_F]
   const void* shape = nullptr;   // pita::EgnnShape of egnn_kernel.hip
   int n_cu = 256;
+  float* d_ws = nullptr;         // reverse-mode checkpoint scratch (egnn_vjp_kernel.hip), grown on demand
+  size_t ws_bytes = 0;
 };

@@ -23,6 +23,8 @@
 //   geometry          d|d|^2 = 2 <d, dd>,  d(d / (|d| + 1)) = (dd - u dnrm) / nrm
 // One wave per SIMD (512 VGPRs: primal + tangent state of three column tiles without spilling) and
 // primal + tangent partner tables in LDS (35 KB per wave).
+#include <cstdlib>
+
 #include "egnn_common.h"
 
 namespace pita {
@@ -68,8 +70,8 @@ __device__ __forceinline__ void silu_dsilu(float v, float& y, float& g) {
   g = s * fmaf(v * (1.0f / SILU_PRESCALE), 1.0f - s, 1.0f);
 }
 
-template <int N, int DIM, int G, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64, 1) egnn_jvp_kernel(JvpParams p) {
+template <int N, int DIM, int G, int WAVES, int OCC>
+__global__ void __launch_bounds__(WAVES * 64, OCC) egnn_jvp_kernel(JvpParams p) {
   using C = JvpCfg<N, DIM, G, WAVES>;
   constexpr int NT = C::NT;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -347,19 +349,21 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_jvp_kernel(JvpParams p) {
 }
 
 struct JvpShape {
-  int n, dim, G, waves;
+  int n, dim, G, waves, occ;
   void (*kernel)(JvpParams);
   size_t (*lds_bytes)(int);
 };
 template <int N, int DIM, int G, int WAVES>
 static size_t jvp_lds_bytes_of(int L) { return JvpCfg<N, DIM, G, WAVES>::lds_bytes(L); }
-#define PITA_JVP_SHAPE(N, DIM, G, WAVES) \
-  JvpShape { N, DIM, G, WAVES, egnn_jvp_kernel<N, DIM, G, WAVES>, jvp_lds_bytes_of<N, DIM, G, WAVES> }
+#define PITA_JVP_SHAPE(N, DIM, G, WAVES, OCC) \
+  JvpShape { N, DIM, G, WAVES, OCC, egnn_jvp_kernel<N, DIM, G, WAVES, OCC>, jvp_lds_bytes_of<N, DIM, G, WAVES> }
 static const JvpShape kJvpShapes[] = {
-    PITA_JVP_SHAPE(4, 2, 8, 4),
-    PITA_JVP_SHAPE(13, 3, 7, 4),
-    PITA_JVP_SHAPE(22, 3, 4, 4),
-    PITA_JVP_SHAPE(55, 3, 1, 4),
+    PITA_JVP_SHAPE(4, 2, 8, 4, 1),
+    PITA_JVP_SHAPE(13, 3, 7, 4, 1),
+    PITA_JVP_SHAPE(22, 3, 4, 4, 1),
+    PITA_JVP_SHAPE(55, 3, 1, 4, 1),
+    // experimental (PITA_JVP_ALT=1): one tile per wave, two waves per SIMD
+    PITA_JVP_SHAPE(13, 3, 2, 4, 2),
 };
 
 }  // namespace pita
@@ -376,8 +380,9 @@ extern "C" int pita_egnn_jvp(pita_egnn_t* net, const float* h, const float* x, c
   const int D = net->cfg.n_particles * net->cfg.n_dim;
   PITA_REQUIRE(vx || (dir >= -1 && dir < D), "pita_egnn_jvp: dir out of range");
   const JvpShape* s = nullptr;
+  static const int alt = getenv("PITA_JVP_ALT") ? atoi(getenv("PITA_JVP_ALT")) : 0;
   for (const auto& c : kJvpShapes)
-    if (c.n == net->cfg.n_particles && c.dim == net->cfg.n_dim) s = &c;
+    if (c.n == net->cfg.n_particles && c.dim == net->cfg.n_dim && (c.occ == 1 || alt)) s = &c;
   if (!s) return fail(PITA_EUNSUPPORTED, "pita_egnn_jvp: no kernel for this particle system");
   JvpParams p{};
   p.mats16 = net->d_mats16; p.vecs = net->d_vecs; p.n_layers = net->cfg.n_layers; p.in_nf = net->cfg.in_node_nf;
@@ -394,7 +399,7 @@ extern "C" int pita_egnn_jvp(pita_egnn_t* net, const float* h, const float* x, c
   }
   const long long ngroups = (B + s->G - 1) / s->G;
   long long want = (ngroups + s->waves - 1) / s->waves;
-  const long long cap = net->n_cu;  // one 4-wave block per CU (one wave per SIMD)
+  const long long cap = (long long)net->n_cu * s->occ;  // occ 4-wave blocks per CU
   const unsigned grid = (unsigned)(want < cap ? want : cap);
   hipLaunchKernelGGL(s->kernel, dim3(grid), dim3(s->waves * 64), lds, (hipStream_t)stream, p);
   PITA_LAUNCH_CHECK();

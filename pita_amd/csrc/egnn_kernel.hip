@@ -518,6 +518,22 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
     pack_mat(mats + M_WN1A * MAT_F, n0w, 2 * H, 0, kS);
     pack_mat(mats + M_WN1B * MAT_F, n0w, 2 * H, H, 1.0f);
     pack_mat(mats + M_WN2 * MAT_F, n2w, H, 0, kSi);
+    {  // transposes of the unscaled matrices (reverse mode): T[k][o] = W[o][col0 + k]
+      float T[EH * EH];
+      auto pack_t = [&](int slot, const float* M, int ld, int col0) {
+        for (int k = 0; k < H; ++k)
+          for (int o = 0; o < H; ++o) T[k * H + o] = M[o * ld + col0 + k];
+        pack_mat16(m16 + slot * MAT_W, T, H, 0, 1.0f);
+        pack_mat(mats + slot * MAT_F, T, H, 0, 1.0f);
+      };
+      pack_t(M_WAT, e0w, 2 * H + 2, 0);
+      pack_t(M_WBT, e0w, 2 * H + 2, H);
+      pack_t(M_W2T, e2w, H, 0);
+      pack_t(M_WC1T, c0w, H, 0);
+      pack_t(M_WN1AT, n0w, 2 * H, 0);
+      pack_t(M_WN1BT, n0w, 2 * H, H);
+      pack_t(M_WN2T, n2w, H, 0);
+    }
     for (int o = 0; o < H; ++o) {
       vecs[V_WRE * EH + o] = kS * e0w[o * (2 * H + 2) + 2 * H];          // w_r[out]  (k = 0: radial)
       vecs[V_WRE * EH + H + o] = kS * e0w[o * (2 * H + 2) + 2 * H + 1];  // w_e[out]  (k = 1: edge_attr)
@@ -529,6 +545,8 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
     pack_vec(vecs + V_WC2 * EH, c2w, 1, kSi);
     pack_vec(vecs + V_BN1 * EH, n0b, 1, kS);
     pack_vec(vecs + V_BN2 * EH, n2b, 1, 1.0f);
+    pack_vec(vecs + V_WRF * EH, e0w + 2 * H, 2 * H + 2, 1.0f);
+    pack_vec(vecs + V_WEF * EH, e0w + 2 * H + 1, 2 * H + 2, 1.0f);
     vecs[V_COUNT * EH] = ab ? ab[0] : 0.f;
   }
   pita_egnn* net = new pita_egnn();
@@ -578,6 +596,7 @@ extern "C" int pita_egnn_destroy(pita_egnn_t* net) {
   (void)hipFree(net->d_mats);
   (void)hipFree(net->d_vecs);
   (void)hipFree(net->d_mats16);
+  (void)hipFree(net->d_ws);
   delete net;
   return PITA_OK;
 }

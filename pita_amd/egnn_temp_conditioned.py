@@ -177,6 +177,22 @@ class EGNN_dynamics(nn.Module):
                                             _lib.stream_ptr(x_t.device)), "pita_egnn_jvp")
         return out, dout
 
+    def vjp(self, h_t, x_t, beta, cot=None, want_primal=True):
+        """(D, J_x D^T cot): the denoiser and its reverse-mode derivative for a per-walker cotangent (default: x_t
+        itself, which is what grad_x E_theta needs).  One launch (pita_egnn_vjp) instead of dim JVP launches."""
+        x_t = _lib.dev_tensor(x_t, "x_t")
+        B = x_t.shape[0]
+        h_t = _lib.dev_tensor(h_t, "h_t").reshape(-1).expand(B).contiguous()
+        b = _as_batch(beta, B, x_t.device) if self.condition_temperature else None
+        if cot is not None:
+            cot = _lib.dev_tensor(cot, "cot")
+        out = torch.empty_like(x_t) if want_primal else None
+        vjp = torch.empty_like(x_t)
+        _lib.check(_lib.lib().pita_egnn_vjp(self._native(x_t.device), h_t.data_ptr(), x_t.data_ptr(), _lib.ptr(b),
+                                            _lib.ptr(cot), _lib.ptr(out), vjp.data_ptr(), B,
+                                            _lib.stream_ptr(x_t.device)), "pita_egnn_vjp")
+        return out, vjp
+
     def sampler_run(self, x, step_tab, n_steps, noise=None, seed=0, walker_offset=0, step0=0, remove_mean=True,
                     drift_out=None):
         """In-place fused Euler-Maruyama steps (pita_egnn_sampler_run); x: [B, n*d] device tensor."""

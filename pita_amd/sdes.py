@@ -7,9 +7,10 @@
   the per-step (recording / plug-in) path.
 * Debiased Feynman-Kac regime (sdes.py:151-239): drift_X = -gamma grad_x E_theta g^2/2 + gamma s_theta g^2/2 and the
   log-weight drift  gamma^2 <-grad E, b> + gamma div b + gamma dE/dt + gamma'(t) E, clamped at its 0.9 quantile.
-  The reference obtains grad_x E (autograd), div s (vmap(jacrev)) and dE/dt (autograd through h(t)); here all three
-  are assembled from forward-mode derivatives of the two denoisers computed by the HIP kernel pita_egnn_jvp
-  (csrc/egnn_jvp_kernel.hip): dim + 1 tangent directions for the energy net, dim for the score net, per step.
+  The reference obtains grad_x E (autograd), div s (vmap(jacrev)) and dE/dt (autograd through h(t)); here they are
+  assembled from derivatives of the two denoisers computed by HIP kernels: one reverse-mode launch (pita_egnn_vjp,
+  csrc/egnn_vjp_kernel.hip) + one forward-mode launch in the h direction for the energy net, and dim forward-mode
+  launches (pita_egnn_jvp, csrc/egnn_jvp_kernel.hip) for the exact divergence of the score net, per step.
 """
 from dataclasses import dataclass
 from typing import Optional
@@ -101,6 +102,18 @@ class VEReverseSDE:
                       want_tangent=False, dot_out=dot_h)
         return Dx, trace, jtx, dot_h
 
+    def _energy_gradient_terms(self, model, ht, x, beta):
+        """D, J_x D^T x (one reverse-mode launch, pita_egnn_vjp) and <x, dD/dh> (one forward-mode launch): all that
+        grad_x E_theta and dE_theta/dt need.  Backbones without ``vjp`` fall back to dim forward-mode launches."""
+        if not hasattr(model, "vjp"):
+            D_E, _, jtx, dot_h = self._denoiser_jacobian_terms(model, ht, x, beta, True)
+            return D_E, jtx, dot_h
+        D_E, jtx = model.vjp(ht, x, beta)
+        dot_h = torch.empty(x.shape[0], device=x.device)
+        model.jvp(ht, x, beta, direction=-1, vh=torch.ones(x.shape[0], device=x.device), want_primal=False,
+                  want_tangent=False, dot_out=dot_h)
+        return D_E, jtx, dot_h
+
     def f_debiased(self, t, x, beta, gamma_energy, gamma_energy_schedule, clamp_chunk=None):
         assert self.energy_net is not None
         if self.pin_energy or getattr(self.energy_net, "precondition_beta", False) or (
@@ -117,7 +130,7 @@ class VEReverseSDE:
         gamma = float(gamma_energy.reshape(-1)[0]) if isinstance(gamma_energy, torch.Tensor) else float(gamma_energy)
         dg = gamma_energy_schedule.dgamma_dt(t)
         dgamma = float(dg.reshape(-1)[0]) if isinstance(dg, torch.Tensor) else float(dg)
-        D_E, _, jtx_E, dot_h = self._denoiser_jacobian_terms(self.energy_net.net, ht, x, beta, True)
+        D_E, jtx_E, dot_h = self._energy_gradient_terms(self.energy_net.net, ht, x, beta)
         D_S, trace_S, _, _ = self._denoiser_jacobian_terms(self.score_net.model, ht, x, beta, False)
         drift_X = torch.empty_like(x)
         drift_A, div_bt, cross, dUdt, Ut = (torch.empty(B, device=x.device) for _ in range(5))
