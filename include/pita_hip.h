@@ -86,11 +86,12 @@ int pita_gmm_logp_force(const float* x, float* logp, float* force /*nullable*/, 
                         void* stream);
 
 /* Table-driven classical force field (K4): bonds, angles, periodic torsions, LJ + Coulomb over all atom pairs with
- * exceptions and the optional CutoffNonPeriodic reaction field -- the functional forms of OpenMM's HarmonicBondForce,
- * HarmonicAngleForce, PeriodicTorsionForce and NonbondedForce.  Stands in for the arithmetic ALPEnergy.__call__
- * (pita/src/energies/alp_energy.py:122-149) delegates to OpenMM; the GB-OBC1 term is not implemented and the real
- * amber14 parameters are outside the reference tree (parity unpinned).  All table pointers are HOST pointers copied at
- * creation.  Units: nm, kJ/mol, elementary charges; x_model * length_scale = nm; logp = -E/kT. */
+ * exceptions and the optional CutoffNonPeriodic reaction field, and the GB-OBC1 implicit solvent with its ACE
+ * surface-area term -- the functional forms of OpenMM's HarmonicBondForce, HarmonicAngleForce, PeriodicTorsionForce,
+ * NonbondedForce and GBSAOBCForce.  Stands in for the arithmetic ALPEnergy.__call__
+ * (pita/src/energies/alp_energy.py:93-149) delegates to OpenMM (amber14-all.xml + implicit/obc1.xml); the real
+ * amber14 parameters are outside the reference tree (parity unpinned).  All table pointers are HOST pointers copied
+ * at creation.  Units: nm, kJ/mol, elementary charges; x_model * length_scale = nm; logp = -E/kT. */
 typedef struct pita_ff pita_ff_t;
 typedef struct {
   int n_atoms;
@@ -102,6 +103,11 @@ typedef struct {
   int use_cutoff; float cutoff; float rf_dielectric;              /* CutoffNonPeriodic reaction field (78.3 in OpenMM) */
   float length_scale;                                              /* 0.1640 for the reference's normalised ALDP (energy/aldp.yaml:11) */
   float kT;                                                        /* kJ/mol */
+  /* GBSAOBCForce, OBC1 (amber implicit/obc1.xml): NULL gb_radius = no implicit solvent */
+  const float* gb_radius;                                          /* [n] nm */
+  const float* gb_scale;                                           /* [n] HCT overlap scale factors */
+  float gb_solute_dielectric, gb_solvent_dielectric;               /* OpenMM defaults 1.0, 78.5 */
+  float gb_surface_area_factor;                                    /* 4 pi x 2.25936 kJ/mol/nm^2 = 28.3919551; 0 = no SA term */
 } pita_ff_config;
 int pita_ff_create(pita_ff_t** out, const pita_ff_config* cfg);
 int pita_ff_destroy(pita_ff_t* ff);

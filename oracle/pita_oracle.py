@@ -689,7 +689,9 @@ def w2_1d(a: np.ndarray, b: np.ndarray) -> float:
 # (amber14-all + implicit/obc1, CutoffNonPeriodic 2 nm) through bgflow (alp_energy.py:93-149); neither OpenMM nor
 # the PDB / force-field XML are in the tree, so only the published functional forms of OpenMM's standard forces are
 # restated here (HarmonicBondForce, HarmonicAngleForce, PeriodicTorsionForce, NonbondedForce with Lorentz-Berthelot
-# mixing, exceptions and the CutoffNonPeriodic reaction field).  The GB-OBC1 implicit-solvent term is NOT restated.
+# mixing, exceptions and the CutoffNonPeriodic reaction field; GBSAOBCForce = the OBC model I generalised-Born
+# solvent of Onufriev, Bashford & Case, Proteins 55:383 (2004) with HCT pairwise descreening and the ACE
+# surface-area term, as OpenMM evaluates it [restated from the published algorithm; not checkable here]).
 # --------------------------------------------------------------------------------------
 
 ONE_4PI_EPS0 = 138.935456  # kJ nm / (mol e^2), OpenMM's constant
@@ -757,7 +759,52 @@ def ff_energy(x: Tensor, ff: Dict[str, Tensor], length_scale: float = 1.0, cutof
         coul = torch.where(is_exc, coul_plain, coul_rf)
         inside = (d < cutoff).to(dt)
         E = E + ((lj + coul) * inside).sum(-1)
+    if "gb_radius" in ff:
+        E = E + gbsa_obc1_energy(r, q, ff["gb_radius"].to(dt), ff["gb_scale"].to(dt), cutoff,
+                                 float(ff.get("gb_solute_dielectric", 1.0)), float(ff.get("gb_solvent_dielectric", 78.5)),
+                                 float(ff.get("gb_surface_area_factor", 28.3919551)))
     return E
+
+
+def gbsa_obc1_energy(r: Tensor, q: Tensor, radius: Tensor, scale: Tensor, cutoff: Optional[float] = None,
+                     solute_eps: float = 1.0, solvent_eps: float = 78.5, sa_factor: float = 28.3919551,
+                     probe: float = 0.14) -> Tensor:
+    """GB-OBC (model I: alpha=0.8, beta=0, gamma=2.909125) + ACE surface area, kJ/mol per walker.  r: [B, n, 3] nm.
+      rho_i = R_i - 0.009, sigma_j = s_j rho_j;  I_i = sum_{j != i, rho_i < r + sigma_j} H(r_ij, rho_i, sigma_j)  (HCT)
+      psi_i = rho_i I_i / 2;  B_i = 1 / (1/rho_i - tanh(alpha psi - beta psi^2 + gamma psi^3) / R_i)
+      E = -k_e (1/eps_in - 1/eps_out) [ sum_{i<j} q_i q_j / f_ij + 1/2 sum_i q_i^2 / B_i ] + sum_i sa (R_i + probe)^2 (R_i/B_i)^6,
+      f_ij = sqrt(r^2 + B_i B_j exp(-r^2 / (4 B_i B_j))); with a cutoff, pairs beyond it are dropped everywhere and the
+      pair term is shifted by -q_i q_j / cutoff."""
+    Bn, n = r.shape[0], r.shape[1]
+    dt = r.dtype
+    eye = torch.eye(n, dtype=torch.bool)
+    diff = r[:, :, None] - r[:, None]
+    d = torch.sqrt((diff * diff).sum(-1) + eye.to(dt))  # diagonal padded with 1 (masked out below)
+    rho = radius - 0.009
+    sig = rho * scale
+    rho_i, sig_j = rho[None, :, None], sig[None, None, :]
+    rs = d + sig_j
+    l = 1.0 / torch.maximum(rho_i.expand_as(d), (d - sig_j).abs())
+    u = 1.0 / rs
+    term = l - u + 0.25 * d * (u * u - l * l) + 0.5 / d * torch.log(u / l) + 0.25 * sig_j**2 / d * (l * l - u * u)
+    term = term + torch.where(rho_i < sig_j - d, 2.0 * (1.0 / rho_i - l), torch.zeros_like(d))
+    mask = (~eye)[None] & (rho_i < rs)
+    if cutoff is not None:
+        mask = mask & (d < cutoff)
+    psi = 0.5 * rho * (term * mask.to(dt)).sum(-1)
+    born = 1.0 / (1.0 / rho - torch.tanh(0.8 * psi + 2.909125 * psi**3) / radius)
+    pf = -ONE_4PI_EPS0 * (1.0 / solute_eps - 1.0 / solvent_eps)
+    iu = torch.triu_indices(n, n, offset=1)
+    dij = d[:, iu[0], iu[1]]
+    a2 = born[:, iu[0]] * born[:, iu[1]]
+    f = torch.sqrt(dij * dij + a2 * torch.exp(-dij * dij / (4 * a2)))
+    c = pf * q[iu[0]] * q[iu[1]]
+    pair = c / f
+    if cutoff is not None:
+        pair = (pair - c / cutoff) * (dij < cutoff).to(dt)
+    e_self = 0.5 * pf * (q * q / born).sum(-1)
+    e_sa = (sa_factor * (radius + probe) ** 2 * (radius / born) ** 6).sum(-1)
+    return pair.sum(-1) + e_self + e_sa
 
 
 def ff_logp_force(x: Tensor, ff: Dict[str, Tensor], kT: float, length_scale: float = 1.0, cutoff: Optional[float] = None,

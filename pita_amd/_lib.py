@@ -34,7 +34,9 @@ class FfConfig(ctypes.Structure):
                 ("charge", c_void_p), ("sigma", c_void_p), ("epsilon", c_void_p),
                 ("n_exceptions", c_int), ("exc_idx", c_void_p), ("exc_par", c_void_p),
                 ("use_cutoff", c_int), ("cutoff", c_float), ("rf_dielectric", c_float),
-                ("length_scale", c_float), ("kT", c_float)]
+                ("length_scale", c_float), ("kT", c_float),
+                ("gb_radius", c_void_p), ("gb_scale", c_void_p), ("gb_solute_dielectric", c_float),
+                ("gb_solvent_dielectric", c_float), ("gb_surface_area_factor", c_float)]
 
 
 class MlpConfig(ctypes.Structure):

@@ -5,9 +5,9 @@ Stands in for ``ALPEnergy`` (pita/src/energies/alp_energy.py:24-149): same call 
 coordinates (``x * data_normalization_factor`` = nm, 0.1640 for ALDP), log-density ``-E/kT`` at the integrator
 temperature.  The reference obtains E from OpenMM (amber14-all + implicit/obc1) through bgflow; here the standard
 bonded + nonbonded terms are evaluated by ``pita_ff_logp_force`` from parameter TABLES the caller supplies (e.g.
-exported from the OpenMM ``System`` the reference itself serialises, generate_md.py:105-106).  The GB-OBC1
-implicit-solvent term is not implemented and no amber parameters ship with the reference tree, so this target is
-parity-unpinned.
+exported from the OpenMM ``System`` the reference itself serialises, generate_md.py:105-106), including the
+GB-OBC1 implicit solvent + ACE surface area of ``implicit/obc1.xml`` when ``gb_radius`` / ``gb_scale`` are given.
+No amber parameters ship with the reference tree, so this target is parity-unpinned.
 """
 import ctypes
 
@@ -22,9 +22,11 @@ KB_KJ_PER_MOL_K = 8.314462618e-3
 
 class ForceFieldEnergy(BaseMoleculeEnergy):
     def __init__(self, tables, n_particles, spatial_dim=3, temperature=300.0, data_normalization_factor=1.0,
-                 cutoff=None, rf_dielectric=78.3, device="cuda", is_molecule=True, **kwargs):
+                 cutoff=None, rf_dielectric=78.3, device="cuda", is_molecule=True, gb_solute_dielectric=1.0,
+                 gb_solvent_dielectric=78.5, gb_surface_area_factor=28.3919551, **kwargs):
         """tables: dict of numpy arrays / tensors: bond_idx[nb,2], bond_par[nb,2], angle_idx[na,3], angle_par[na,2],
-        tors_idx[nt,4], tors_par[nt,3], charge[n], sigma[n], epsilon[n], exc_idx[ne,2], exc_par[ne,3]."""
+        tors_idx[nt,4], tors_par[nt,3], charge[n], sigma[n], epsilon[n], exc_idx[ne,2], exc_par[ne,3]; optional
+        gb_radius[n], gb_scale[n] switch the GB-OBC1 implicit solvent on (OpenMM GBSAOBCForce parameters)."""
         assert spatial_dim == 3
         super().__init__(dimensionality=3 * n_particles, n_particles=n_particles, spatial_dim=3, data_path=None,
                          device=device, is_molecule=is_molecule, temperature=temperature, should_normalize=False,
@@ -40,6 +42,11 @@ class ForceFieldEnergy(BaseMoleculeEnergy):
                        charge=f32("charge", 1), sigma=f32("sigma", 1), epsilon=f32("epsilon", 1),
                        exc_idx=i32("exc_idx", 2), exc_par=f32("exc_par", 3))
         assert self._t["charge"].shape[0] == n_particles
+        self._gb = "gb_radius" in tables
+        if self._gb:
+            self._t["gb_radius"], self._t["gb_scale"] = f32("gb_radius", 1), f32("gb_scale", 1)
+            assert self._t["gb_radius"].shape[0] == n_particles and self._t["gb_scale"].shape[0] == n_particles
+        self._gb_par = (float(gb_solute_dielectric), float(gb_solvent_dielectric), float(gb_surface_area_factor))
         self._handle = None
 
     def _native(self):
@@ -52,7 +59,9 @@ class ForceFieldEnergy(BaseMoleculeEnergy):
                                 P(t["charge"]), P(t["sigma"]), P(t["epsilon"]),
                                 len(t["exc_idx"]), P(t["exc_idx"]), P(t["exc_par"]),
                                 int(self.cutoff is not None), float(self.cutoff or 0.0), self.rf_dielectric,
-                                self.length_scale, self.kT)
+                                self.length_scale, self.kT,
+                                P(t["gb_radius"]) if self._gb else None, P(t["gb_scale"]) if self._gb else None,
+                                *self._gb_par)
             h = ctypes.c_void_p()
             _lib.check(_lib.lib().pita_ff_create(ctypes.byref(h), ctypes.byref(cfg)), "pita_ff_create")
             self._handle = h

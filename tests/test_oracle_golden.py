@@ -258,3 +258,27 @@ def test_w2():
     assert O.w2_1d(a, a) == 0
     assert abs(O.w2_1d(a, a + 2.0) - 2.0) < 1e-12
     assert abs(O.w2_1d(a[:500], np.concatenate([a[:500], a[:500]])) ) < 1e-9
+
+
+def test_gbsa_obc1_limits():
+    """GB-OBC1 restatement (parity unpinned): closed-form limits.  One ion: Born radius = offset radius, energy =
+    Born self energy + ACE term.  Two distant ions: Born radii -> offset radii and the pair term -> the screened
+    Coulomb correction -k_e (1 - 1/eps) q1 q2 / r."""
+    q = torch.tensor([0.7, -0.4], dtype=torch.float64)
+    R = torch.tensor([0.15, 0.17], dtype=torch.float64)
+    s = torch.tensor([0.8, 0.72], dtype=torch.float64)
+    pf = -O.ONE_4PI_EPS0 * (1.0 - 1.0 / 78.5)
+    one = O.gbsa_obc1_energy(torch.zeros(1, 1, 3, dtype=torch.float64), q[:1], R[:1], s[:1])
+    rho = R - 0.009
+    want1 = 0.5 * pf * q[0] ** 2 / rho[0] + 28.3919551 * (R[0] + 0.14) ** 2 * (R[0] / rho[0]) ** 6
+    assert abs(one.item() - want1.item()) < 1e-10
+    r = torch.zeros(1, 2, 3, dtype=torch.float64)
+    r[0, 1, 0] = 50.0
+    two = O.gbsa_obc1_energy(r, q, R, s)
+    self2 = sum(0.5 * pf * q[i] ** 2 / rho[i] + 28.3919551 * (R[i] + 0.14) ** 2 * (R[i] / rho[i]) ** 6 for i in range(2))
+    assert abs(two.item() - (self2 + pf * q[0] * q[1] / 50.0).item()) < 1e-4
+    # descreening: a buried neighbour raises the Born radius, i.e. weakens |self energy|
+    r[0, 1, 0] = 0.2
+    near = O.gbsa_obc1_energy(r, torch.tensor([0.7, 0.0], dtype=torch.float64), R, s, sa_factor=0.0)
+    far = 0.5 * pf * 0.49 / rho[0]
+    assert far < near.item() < 0.0
