@@ -8,154 +8,176 @@
 // from the caller as flat tables (e.g. exported from an OpenMM System).  PARITY UNPINNED: checked only against the
 // oracle's restatement of the same forms (autograd forces) on synthetic topologies.
 //
-// Mapping: one lane = one walker; a wave stages its 64 walkers' coordinates in LDS (row stride odd -> the per-lane row
-// accesses of a uniformly indexed atom are bank-conflict free), walks the interaction tables with wave-uniform
-// (scalar) loads, and accumulates the energy gradient into a second LDS row per walker (only the owning lane touches
-// its row: no atomics).  Loads and stores of x / force are contiguous spans.  ~14 kflop and 536 B per walker-eval for a
-// 22-atom peptide: latency- rather than bandwidth-bound at the 16 384-walker batches of BASELINE config C4.
+// Mapping: one thread = one (walker, atom), floor(256/n) walkers per 256-thread block (so even the 4 096 walkers per
+// GPU of BASELINE config C4 put a wave on every SIMD); coordinates and tables live in LDS; loads and stores of
+// x / force are contiguous spans.  ~14 kflop (+ ~60 kflop with GB-OBC1) and 536 B per walker-eval for a 22-atom
+// peptide: compute- rather than bandwidth-bound.
 #include "common.h"
 
 namespace pita {
 
 struct FfParams {
   int n, nb, na, nt, np;
-  const int* bond_idx; const float* bond_par;
-  const int* angle_idx; const float* angle_par;
-  const int* tors_idx; const float* tors_par;
-  const int* pair_idx; const float* pair_par;  // [np][2] ; [np][4] = (ONE_4PI_EPS0*qq, sigma, 4*eps, is_exception)
+  // tables (inside `blob`): bond_idx[nb][2], bond_par[nb][2], angle_idx[na][3], angle_par[na][2], tors_idx[nt][4],
+  // tors_par[nt][3], pair_idx[np][2], pair_par[np][4] = (ONE_4PI_EPS0*qq, sigma, 4*eps, is_exception)
   float length_scale, inv_kT, cutoff, krf, crf;
   int use_cutoff;
   int gb;                // GBSAOBCForce (OBC1) present
-  const float* gb_par;   // [n][4] = (offset radius rho = R - 0.009, scaled radius s*rho, R, charge)
+  // gb_par[n][4] (inside `blob`) = (offset radius rho = R - 0.009, scaled radius s*rho, R, charge)
   float gb_pf, gb_sa, gb_probe;  // -ONE_4PI_EPS0 (1/eps_solute - 1/eps_solvent); 4 pi * surface-area energy; probe radius
+  const unsigned* blob;  // all tables, contiguous (each padded to 16 B); staged into LDS once per block
+  int blob_words;
+  int o_bond_idx, o_bond_par, o_angle_idx, o_angle_par, o_tors_idx, o_tors_par, o_pair_idx, o_pair_par, o_gb_par;  // word offsets
+  int o_csr_off, o_csr_ent;  // per-atom interaction lists: csr_off[3][n+1] (bonds, angles, torsions), entries (term << 2) | role
   const float* x; float* logp; float* force;
   long long B;
 };
 
-__global__ void __launch_bounds__(64) ff_kernel(FfParams p) {
+// One thread = one (walker, atom): it evaluates every interaction its atom takes part in and keeps the atom's gradient
+// in registers -- no atomics, no cross-lane reduction of forces (an interaction is evaluated once per participating
+// atom: 2x for pairs and bonds, 3x angles, 4x torsions; the alternative, LDS float atomics, measured 10x slower: the
+// LDS executes ds_add_f32 at well under one lane per clock).  Per-atom interaction lists (CSR) are built on the host.
+constexpr int FF_THREADS = 256;
+
+__global__ void __launch_bounds__(FF_THREADS) ff_kernel(FfParams p) {
   extern __shared__ float sm[];
-  const int D = 3 * p.n, S = D | 1, SB = p.n | 1;
-  float* xs = sm;
-  float* gs = sm + 64 * S;
-  float* bs = gs + 64 * S;  // GB: Born radii | chain factors | dE/dB, three [64][SB] tables
-  const int lane = threadIdx.x;
-  const long long nblk = (p.B + 63) / 64;
+  const int n = p.n, D = 3 * n, WPB = FF_THREADS / n;
+  // interaction tables: LDS-resident for the whole (persistent) block
+  unsigned* tb = reinterpret_cast<unsigned*>(sm);
+  for (int i = threadIdx.x; i < p.blob_words; i += FF_THREADS) tb[i] = p.blob[i];
+  const int* bond_idx = reinterpret_cast<const int*>(tb + p.o_bond_idx);
+  const float* bond_par = reinterpret_cast<const float*>(tb + p.o_bond_par);
+  const int* angle_idx = reinterpret_cast<const int*>(tb + p.o_angle_idx);
+  const float* angle_par = reinterpret_cast<const float*>(tb + p.o_angle_par);
+  const int* tors_idx = reinterpret_cast<const int*>(tb + p.o_tors_idx);
+  const float* tors_par = reinterpret_cast<const float*>(tb + p.o_tors_par);
+  const float* pair_par = reinterpret_cast<const float*>(tb + p.o_pair_par);
+  const float* gb_par = reinterpret_cast<const float*>(tb + p.o_gb_par);
+  const int* csr_off = reinterpret_cast<const int*>(tb + p.o_csr_off);  // [3][n+1]: bonds, angles, torsions
+  const int* csr_ent = reinterpret_cast<const int*>(tb + p.o_csr_ent);  // (term << 2) | role
+  float* xs = sm + p.blob_words;   // [WPB][D] coordinates (nm)
+  float* gs = xs + WPB * D;        // [WPB][D] gradient, for the coalesced store
+  float* es = gs + WPB * D;        // [WPB][n] energy partials
+  float* br = es + WPB * n;        // [WPB][n] Born radii
+  float* bw = br + WPB * n;        // [WPB][n] dE/d(HCT sum)
+  const int tid = threadIdx.x, wl = tid / n, a = tid - wl * n;
+  const bool lane_on = wl < WPB;
+  const long long nblk = (p.B + WPB - 1) / WPB;
   for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-    const long long w0 = blk * 64;
-    const int nw = (int)((p.B - w0) < 64 ? (p.B - w0) : 64);
-    for (int q = lane; q < 64 * D; q += 64) {
-      const int w = q / D, c = q - w * D;
-      xs[w * S + c] = (w < nw) ? p.x[w0 * D + q] * p.length_scale : (float)(c % 7) * 0.37f;  // dummy rows stay finite
-      gs[w * S + c] = 0.f;
-    }
+    const long long w0 = blk * WPB;
+    const int nw = (int)((p.B - w0) < WPB ? (p.B - w0) : WPB);
+    for (int q = tid; q < nw * D; q += FF_THREADS) xs[q] = p.x[w0 * D + q] * p.length_scale;
     __syncthreads();
-    const float* xr = xs + lane * S;
-    float* gr = gs + lane * S;
-    float E = 0.f;
-    // ---- HarmonicBondForce: 1/2 k (r - r0)^2
-    for (int t = 0; t < p.nb; ++t) {
-      const int i = 3 * p.bond_idx[2 * t], j = 3 * p.bond_idx[2 * t + 1];
-      const float r0 = p.bond_par[2 * t], k = p.bond_par[2 * t + 1];
-      const float d0 = xr[i] - xr[j], d1 = xr[i + 1] - xr[j + 1], d2 = xr[i + 2] - xr[j + 2];
-      const float r = sqrtf(fmaf(d0, d0, fmaf(d1, d1, d2 * d2)));
-      const float dr = r - r0;
-      E = fmaf(0.5f * k * dr, dr, E);
-      const float c = k * dr / r;
-      gr[i] += c * d0; gr[i + 1] += c * d1; gr[i + 2] += c * d2;
-      gr[j] -= c * d0; gr[j + 1] -= c * d1; gr[j + 2] -= c * d2;
-    }
-    // ---- HarmonicAngleForce: 1/2 k (theta - theta0)^2
-    for (int t = 0; t < p.na; ++t) {
-      const int i = 3 * p.angle_idx[3 * t], j = 3 * p.angle_idx[3 * t + 1], k3 = 3 * p.angle_idx[3 * t + 2];
-      const float th0 = p.angle_par[2 * t], k = p.angle_par[2 * t + 1];
-      float a[3], b[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { a[c] = xr[i + c] - xr[j + c]; b[c] = xr[k3 + c] - xr[j + c]; }
-      const float aa = fmaf(a[0], a[0], fmaf(a[1], a[1], a[2] * a[2])), bb = fmaf(b[0], b[0], fmaf(b[1], b[1], b[2] * b[2]));
-      const float ab = fmaf(a[0], b[0], fmaf(a[1], b[1], a[2] * b[2]));
-      const float inv = 1.0f / sqrtf(aa * bb);
-      const float cosv = fminf(fmaxf(ab * inv, -1.0f), 1.0f);
-      const float th = acosf(cosv);
-      const float dth = th - th0;
-      E = fmaf(0.5f * k * dth, dth, E);
-      const float sinv = fmaxf(sqrtf(fmaf(-cosv, cosv, 1.0f)), 1e-6f);
-      const float dEdc = -k * dth / sinv;  // dE/dcos
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float gi = dEdc * (b[c] * inv - cosv * a[c] / aa);
-        const float gk = dEdc * (a[c] * inv - cosv * b[c] / bb);
-        gr[i + c] += gi; gr[k3 + c] += gk; gr[j + c] -= gi + gk;
+    const bool act = lane_on && wl < nw;
+    const float* xr = xs + (act ? wl : 0) * D;
+    const float xa0 = xr[3 * a % D], xa1 = xr[(3 * a + 1) % D], xa2 = xr[(3 * a + 2) % D];
+    float E = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (act) {
+      // ---- HarmonicBondForce: 1/2 k (r - r0)^2
+      for (int e = csr_off[a]; e < csr_off[a + 1]; ++e) {
+        const int t = csr_ent[e] >> 2, role = csr_ent[e] & 3;
+        const int i = 3 * bond_idx[2 * t], j = 3 * bond_idx[2 * t + 1];
+        const float r0 = bond_par[2 * t], k = bond_par[2 * t + 1];
+        const float d0 = xr[i] - xr[j], d1 = xr[i + 1] - xr[j + 1], d2 = xr[i + 2] - xr[j + 2];
+        const float r = sqrtf(fmaf(d0, d0, fmaf(d1, d1, d2 * d2)));
+        const float dr = r - r0;
+        if (role == 0) E = fmaf(0.5f * k * dr, dr, E);
+        const float c = (role == 0 ? k : -k) * dr / r;
+        g0 = fmaf(c, d0, g0); g1 = fmaf(c, d1, g1); g2 = fmaf(c, d2, g2);
       }
-    }
-    // ---- PeriodicTorsionForce: k (1 + cos(n phi - phase))
-    for (int t = 0; t < p.nt; ++t) {
-      const int i = 3 * p.tors_idx[4 * t], j = 3 * p.tors_idx[4 * t + 1], k3 = 3 * p.tors_idx[4 * t + 2], l = 3 * p.tors_idx[4 * t + 3];
-      const float per = p.tors_par[3 * t], ph = p.tors_par[3 * t + 1], k = p.tors_par[3 * t + 2];
-      float b1[3], b2[3], b3[3];
+      // ---- HarmonicAngleForce: 1/2 k (theta - theta0)^2
+      for (int e = csr_off[n + 1 + a]; e < csr_off[n + 1 + a + 1]; ++e) {
+        const int t = csr_ent[e] >> 2, role = csr_ent[e] & 3;
+        const int i = 3 * angle_idx[3 * t], j = 3 * angle_idx[3 * t + 1], k3 = 3 * angle_idx[3 * t + 2];
+        const float th0 = angle_par[2 * t], k = angle_par[2 * t + 1];
+        float av[3], bv[3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { b1[c] = xr[j + c] - xr[i + c]; b2[c] = xr[k3 + c] - xr[j + c]; b3[c] = xr[l + c] - xr[k3 + c]; }
-      const float n1[3] = {b1[1] * b2[2] - b1[2] * b2[1], b1[2] * b2[0] - b1[0] * b2[2], b1[0] * b2[1] - b1[1] * b2[0]};
-      const float n2[3] = {b2[1] * b3[2] - b2[2] * b3[1], b2[2] * b3[0] - b2[0] * b3[2], b2[0] * b3[1] - b2[1] * b3[0]};
-      const float b22 = fmaf(b2[0], b2[0], fmaf(b2[1], b2[1], b2[2] * b2[2]));
-      const float nb2 = sqrtf(b22);
-      const float yv = (b1[0] * n2[0] + b1[1] * n2[1] + b1[2] * n2[2]) * nb2;
-      const float xv = n1[0] * n2[0] + n1[1] * n2[1] + n1[2] * n2[2];
-      const float phi = atan2f(yv, xv);
-      const float ang = fmaf(per, phi, -ph);
-      E += k * (1.0f + cosf(ang));
-      const float dEdphi = -k * per * sinf(ang);
-      const float n11 = fmaxf(n1[0] * n1[0] + n1[1] * n1[1] + n1[2] * n1[2], 1e-20f);
-      const float n22 = fmaxf(n2[0] * n2[0] + n2[1] * n2[1] + n2[2] * n2[2], 1e-20f);
-      const float pq = (b1[0] * b2[0] + b1[1] * b2[1] + b1[2] * b2[2]) / b22;
-      const float qq = (b3[0] * b2[0] + b3[1] * b2[1] + b3[2] * b2[2]) / b22;
-      const float ci = -nb2 / n11, cl = nb2 / n22;
+        for (int c = 0; c < 3; ++c) { av[c] = xr[i + c] - xr[j + c]; bv[c] = xr[k3 + c] - xr[j + c]; }
+        const float aa = fmaf(av[0], av[0], fmaf(av[1], av[1], av[2] * av[2]));
+        const float bb = fmaf(bv[0], bv[0], fmaf(bv[1], bv[1], bv[2] * bv[2]));
+        const float ab = fmaf(av[0], bv[0], fmaf(av[1], bv[1], av[2] * bv[2]));
+        const float inv = 1.0f / sqrtf(aa * bb);
+        const float cosv = fminf(fmaxf(ab * inv, -1.0f), 1.0f);
+        const float dth = acosf(cosv) - th0;
+        if (role == 0) E = fmaf(0.5f * k * dth, dth, E);
+        const float sinv = fmaxf(sqrtf(fmaf(-cosv, cosv, 1.0f)), 1e-6f);
+        const float dEdc = -k * dth / sinv;  // dE/dcos
+        float gg[3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float di = ci * n1[c], dl = cl * n2[c];
-        gr[i + c] += dEdphi * di;
-        gr[l + c] += dEdphi * dl;
-        gr[j + c] += dEdphi * (-(pq + 1.0f) * di + qq * dl);
-        gr[k3 + c] += dEdphi * (-(qq + 1.0f) * dl + pq * di);
+        for (int c = 0; c < 3; ++c) {
+          const float gi = dEdc * (bv[c] * inv - cosv * av[c] / aa);
+          const float gk = dEdc * (av[c] * inv - cosv * bv[c] / bb);
+          gg[c] = role == 0 ? gi : (role == 2 ? gk : -(gi + gk));
+        }
+        g0 += gg[0]; g1 += gg[1]; g2 += gg[2];
       }
-    }
-    // ---- NonbondedForce: all pairs i<j (exceptions carry their own parameters)
-    for (int t = 0; t < p.np; ++t) {
-      const int i = 3 * p.pair_idx[2 * t], j = 3 * p.pair_idx[2 * t + 1];
-      const float qq = p.pair_par[4 * t], sg = p.pair_par[4 * t + 1], e4 = p.pair_par[4 * t + 2], exc = p.pair_par[4 * t + 3];
-      const float d0 = xr[i] - xr[j], d1 = xr[i + 1] - xr[j + 1], d2 = xr[i + 2] - xr[j + 2];
-      const float r2 = fmaf(d0, d0, fmaf(d1, d1, d2 * d2));
-      const float ir2 = 1.0f / r2, ir = sqrtf(ir2);
-      const float s2 = sg * sg * ir2, s6 = s2 * s2 * s2;
-      float e = e4 * fmaf(s6, s6, -s6);
-      float g = e4 * (-12.0f * s6 * s6 + 6.0f * s6) * ir2;  // (dE/dr)/r
-      if (p.use_cutoff && exc == 0.f) {
-        e += qq * (ir + p.krf * r2 - p.crf);
-        g += qq * (-ir * ir2 + 2.0f * p.krf);
-      } else {
-        e += qq * ir;
-        g += -qq * ir * ir2;
+      // ---- PeriodicTorsionForce: k (1 + cos(n phi - phase))
+      for (int e = csr_off[2 * (n + 1) + a]; e < csr_off[2 * (n + 1) + a + 1]; ++e) {
+        const int t = csr_ent[e] >> 2, role = csr_ent[e] & 3;
+        const int i = 3 * tors_idx[4 * t], j = 3 * tors_idx[4 * t + 1], k3 = 3 * tors_idx[4 * t + 2], l = 3 * tors_idx[4 * t + 3];
+        const float per = tors_par[3 * t], ph = tors_par[3 * t + 1], k = tors_par[3 * t + 2];
+        float b1[3], b2[3], b3[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { b1[c] = xr[j + c] - xr[i + c]; b2[c] = xr[k3 + c] - xr[j + c]; b3[c] = xr[l + c] - xr[k3 + c]; }
+        const float n1[3] = {b1[1] * b2[2] - b1[2] * b2[1], b1[2] * b2[0] - b1[0] * b2[2], b1[0] * b2[1] - b1[1] * b2[0]};
+        const float n2[3] = {b2[1] * b3[2] - b2[2] * b3[1], b2[2] * b3[0] - b2[0] * b3[2], b2[0] * b3[1] - b2[1] * b3[0]};
+        const float b22 = fmaf(b2[0], b2[0], fmaf(b2[1], b2[1], b2[2] * b2[2]));
+        const float nb2 = sqrtf(b22);
+        const float yv = (b1[0] * n2[0] + b1[1] * n2[1] + b1[2] * n2[2]) * nb2;
+        const float xv = n1[0] * n2[0] + n1[1] * n2[1] + n1[2] * n2[2];
+        const float ang = fmaf(per, atan2f(yv, xv), -ph);
+        if (role == 0) E += k * (1.0f + cosf(ang));
+        const float dEdphi = -k * per * sinf(ang);
+        const float n11 = fmaxf(n1[0] * n1[0] + n1[1] * n1[1] + n1[2] * n1[2], 1e-20f);
+        const float n22 = fmaxf(n2[0] * n2[0] + n2[1] * n2[1] + n2[2] * n2[2], 1e-20f);
+        const float pq = (b1[0] * b2[0] + b1[1] * b2[1] + b1[2] * b2[2]) / b22;
+        const float qq = (b3[0] * b2[0] + b3[1] * b2[1] + b3[2] * b2[2]) / b22;
+        const float ci = -nb2 / n11, cl = nb2 / n22;
+        // d phi / d r: role 0 -> i, 1 -> j, 2 -> k, 3 -> l
+        const float wi = role == 0 ? 1.0f : (role == 1 ? -(pq + 1.0f) : (role == 2 ? pq : 0.f));
+        const float wlc = role == 3 ? 1.0f : (role == 2 ? -(qq + 1.0f) : (role == 1 ? qq : 0.f));
+        g0 = fmaf(dEdphi, wi * ci * n1[0] + wlc * cl * n2[0], g0);
+        g1 = fmaf(dEdphi, wi * ci * n1[1] + wlc * cl * n2[1], g1);
+        g2 = fmaf(dEdphi, wi * ci * n1[2] + wlc * cl * n2[2], g2);
       }
-      const float inside = (!p.use_cutoff || r2 < p.cutoff * p.cutoff) ? 1.0f : 0.0f;
-      E += inside * e;
-      g *= inside;
-      gr[i] += g * d0; gr[i + 1] += g * d1; gr[i + 2] += g * d2;
-      gr[j] -= g * d0; gr[j + 1] -= g * d1; gr[j + 2] -= g * d2;
+      // ---- NonbondedForce: every partner j of atom a (exceptions carry their own parameters)
+      for (int j = 0; j < n; ++j) {
+        if (j == a) continue;
+        const int lo = a < j ? a : j, hi = a < j ? j : a;
+        const int t = lo * n - lo * (lo + 1) / 2 + (hi - lo - 1);
+        const float qq = pair_par[4 * t], sg = pair_par[4 * t + 1], e4 = pair_par[4 * t + 2], exc = pair_par[4 * t + 3];
+        const float d0 = xa0 - xr[3 * j], d1 = xa1 - xr[3 * j + 1], d2 = xa2 - xr[3 * j + 2];
+        const float r2 = fmaf(d0, d0, fmaf(d1, d1, d2 * d2));
+        const float ir2 = 1.0f / r2, ir = sqrtf(ir2);
+        const float s2 = sg * sg * ir2, s6 = s2 * s2 * s2;
+        float e = e4 * fmaf(s6, s6, -s6);
+        float g = e4 * (-12.0f * s6 * s6 + 6.0f * s6) * ir2;  // (dE/dr)/r
+        if (p.use_cutoff && exc == 0.f) {
+          e += qq * (ir + p.krf * r2 - p.crf);
+          g += qq * (-ir * ir2 + 2.0f * p.krf);
+        } else {
+          e += qq * ir;
+          g += -qq * ir * ir2;
+        }
+        const float inside = (!p.use_cutoff || r2 < p.cutoff * p.cutoff) ? 1.0f : 0.0f;
+        if (a < j) E += inside * e;
+        g *= inside;
+        g0 = fmaf(g, d0, g0); g1 = fmaf(g, d1, g1); g2 = fmaf(g, d2, g2);
+      }
     }
     // ---- GBSAOBCForce, OBC1 (Onufriev-Bashford-Case 2004, model I: alpha, beta, gamma = 0.8, 0, 2.909125) with the
     //      ACE surface-area term, as in OpenMM's reference algorithm: Born radii from the pairwise HCT integral,
     //      the generalised-Born pair sum (self terms included), then the chain rule through the Born radii.
     if (p.gb) {
-      float* br = bs + lane * SB;
-      float* bc = br + 64 * SB;
-      float* bf = bc + 64 * SB;
       const float rc = p.use_cutoff ? p.cutoff : 3.0e38f;
-      for (int i = 0; i < p.n; ++i) {
-        const float rho = p.gb_par[4 * i], R = p.gb_par[4 * i + 2];
+      const float rho = gb_par[4 * a], sga = gb_par[4 * a + 1], R = gb_par[4 * a + 2], qa = gb_par[4 * a + 3];
+      float chain = 0.f, Ba = 1.f;
+      if (act) {
         float sum = 0.f;
-        for (int j = 0; j < p.n; ++j) {
-          if (j == i) continue;
-          const float sg = p.gb_par[4 * j + 1];
-          const float d0 = xr[3 * i] - xr[3 * j], d1 = xr[3 * i + 1] - xr[3 * j + 1], d2 = xr[3 * i + 2] - xr[3 * j + 2];
+        for (int j = 0; j < n; ++j) {  // HCT integral of atom a
+          if (j == a) continue;
+          const float sg = gb_par[4 * j + 1];
+          const float d0 = xa0 - xr[3 * j], d1 = xa1 - xr[3 * j + 1], d2 = xa2 - xr[3 * j + 2];
           const float r = sqrtf(fmaf(d0, d0, fmaf(d1, d1, d2 * d2)));
           const float rs = r + sg, ir = 1.0f / r;
           const float l = 1.0f / fmaxf(rho, fabsf(r - sg)), u = 1.0f / rs;
@@ -166,67 +188,73 @@ __global__ void __launch_bounds__(64) ff_kernel(FfParams p) {
         }
         const float psi = 0.5f * rho * sum, psi2 = psi * psi;
         const float th = tanhf(fmaf(2.909125f * psi2, psi, 0.8f * psi));
-        const float B = 1.0f / (1.0f / rho - th / R);
-        br[i] = B;
-        bc[i] = B * B * (1.0f - th * th) * fmaf(3.0f * 2.909125f, psi2, 0.8f) * 0.5f * rho / R;  // dB / d(sum)
-        bf[i] = 0.f;
+        Ba = 1.0f / (1.0f / rho - th / R);
+        chain = Ba * Ba * (1.0f - th * th) * fmaf(3.0f * 2.909125f, psi2, 0.8f) * 0.5f * rho / R;  // dB / d(sum)
+        br[wl * n + a] = Ba;
       }
-      for (int i = 0; i < p.n; ++i) {
-        const float qi = p.gb_pf * p.gb_par[4 * i + 3], Bi = br[i], R = p.gb_par[4 * i + 2];
-        // self term and ACE surface area
-        const float rr = R + p.gb_probe, q3 = (R / Bi) * (R / Bi) * (R / Bi);
+      __syncthreads();
+      if (act) {
+        // self term and ACE surface area, then the generalised-Born pair sum
+        const float rr = R + p.gb_probe, q3 = (R / Ba) * (R / Ba) * (R / Ba);
         const float sa = p.gb_sa * rr * rr * q3 * q3;
-        const float eself = 0.5f * qi * p.gb_par[4 * i + 3] / Bi;
+        const float eself = 0.5f * p.gb_pf * qa * qa / Ba;
         E += eself + sa;
-        float bfi = -(eself + 6.0f * sa) / Bi;
-        for (int j = i + 1; j < p.n; ++j) {
-          const float c = qi * p.gb_par[4 * j + 3], Bj = br[j];
-          const float d0 = xr[3 * i] - xr[3 * j], d1 = xr[3 * i + 1] - xr[3 * j + 1], d2 = xr[3 * i + 2] - xr[3 * j + 2];
+        float bfa = -(eself + 6.0f * sa) / Ba;  // dE/dB_a
+        for (int j = 0; j < n; ++j) {
+          if (j == a) continue;
+          const float c = p.gb_pf * qa * gb_par[4 * j + 3], Bj = br[wl * n + j];
+          const float d0 = xa0 - xr[3 * j], d1 = xa1 - xr[3 * j + 1], d2 = xa2 - xr[3 * j + 2];
           const float r2 = fmaf(d0, d0, fmaf(d1, d1, d2 * d2));
-          const float a2 = Bi * Bj, Dv = r2 / (4.0f * a2), ex = expf(-Dv);
+          const float a2 = Ba * Bj, Dv = r2 / (4.0f * a2), ex = expf(-Dv);
           const float if2 = 1.0f / fmaf(a2, ex, r2), G = c * sqrtf(if2);
           const float inside = (r2 < rc * rc) ? 1.0f : 0.f;
-          E += inside * (p.use_cutoff ? G - c / p.cutoff : G);
-          const float g = inside * (-G * if2 * (1.0f - 0.25f * ex));        // (dG/dr)/r
-          const float da = inside * (-0.5f * G * if2 * ex * (1.0f + Dv));    // dG/d(Bi Bj)
-          gr[3 * i] += g * d0; gr[3 * i + 1] += g * d1; gr[3 * i + 2] += g * d2;
-          gr[3 * j] -= g * d0; gr[3 * j + 1] -= g * d1; gr[3 * j + 2] -= g * d2;
-          bfi = fmaf(da, Bj, bfi);
-          bf[j] = fmaf(da, Bi, bf[j]);
+          if (a < j) E += inside * (p.use_cutoff ? G - c / p.cutoff : G);
+          const float g = inside * (-G * if2 * (1.0f - 0.25f * ex));           // (dG/dr)/r
+          bfa = fmaf(inside * (-0.5f * G * if2 * ex * (1.0f + Dv)), Bj, bfa);  // dG/d(Ba Bj) * Bj
+          g0 = fmaf(g, d0, g0); g1 = fmaf(g, d1, g1); g2 = fmaf(g, d2, g2);
         }
-        bf[i] += bfi;
+        bw[wl * n + a] = bfa * chain;  // dE / d(sum_a)
       }
-      for (int i = 0; i < p.n; ++i) {
-        const float rho = p.gb_par[4 * i];
-        const float wi = bf[i] * bc[i];  // dE / d(sum_i)
-        for (int j = 0; j < p.n; ++j) {
-          if (j == i) continue;
-          const float sg = p.gb_par[4 * j + 1];
-          const float d0 = xr[3 * i] - xr[3 * j], d1 = xr[3 * i + 1] - xr[3 * j + 1], d2 = xr[3 * i + 2] - xr[3 * j + 2];
-          const float r = sqrtf(fmaf(d0, d0, fmaf(d1, d1, d2 * d2)));
-          const float rs = r + sg, ir = 1.0f / r, dl = r - sg;
-          const float l = 1.0f / fmaxf(rho, fabsf(dl)), u = 1.0f / rs;
-          const float l2 = l * l, u2 = u * u, u3 = u2 * u;
-          const float lp = (fabsf(dl) > rho) ? (dl > 0.f ? -l2 : l2) : 0.f;  // dl/dr
-          const float lg = logf(u / l);
-          float dt = lp + u2 + 0.25f * (u2 - l2) - 0.5f * r * fmaf(l, lp, u3) - 0.5f * lg * ir * ir -
-                     0.5f * ir * (u + lp / l) - 0.25f * sg * sg * (l2 - u2) * ir * ir + 0.5f * sg * sg * ir * fmaf(l, lp, u3);
-          if (rho < sg - r) dt -= 2.0f * lp;
-          const float g = (rho < rs && r < rc) ? wi * dt * ir : 0.f;
-          gr[3 * i] += g * d0; gr[3 * i + 1] += g * d1; gr[3 * i + 2] += g * d2;
-          gr[3 * j] -= g * d0; gr[3 * j + 1] -= g * d1; gr[3 * j + 2] -= g * d2;
+      __syncthreads();
+      if (act) {
+        const float wa = bw[wl * n + a];
+        for (int j = 0; j < n; ++j) {  // chain rule through the Born radii of a (descreened by j) and of j (by a)
+          if (j == a) continue;
+          const float rhoj = gb_par[4 * j], sgj = gb_par[4 * j + 1], wj = bw[wl * n + j];
+          const float d0 = xa0 - xr[3 * j], d1 = xa1 - xr[3 * j + 1], d2 = xa2 - xr[3 * j + 2];
+          const float r = sqrtf(fmaf(d0, d0, fmaf(d1, d1, d2 * d2))), ir = 1.0f / r;
+          float acc = 0.f;
+#pragma unroll
+          for (int side = 0; side < 2; ++side) {
+            const float ro = side ? rhoj : rho, sg = side ? sga : sgj, w = side ? wj : wa;
+            const float rs = r + sg, dl = r - sg;
+            const float l = 1.0f / fmaxf(ro, fabsf(dl)), u = 1.0f / rs;
+            const float l2 = l * l, u2 = u * u, u3 = u2 * u;
+            const float lp = (fabsf(dl) > ro) ? (dl > 0.f ? -l2 : l2) : 0.f;  // dl/dr
+            const float lg = logf(u / l);
+            float dt = lp + u2 + 0.25f * (u2 - l2) - 0.5f * r * fmaf(l, lp, u3) - 0.5f * lg * ir * ir -
+                       0.5f * ir * (u + lp / l) - 0.25f * sg * sg * (l2 - u2) * ir * ir + 0.5f * sg * sg * ir * fmaf(l, lp, u3);
+            if (ro < sg - r) dt -= 2.0f * lp;
+            acc += (ro < rs && r < rc) ? w * dt : 0.f;
+          }
+          const float g = acc * ir;
+          g0 = fmaf(g, d0, g0); g1 = fmaf(g, d1, g1); g2 = fmaf(g, d2, g2);
         }
       }
     }
-    if (lane < nw) p.logp[w0 + lane] = -E * p.inv_kT;
-    __syncthreads();
-    if (p.force) {
+    if (act) {
       const float sc = -p.inv_kT * p.length_scale;  // d logp / d x_model
-      for (int q = lane; q < nw * D; q += 64) {
-        const int w = q / D, c = q - w * D;
-        p.force[w0 * D + q] = sc * gs[w * S + c];
-      }
+      gs[wl * D + 3 * a] = sc * g0; gs[wl * D + 3 * a + 1] = sc * g1; gs[wl * D + 3 * a + 2] = sc * g2;
+      es[wl * n + a] = E;
     }
+    __syncthreads();
+    if (act && a == 0) {
+      float tot = 0.f;
+      for (int q = 0; q < n; ++q) tot += es[wl * n + q];
+      p.logp[w0 + wl] = -tot * p.inv_kT;
+    }
+    if (p.force)
+      for (int q = tid; q < nw * D; q += FF_THREADS) p.force[w0 * D + q] = gs[q];
     __syncthreads();
   }
 }
@@ -242,7 +270,7 @@ using namespace pita;
 
 extern "C" int pita_ff_create(pita_ff_t** out, const pita_ff_config* c) {
   PITA_REQUIRE(out && c, "pita_ff_create: null argument");
-  PITA_REQUIRE(c->n_atoms >= 2 && c->n_atoms <= 40, "pita_ff_create: n_atoms must be in [2,40] (LDS rows of 64 walkers)");
+  PITA_REQUIRE(c->n_atoms >= 2 && c->n_atoms <= 40, "pita_ff_create: n_atoms must be in [2,40]");
   PITA_REQUIRE(c->charge && c->sigma && c->epsilon, "pita_ff_create: per-atom nonbonded parameters missing");
   PITA_REQUIRE(c->kT > 0.f && c->length_scale > 0.f, "pita_ff_create: kT and length_scale must be > 0");
   PITA_REQUIRE((c->n_bonds == 0 || (c->bond_idx && c->bond_par)) && (c->n_angles == 0 || (c->angle_idx && c->angle_par)) &&
@@ -297,7 +325,26 @@ extern "C" int pita_ff_create(pita_ff_t** out, const pita_ff_config* c) {
     gpar[4 * i + 3] = c->charge[i];
   }
   const size_t b_gb = gb ? sizeof(float) * 4 * n : 0;
-  const size_t total = b_bi + b_bp + b_ai + b_ap + b_ti + b_tp + b_pi + b_pp + b_gb + 16 * 9;  // each table padded to 16 B
+  // per-atom interaction lists
+  const int n_ent = 2 * c->n_bonds + 3 * c->n_angles + 4 * c->n_torsions;
+  int* csr_off = new int[3 * (n + 1)];
+  int* csr_ent = new int[n_ent > 0 ? n_ent : 1];
+  {
+    int pos = 0;
+    const int* idx[3] = {c->bond_idx, c->angle_idx, c->tors_idx};
+    const int cnt[3] = {c->n_bonds, c->n_angles, c->n_torsions}, arity[3] = {2, 3, 4};
+    for (int kind = 0; kind < 3; ++kind) {
+      for (int a = 0; a < n; ++a) {
+        csr_off[kind * (n + 1) + a] = pos;
+        for (int tt = 0; tt < cnt[kind]; ++tt)
+          for (int role = 0; role < arity[kind]; ++role)
+            if (idx[kind][arity[kind] * tt + role] == a) csr_ent[pos++] = (tt << 2) | role;
+      }
+      csr_off[kind * (n + 1) + n] = pos;
+    }
+  }
+  const size_t b_co = sizeof(int) * 3 * (n + 1), b_ce = sizeof(int) * (n_ent > 0 ? n_ent : 1);
+  const size_t total = b_bi + b_bp + b_ai + b_ap + b_ti + b_tp + b_pi + b_pp + b_gb + b_co + b_ce + 16 * 11;  // each table padded to 16 B
   pita_ff* ff = new pita_ff();
   hipError_t e = hipMalloc(&ff->d_all, total);
   char* base = static_cast<char*>(ff->d_all);
@@ -309,16 +356,22 @@ extern "C" int pita_ff_create(pita_ff_t** out, const pita_ff_config* c) {
     return dst;
   };
   FfParams& p = ff->p;
+  auto word_off = [&](const void* q) { return (int)((static_cast<const char*>(q) - base) / 4); };
   if (e == hipSuccess) {
-    p.bond_idx = (const int*)put(c->bond_idx, b_bi); p.bond_par = (const float*)put(c->bond_par, b_bp);
-    p.angle_idx = (const int*)put(c->angle_idx, b_ai); p.angle_par = (const float*)put(c->angle_par, b_ap);
-    p.tors_idx = (const int*)put(c->tors_idx, b_ti); p.tors_par = (const float*)put(c->tors_par, b_tp);
-    p.pair_idx = (const int*)put(pidx, b_pi); p.pair_par = (const float*)put(ppar, b_pp);
-    p.gb_par = (const float*)put(gpar, b_gb);
+    p.o_bond_idx = word_off(put(c->bond_idx, b_bi)); p.o_bond_par = word_off(put(c->bond_par, b_bp));
+    p.o_angle_idx = word_off(put(c->angle_idx, b_ai)); p.o_angle_par = word_off(put(c->angle_par, b_ap));
+    p.o_tors_idx = word_off(put(c->tors_idx, b_ti)); p.o_tors_par = word_off(put(c->tors_par, b_tp));
+    p.o_pair_idx = word_off(put(pidx, b_pi)); p.o_pair_par = word_off(put(ppar, b_pp));
+    p.o_gb_par = word_off(put(gpar, b_gb));
+    p.o_csr_off = word_off(put(csr_off, b_co)); p.o_csr_ent = word_off(put(csr_ent, b_ce));
+    p.blob = reinterpret_cast<const unsigned*>(base);
+    p.blob_words = (int)(off / 4);
   }
   delete[] pidx;
   delete[] ppar;
   delete[] gpar;
+  delete[] csr_off;
+  delete[] csr_ent;
   if (e != hipSuccess) {
     (void)hipFree(ff->d_all);
     delete ff;
@@ -356,10 +409,12 @@ extern "C" int pita_ff_logp_force(pita_ff_t* ff, const float* x, float* logp, fl
   PITA_REQUIRE(x && logp, "pita_ff_logp_force: null argument");
   FfParams p = ff->p;
   p.x = x; p.logp = logp; p.force = force; p.B = B;
-  const int S = (3 * p.n) | 1, SB = p.n | 1;
-  const size_t lds = sizeof(float) * (2 * 64 * S + (p.gb ? 3 * 64 * SB : 0));
-  const long long nblk = (B + 63) / 64;
-  hipLaunchKernelGGL(ff_kernel, dim3((unsigned)(nblk < 8192 ? nblk : 8192)), dim3(64), lds, (hipStream_t)stream, p);
+  const int WPB = FF_THREADS / p.n;
+  const size_t lds = sizeof(float) * ((size_t)p.blob_words + (size_t)WPB * (2 * 3 * p.n + 3 * p.n));
+  PITA_REQUIRE(lds <= 64 * 1024, "pita_ff_logp_force: interaction tables do not fit in LDS");
+  const long long nblk = (B + WPB - 1) / WPB;
+  const long long cap = 256LL * 8;  // persistent blocks: the tables are staged once per block
+  hipLaunchKernelGGL(ff_kernel, dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(FF_THREADS), lds, (hipStream_t)stream, p);
   PITA_LAUNCH_CHECK();
   return PITA_OK;
 }
