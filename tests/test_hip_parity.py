@@ -639,6 +639,50 @@ def test_forcefield_vs_oracle(pa, cutoff, gb):
     assert abs(f.reshape(B, 22, 3).sum(1)).max() < 1e-3 * f.abs().max().item()  # translation invariance
 
 
+def test_final_histograms_match_oracle_sampler(pa, golden):
+    """Distribution-level parity of the whole sampler with its OWN noise (Philox): the final interatomic-distance and
+    energy histograms of the HIP run must be as close to an oracle run (torch noise, fp32 CPU) as two oracle runs with
+    different seeds are to each other (1-D Wasserstein-2; 4x margin).  LJ13, EGNN h32x3, 40 steps from the prior."""
+    w = golden("egnn_weights_trainedlike.npz")
+    wt = {k: T(v) for k, v in w.items()}
+    N, B = 40, 1024
+    bb = lambda cn, xs, b: O.egnn_forward(wt, cn, xs, b, 13, 3)
+    osched, ogam = O.Elucidating(0.05, 80.0, 7), O.GammaConstant(4 / 3)
+    cfg = O.IntegratorConfig(num_integration_steps=N, start_resampling_step=0, end_resampling_step=N, resampling_interval=-1)
+    scale = 80.0 / np.sqrt(4 / 3)
+    iu = np.triu_indices(13, 1)
+
+    def stats(x):
+        x = x.detach().cpu().float()
+        d = (x.reshape(-1, 13, 1, 3) - x.reshape(-1, 1, 13, 3)).norm(dim=-1)[:, iu[0], iu[1]].reshape(-1).numpy()
+        le = np.log10(-O.lj_logp(x, 13, 3).numpy())  # energies span 8 decades with these weights: compare in log
+        return d, le
+
+    ref = []
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(min(16, nthreads))  # small ops: more threads only add overhead on a 256-thread host
+    for seed in (1, 2):
+        gen = torch.Generator().manual_seed(seed)
+        x1 = O.remove_mean(torch.randn(B, 39, generator=gen) * scale, 13, 3)
+        out = O.integrate_sde(cfg, x1, lambda t, xc: O.f_not_debiased(bb, osched, ogam, t, xc, 1.0), osched.g,
+                              lambda i, shp: torch.randn(shp, generator=gen), 13, 3)
+        ref.append(stats(out["x"]))
+    torch.set_num_threads(nthreads)
+    net = make_net(pa, 13, 3, w)
+    sde = pa.VEReverseSDE(noise_schedule=pa.ElucidatingNoiseSchedule(sigma_min=0.05, sigma_max=80.0, rho=7),
+                          score_net=pa.ScoreNet(net), debias_inference=False)
+    integ = pa.WeightedSDEIntegrator(sde=sde, num_integration_steps=N, start_resampling_step=0, end_resampling_step=N,
+                                     resampling_interval=-1, num_negative_time_steps=0, post_mcmc_steps=0, seed=77)
+    x1 = pa.Prior(scale=scale, n_particles=13, spatial_dim=3, seed=5).sample(B)
+    x, _, _, _, _ = integ.integrate_sde(x1, pa.LennardJonesEnergy(39, 13, 3), pa.ConstantAnnealingFactorSchedule(4 / 3),
+                                        inverse_temperature=1.0)
+    got = stats(x)
+    for k, name in enumerate(("interatomic distance", "log10 energy")):
+        seed_to_seed = O.w2_1d(ref[0][k], ref[1][k])
+        hip_to_ref = max(O.w2_1d(got[k], ref[0][k]), O.w2_1d(got[k], ref[1][k]))
+        assert hip_to_ref < 4 * seed_to_seed + 1e-3 * float(np.abs(ref[0][k]).mean()), (name, hip_to_ref, seed_to_seed)
+
+
 @pytest.mark.parametrize("start,end,interval", [(0, 12, -1), (3, 12, -1), (2, 9, 3), (0, 12, 1), (5, 7, 2)])
 def test_integrator_window_and_resampling_semantics(pa, golden, start, end, interval):
     """A2 gates (sde_integration.py:278-297): walkers frozen before start_resampling_step, resampling events only
