@@ -175,6 +175,14 @@ int pita_egnn_jvp(pita_egnn_t* net, const float* h, const float* x, const float*
 int pita_egnn_vjp(pita_egnn_t* net, const float* h, const float* x, const float* beta, const float* cot /*nullable*/,
                   float* out /*nullable*/, float* vjp, int64_t B, void* stream);
 
+/* Exact trace of the denoiser Jacobian, K unit directions per launch sharing one primal evaluation:
+ *   diag_acc[b] += sum_{k < ndir} (J_x D(h, x) e_{dir0+k})_{dir0+k},   1 <= ndir <= pita_egnn_div_directions(net).
+ * Looping dir0 over 0, K, 2K, ... < D accumulates trace(J_x D), from which div_x s_theta = (trace - D)/h: the exact
+ * divergence the reference computes with vmap(jacrev) (pita/src/models/components/utils.py:30-51). */
+int pita_egnn_div_directions(const pita_egnn_t* net);
+int pita_egnn_div_accumulate(pita_egnn_t* net, const float* h, const float* x, const float* beta, int dir0, int ndir,
+                             float* diag_acc, int64_t B, void* stream);
+
 /* Feynman-Kac drift assembly per walker from those reductions (replaces the torch/autograd expressions of
  * sdes.py:157-227): with E = (1+c_s)|x|^2/(2h) - <D_E,x>/h,
  *   grad E = ((1+c_s) x - D_E - jtx_E)/h,  b = (D_S - x)/h * g2/2,  drift_X = gamma (-grad E) g2/2 + gamma b,

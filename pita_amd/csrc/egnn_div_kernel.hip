@@ -1,0 +1,407 @@
+// Exact divergence of the EDM-preconditioned EGNN denoiser for gfx950: K unit tangent directions per launch sharing
+// ONE primal evaluation.
+//
+// The debiased (Feynman-Kac) weights of the reference sampler (pita/src/models/components/sdes.py:151-239) need
+// div_x s_theta = (trace(J_x D) - dim) / h, which the reference computes exactly with vmap(jacrev)
+// (pita/src/models/components/utils.py:30-51).  trace(J_x D) = sum_d (J_x D e_d)_d takes dim forward-mode passes;
+// pita_egnn_jvp spends half of every pass recomputing the primal network.  This kernel pushes K directions
+// e_{dir0}, ..., e_{dir0+K-1} through the network together: per edge the primal MLP (activations and their derivative
+// factors) is evaluated once and the K tangent chains -- independent MFMA chains, so they also give the single wave
+// per SIMD the instruction-level parallelism it lacks in the one-direction kernel -- reuse it.  Output:
+// diag_acc[b] += sum_k (J_x D e_{dir0+k})_{dir0+k}.
+//
+// Mapping: as egnn_jvp_kernel.hip (wave = G walkers = dense 32-column tiles, lane = column x 16 features, exact 3-way
+// bf16 split on the matrix pipe, tangents in the lane/register position of their primals); one wave per SIMD.
+#include "egnn_common.h"
+
+namespace pita {
+
+struct DivParams {
+  const unsigned* mats16;
+  const float* vecs;
+  int n_layers, in_nf, attention, tanh_on, feature_layout;
+  float coord_scale;
+  long long B;
+  const float* h;     // [B] sigma^2
+  const float* x;     // [B, D]
+  const float* beta;  // [B] or null
+  int dir0, ndir;     // unit directions dir0 .. dir0 + ndir - 1 (ndir <= K)
+  float* diag_acc;    // [B] += sum_k dD_k[b, dir0 + k]
+};
+
+template <int N, int DIM, int G, int WAVES, int K>
+struct DivCfg {
+  static constexpr int NCOL = G * N;
+  static constexpr int NT = (NCOL + 31) / 32;
+  static constexpr int NCOLP = NT * 32;
+  static constexpr int PB_F = NCOLP * PBS;
+  static constexpr int POS_F = NCOLP * DIM;
+  // PB, dPB[K]; pos[2], pos0; dpos[K][2], dpos0[K]
+  static constexpr int WAVE_F = (1 + K) * PB_F + 3 * POS_F + 3 * K * POS_F;
+  static __host__ __device__ constexpr int vec_f(int L) { return ((VEC_EMB_F + L * VEC_LAYER_F) + 3) & ~3; }
+  static __host__ __device__ constexpr size_t lds_bytes(int L) {
+    return sizeof(float) * (size_t)(vec_f(L) + WAVES * WAVE_F);
+  }
+};
+
+__device__ __forceinline__ void silu_dsilu2(float v, float& y, float& g) {
+  const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v));
+  y = v * s;
+  g = s * fmaf(v * (1.0f / SILU_PRESCALE), 1.0f - s, 1.0f);
+}
+
+template <int N, int DIM, int G, int WAVES, int K>
+__global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_kernel(DivParams p) {
+  using C = DivCfg<N, DIM, G, WAVES, K>;
+  constexpr int NT = C::NT;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int L = p.n_layers;
+  const int vec_f = C::vec_f(L);
+  for (int i = threadIdx.x; i < VEC_EMB_F + L * VEC_LAYER_F; i += WAVES * 64) lds[i] = p.vecs[i];
+  __syncthreads();
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cl = lane & 31, hh = lane >> 5;
+  float* PB = lds + vec_f + wave * C::WAVE_F;
+  float* dPB = PB + C::PB_F;                       // [K][PB_F]
+  float* posb = dPB + K * C::PB_F;                 // [2][POS_F]
+  float* pos0 = posb + 2 * C::POS_F;
+  float* dposb = pos0 + C::POS_F;                  // [K][2][POS_F]
+  float* dpos0 = dposb + 2 * K * C::POS_F;         // [K][POS_F]
+  const float* vemb = lds;
+  const f32x16 zero16 = {0};
+
+  const long long total_waves = (long long)gridDim.x * WAVES;
+  const long long quota = (p.B + total_waves - 1) / total_waves;
+  const long long wbeg = ((long long)blockIdx.x * WAVES + wave) * quota;
+  const long long wend = (wbeg + quota < p.B) ? wbeg + quota : p.B;
+  for (long long walker0 = wbeg; walker0 < wend; walker0 += G) {
+    const int nwalk = (int)((wend - walker0) < G ? (wend - walker0) : G);
+    const int ncol = nwalk * N;
+    const int ntile = (ncol + 31) >> 5;
+    int col[NT], nodei[NT];
+    bool valid[NT];
+    float c_s[NT], c_in[NT], c_out[NT];
+    float posi[NT][DIM], p0i[NT][DIM], dposi[NT][K][DIM], dp0i[NT][K][DIM];
+    f32x16 hf[NT], dhf[NT][K];
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+      col[T] = T * 32 + cl;
+      const int w = col[T] / N;
+      nodei[T] = col[T] - w * N;
+      valid[T] = col[T] < ncol;
+      const long long wid = valid[T] ? walker0 + w : p.B - 1;
+      const float hv = p.h[wid];
+      const float bet = p.beta ? p.beta[wid] : 0.f;
+      const float op = 1.0f + hv, rs = 1.0f / sqrtf(op);
+      c_s[T] = 1.0f / op;
+      c_in[T] = rs;
+      c_out[T] = sqrtf(hv) * rs;
+      const float tfeat = 0.125f * logf(hv);
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) {
+        const long long gi = (walker0 * N + col[T]) * DIM + k;
+        const float xv = valid[T] ? p.x[gi] : 0.f;
+        posi[T][k] = c_in[T] * xv;
+        p0i[T][k] = posi[T][k];
+        if (hh == 0) {
+          pos0[col[T] * DIM + k] = posi[T][k];
+          posb[col[T] * DIM + k] = posi[T][k];
+        }
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+          const float v = (valid[T] && q < p.ndir && nodei[T] * DIM + k == p.dir0 + q) ? c_in[T] : 0.f;  // d(c_in x)
+          dposi[T][q][k] = v;
+          dp0i[T][q][k] = v;
+          if (hh == 0) {
+            dpos0[q * C::POS_F + col[T] * DIM + k] = v;
+            dposb[(2 * q) * C::POS_F + col[T] * DIM + k] = v;
+          }
+        }
+      }
+      float a0, a1;
+      if (p.in_nf == 1) { a0 = tfeat; a1 = 0.f; }
+      else if (p.feature_layout == 0) {
+        a0 = (2 * nodei[T] < N) ? tfeat : bet;
+        a1 = (2 * nodei[T] + 1 < N) ? tfeat : bet;
+      } else { a0 = tfeat; a1 = bet; }
+      const f32x16 w0 = lds_vec16(vemb + hh * 16), w1 = lds_vec16(vemb + 32 + hh * 16), eb = lds_vec16(vemb + 64 + hh * 16);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hf[T][r] = fmaf(w0[r], a0, fmaf(w1[r], a1, eb[r]));
+#pragma unroll
+      for (int q = 0; q < K; ++q) dhf[T][q] = zero16;  // node features do not depend on x
+    }
+    wave_lds_fence();
+
+    int cur = 0;
+    for (int l = 0; l < L; ++l) {
+      const unsigned* mats16 = p.mats16 + (size_t)l * M_COUNT * MAT_W;
+      const float* vl = lds + VEC_EMB_F + l * VEC_LAYER_F + hh * 16;
+      const bool last = (l == L - 1);
+      const float* poscur = posb + cur * C::POS_F;
+      {
+        WFrag<1> wb;
+        wb.load(nullptr, mats16, M_WB, lane);
+#pragma unroll
+        for (int T = 0; T < NT; ++T) {
+          if (T >= ntile) continue;
+          const f32x16 pb = wb.mul(hf[T], zero16);
+          f32x4* dst = reinterpret_cast<f32x4*>(PB + col[T] * PBS + hh * 16);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dst[q] = f32x4{pb[4 * q], pb[4 * q + 1], pb[4 * q + 2], pb[4 * q + 3]};
+#pragma unroll
+          for (int d = 0; d < K; ++d) {
+            f32x16 dpb = zero16;
+            if (l > 0) dpb = wb.mul(dhf[T][d], zero16);  // dh = 0 in the first layer
+            f32x4* ddst = reinterpret_cast<f32x4*>(dPB + d * C::PB_F + col[T] * PBS + hh * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ddst[q] = f32x4{dpb[4 * q], dpb[4 * q + 1], dpb[4 * q + 2], dpb[4 * q + 3]};
+          }
+        }
+      }
+      wave_lds_fence();
+      WFrag<1> w2f, wc1f;
+      w2f.load(nullptr, mats16, M_W2, lane);
+      wc1f.load(nullptr, mats16, M_WC1, lane);
+      const float a_re = lds[VEC_EMB_F + l * VEC_LAYER_F + V_WRE * EH + lane];
+      const float b_att = lds[VEC_EMB_F + l * VEC_LAYER_F + V_COUNT * EH];
+#pragma unroll
+      for (int T = 0; T < NT; ++T) {
+        if (T >= ntile) continue;
+        f32x16 Ai, dAi[K];
+        {
+          WFrag<1> wa;
+          wa.load(nullptr, mats16, M_WA, lane);
+          Ai = wa.mul(hf[T], lds_vec16(vl + V_B1 * EH));
+#pragma unroll
+          for (int d = 0; d < K; ++d) dAi[d] = (l > 0) ? wa.mul(dhf[T][d], zero16) : zero16;
+        }
+        f32x16 agg = {0}, dagg[K];
+        float xacc[DIM], dxacc[K][DIM];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) xacc[k] = 0.f;
+#pragma unroll
+        for (int d = 0; d < K; ++d) {
+          dagg[d] = zero16;
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) dxacc[d][k] = 0.f;
+        }
+        const int cbase = col[T] - nodei[T];
+        for (int dd = 1; dd < N; ++dd) {
+          asm volatile("" ::: "memory");
+          int j = nodei[T] + dd;
+          j = (j >= N) ? j - N : j;
+          const int cj = (col[T] < ncol) ? cbase + j : col[T];
+          float df[DIM], e0[DIM], radial = 0.f, ea = 0.f;
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) {
+            df[k] = posi[T][k] - poscur[cj * DIM + k];
+            radial = fmaf(df[k], df[k], radial);
+            e0[k] = p0i[T][k] - pos0[cj * DIM + k];
+            ea = fmaf(e0[k], e0[k], ea);
+          }
+          // ---- primal edge MLP with derivative factors (once for all K directions)
+          f32x16 z = Ai + lds_vec16(PB + cj * PBS + hh * 16);
+          z = __builtin_amdgcn_mfma_f32_32x32x2f32(a_re, hh ? ea : radial, z, 0, 0, 0);
+          f32x16 g1, g2, gc, m2, m;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { float y, g; silu_dsilu2(z[r], y, g); z[r] = y; g1[r] = g; }
+          z = w2f.mul(z, lds_vec16(vl + V_B2 * EH));
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { float y, g; silu_dsilu2(z[r], y, g); m2[r] = y; g2[r] = g; }
+          float att = 1.0f;
+          m = m2;
+          const f32x16 v_watt = lds_vec16(vl + V_WATT * EH);
+          if (p.attention) {
+            att = fast_sigmoid(xhalf_sum(dot16(v_watt, m2)) + b_att);
+            m *= att;
+          }
+          if (!last) agg += m;
+          z = wc1f.mul(m, lds_vec16(vl + V_BC1 * EH));
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { float y, g; silu_dsilu2(z[r], y, g); z[r] = y; gc[r] = g; }
+          const f32x16 v_wc2 = lds_vec16(vl + V_WC2 * EH);
+          float cs = xhalf_sum(dot16(v_wc2, z)), dcs_f = 1.0f;
+          if (p.tanh_on) {
+            const float th = accurate_tanh(cs);
+            dcs_f = p.coord_scale * fmaf(-th, th, 1.0f);
+            cs = th * p.coord_scale;
+          }
+          const float sq = sqrtf(radial + 1e-8f), inv = 1.0f / (sq + 1.0f), hsq = 0.5f / sq;
+          float u[DIM];
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) {
+            u[k] = df[k] * inv;
+            xacc[k] = fmaf(u[k], cs, xacc[k]);
+          }
+          // ---- K tangent chains
+#pragma unroll
+          for (int d = 0; d < K; ++d) {
+            const float* dposcur = dposb + (2 * d + cur) * C::POS_F;
+            float ddf[DIM], dradial = 0.f, dea = 0.f;
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+              ddf[k] = dposi[T][d][k] - dposcur[cj * DIM + k];
+              dradial = fmaf(df[k], ddf[k], dradial);
+              dea = fmaf(e0[k], dp0i[T][d][k] - dpos0[d * C::POS_F + cj * DIM + k], dea);
+            }
+            dradial *= 2.0f;
+            dea *= 2.0f;
+            f32x16 dz = dAi[d] + lds_vec16(dPB + d * C::PB_F + cj * PBS + hh * 16);
+            dz = __builtin_amdgcn_mfma_f32_32x32x2f32(a_re, hh ? dea : dradial, dz, 0, 0, 0);
+            dz *= g1;
+            dz = w2f.mul(dz, zero16);
+            dz *= g2;  // dm2
+            if (p.attention) {
+              const float datt = att * (1.0f - att) * xhalf_sum(dot16(v_watt, dz));
+#pragma unroll
+              for (int r = 0; r < 16; ++r) dz[r] = fmaf(datt, m2[r], att * dz[r]);
+            }
+            if (!last) dagg[d] += dz;
+            dz = wc1f.mul(dz, zero16);
+            dz *= gc;
+            const float dcs = dcs_f * xhalf_sum(dot16(v_wc2, dz));
+            const float dnrm = dradial * hsq;
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+              const float du = (ddf[k] - u[k] * dnrm) * inv;
+              dxacc[d][k] = fmaf(du, cs, fmaf(u[k], dcs, dxacc[d][k]));
+            }
+          }
+        }
+        float* posnext = posb + (cur ^ 1) * C::POS_F;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          posi[T][k] += xacc[k];
+          if (hh == 0) posnext[col[T] * DIM + k] = posi[T][k];
+#pragma unroll
+          for (int d = 0; d < K; ++d) {
+            dposi[T][d][k] += dxacc[d][k];
+            if (hh == 0) dposb[(2 * d + (cur ^ 1)) * C::POS_F + col[T] * DIM + k] = dposi[T][d][k];
+          }
+        }
+        if (!last) {
+          WFrag<1> wn;
+          wn.load(nullptr, mats16, M_WN1A, lane);
+          f32x16 zn = wn.mul(hf[T], lds_vec16(vl + V_BN1 * EH));
+          f32x16 dzn[K];
+#pragma unroll
+          for (int d = 0; d < K; ++d) dzn[d] = (l > 0) ? wn.mul(dhf[T][d], zero16) : zero16;
+          wn.load(nullptr, mats16, M_WN1B, lane);
+          zn = wn.mul(agg, zn);
+#pragma unroll
+          for (int d = 0; d < K; ++d) dzn[d] = wn.mul(dagg[d], dzn[d]);
+          f32x16 gn;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { float y, g; silu_dsilu2(zn[r], y, g); zn[r] = y; gn[r] = g; }
+          wn.load(nullptr, mats16, M_WN2, lane);
+          hf[T] += wn.mul(zn, lds_vec16(vl + V_BN2 * EH));
+#pragma unroll
+          for (int d = 0; d < K; ++d) {
+            dzn[d] *= gn;
+            dhf[T][d] += wn.mul(dzn[d], zero16);
+          }
+        }
+      }
+      wave_lds_fence();
+      cur ^= 1;
+    }
+
+    // dD = c_s e_d + c_out (dF - mean dF);  only the component [dir] of each direction is needed
+    float* dscr = dPB;  // [K][NCOLP*DIM] scratch (dPB is free now)
+#pragma unroll
+    for (int T = 0; T < NT; ++T)
+#pragma unroll
+      for (int d = 0; d < K; ++d)
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          dposi[T][d][k] -= dp0i[T][d][k];  // dF
+          if (hh == 0) dscr[d * C::POS_F + col[T] * DIM + k] = dposi[T][d][k];
+        }
+    wave_lds_fence();
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+      const int cb = (col[T] < ncol) ? col[T] - nodei[T] : 0;
+#pragma unroll
+      for (int d = 0; d < K; ++d)
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          if (!(valid[T] && hh == 0 && d < p.ndir && nodei[T] * DIM + k == p.dir0 + d)) continue;
+          float ds = 0.f;
+          for (int q = 0; q < N; ++q) ds += dscr[d * C::POS_F + (cb + q) * DIM + k];
+          const float dF = dposi[T][d][k] - ds / (float)N;
+          // the K owners of one walker are different lanes: the read-modify-writes below would race
+          atomicAdd(&p.diag_acc[walker0 + col[T] / N], fmaf(c_out[T], dF, c_s[T]));
+        }
+    }
+    wave_lds_fence();
+  }
+}
+
+struct DivShape {
+  int n, dim, G, waves, K;
+  void (*kernel)(DivParams);
+  size_t (*lds_bytes)(int);
+};
+template <int N, int DIM, int G, int WAVES, int K>
+static size_t div_lds_bytes_of(int L) { return DivCfg<N, DIM, G, WAVES, K>::lds_bytes(L); }
+#define PITA_DIV_SHAPE(N, DIM, G, WAVES, K) \
+  DivShape { N, DIM, G, WAVES, K, egnn_div_kernel<N, DIM, G, WAVES, K>, div_lds_bytes_of<N, DIM, G, WAVES, K> }
+static const DivShape kDivShapes[] = {
+    PITA_DIV_SHAPE(4, 2, 8, 4, 4),
+    PITA_DIV_SHAPE(13, 3, 2, 4, 3),
+    PITA_DIV_SHAPE(22, 3, 1, 4, 3),
+    PITA_DIV_SHAPE(55, 3, 1, 4, 1),
+};
+// measured for LJ13 at 65 536 walkers, all 39 directions: K = 2: 117.9 ms, K = 3: 100.6 ms, K = 4: 102.8 ms (more
+// spilling), 39 single-direction JVP launches: 126 ms.  PITA_DIV_K selects an alternative for experiments.
+static const DivShape kDivAlt[] = {PITA_DIV_SHAPE(13, 3, 2, 4, 2), PITA_DIV_SHAPE(13, 3, 2, 4, 4)};
+static const DivShape* find_div_shape(int n, int dim) {
+  static const int altk = getenv("PITA_DIV_K") ? atoi(getenv("PITA_DIV_K")) : 0;
+  if (altk)
+    for (const auto& c : kDivAlt)
+      if (c.n == n && c.dim == dim && c.K == altk) return &c;
+  for (const auto& c : kDivShapes)
+    if (c.n == n && c.dim == dim) return &c;
+  return nullptr;
+}
+
+}  // namespace pita
+
+using namespace pita;
+
+extern "C" int pita_egnn_div_directions(const pita_egnn_t* net) {
+  if (!net) return PITA_EINVAL;
+  const DivShape* s = find_div_shape(net->cfg.n_particles, net->cfg.n_dim);
+  return s ? s->K : PITA_EUNSUPPORTED;
+}
+
+extern "C" int pita_egnn_div_accumulate(pita_egnn_t* net, const float* h, const float* x, const float* beta, int dir0,
+                                        int ndir, float* diag_acc, int64_t B, void* stream) {
+  PITA_REQUIRE(net && B >= 0, "pita_egnn_div_accumulate: bad argument");
+  if (B == 0) return PITA_OK;
+  PITA_REQUIRE(h && x && diag_acc, "pita_egnn_div_accumulate: null argument");
+  PITA_REQUIRE(beta || net->cfg.in_node_nf == 1, "pita_egnn_div_accumulate: beta required for in_node_nf=2");
+  const int D = net->cfg.n_particles * net->cfg.n_dim;
+  const DivShape* s = find_div_shape(net->cfg.n_particles, net->cfg.n_dim);
+  if (!s) return fail(PITA_EUNSUPPORTED, "pita_egnn_div_accumulate: no kernel for this particle system");
+  PITA_REQUIRE(dir0 >= 0 && ndir >= 1 && ndir <= s->K && dir0 + ndir <= D, "pita_egnn_div_accumulate: directions out of range");
+  DivParams p{};
+  p.mats16 = net->d_mats16; p.vecs = net->d_vecs; p.n_layers = net->cfg.n_layers; p.in_nf = net->cfg.in_node_nf;
+  p.attention = net->cfg.attention; p.tanh_on = net->cfg.tanh; p.feature_layout = net->cfg.feature_layout;
+  p.coord_scale = net->cfg.coords_range / (float)net->cfg.n_layers;
+  p.B = B; p.h = h; p.x = x; p.beta = beta; p.dir0 = dir0; p.ndir = ndir; p.diag_acc = diag_acc;
+  const size_t lds = s->lds_bytes(p.n_layers);
+  static thread_local const void* configured = nullptr;
+  if (configured != (const void*)s->kernel) {
+    PITA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(s->kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = (const void*)s->kernel;
+  }
+  const long long ngroups = (B + s->G - 1) / s->G;
+  long long want = (ngroups + s->waves - 1) / s->waves;
+  const long long cap = net->n_cu;  // one 4-wave block per CU (one wave per SIMD)
+  const unsigned grid = (unsigned)(want < cap ? want : cap);
+  hipLaunchKernelGGL(s->kernel, dim3(grid), dim3(s->waves * 64), lds, (hipStream_t)stream, p);
+  PITA_LAUNCH_CHECK();
+  return PITA_OK;
+}

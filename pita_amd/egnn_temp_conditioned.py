@@ -177,6 +177,25 @@ class EGNN_dynamics(nn.Module):
                                             _lib.stream_ptr(x_t.device)), "pita_egnn_jvp")
         return out, dout
 
+    def jacobian_trace(self, h_t, x_t, beta):
+        """trace(J_x D_theta(h, x)) per walker, exactly: dim unit directions, K per launch sharing the primal
+        evaluation (pita_egnn_div_accumulate)."""
+        x_t = _lib.dev_tensor(x_t, "x_t")
+        B, D = x_t.shape
+        h_t = _lib.dev_tensor(h_t, "h_t").reshape(-1).expand(B).contiguous()
+        b = _as_batch(beta, B, x_t.device) if self.condition_temperature else None
+        L = _lib.lib()
+        net = self._native(x_t.device)
+        K = L.pita_egnn_div_directions(net)
+        if K < 1:
+            raise _lib.PitaHipError("pita_egnn_div_directions: no divergence kernel for this particle system")
+        trace = torch.zeros(B, device=x_t.device)
+        st = _lib.stream_ptr(x_t.device)
+        for d0 in range(0, D, K):
+            _lib.check(L.pita_egnn_div_accumulate(net, h_t.data_ptr(), x_t.data_ptr(), _lib.ptr(b), d0, min(K, D - d0),
+                                                  trace.data_ptr(), B, st), "pita_egnn_div_accumulate")
+        return trace
+
     def vjp(self, h_t, x_t, beta, cot=None, want_primal=True):
         """(D, J_x D^T cot): the denoiser and its reverse-mode derivative for a per-walker cotangent (default: x_t
         itself, which is what grad_x E_theta needs).  One launch (pita_egnn_vjp) instead of dim JVP launches."""

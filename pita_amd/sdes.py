@@ -9,8 +9,9 @@
   log-weight drift  gamma^2 <-grad E, b> + gamma div b + gamma dE/dt + gamma'(t) E, clamped at its 0.9 quantile.
   The reference obtains grad_x E (autograd), div s (vmap(jacrev)) and dE/dt (autograd through h(t)); here they are
   assembled from derivatives of the two denoisers computed by HIP kernels: one reverse-mode launch (pita_egnn_vjp,
-  csrc/egnn_vjp_kernel.hip) + one forward-mode launch in the h direction for the energy net, and dim forward-mode
-  launches (pita_egnn_jvp, csrc/egnn_jvp_kernel.hip) for the exact divergence of the score net, per step.
+  csrc/egnn_vjp_kernel.hip) + one forward-mode launch in the h direction (pita_egnn_jvp, csrc/egnn_jvp_kernel.hip)
+  for the energy net, and dim / K launches of the K-direction divergence kernel (pita_egnn_div_accumulate,
+  csrc/egnn_div_kernel.hip) for the exact divergence of the score net, per step.
 """
 from dataclasses import dataclass
 from typing import Optional
@@ -114,6 +115,14 @@ class VEReverseSDE:
                   want_tangent=False, dot_out=dot_h)
         return D_E, jtx, dot_h
 
+    def _score_divergence_terms(self, model, ht, x, beta):
+        """D and trace(J_x D) of the score net's denoiser: one forward launch + the multi-direction divergence kernel
+        (dim / K launches); backbones without it use dim single-direction JVP launches."""
+        if not (hasattr(model, "jacobian_trace") and hasattr(model, "edm")):
+            D_S, trace, _, _ = self._denoiser_jacobian_terms(model, ht, x, beta, False)
+            return D_S, trace
+        return model.edm(1, ht, x, beta), model.jacobian_trace(ht, x, beta)
+
     def f_debiased(self, t, x, beta, gamma_energy, gamma_energy_schedule, clamp_chunk=None):
         assert self.energy_net is not None
         if self.pin_energy or getattr(self.energy_net, "precondition_beta", False) or (
@@ -131,7 +140,7 @@ class VEReverseSDE:
         dg = gamma_energy_schedule.dgamma_dt(t)
         dgamma = float(dg.reshape(-1)[0]) if isinstance(dg, torch.Tensor) else float(dg)
         D_E, jtx_E, dot_h = self._energy_gradient_terms(self.energy_net.net, ht, x, beta)
-        D_S, trace_S, _, _ = self._denoiser_jacobian_terms(self.score_net.model, ht, x, beta, False)
+        D_S, trace_S = self._score_divergence_terms(self.score_net.model, ht, x, beta)
         drift_X = torch.empty_like(x)
         drift_A, div_bt, cross, dUdt, Ut = (torch.empty(B, device=x.device) for _ in range(5))
         _lib.check(_lib.lib().pita_fk_assemble(

@@ -520,6 +520,33 @@ def test_jvp_vs_oracle(pa, golden):
             assert rel(dk, dref) < 2e-5, k
 
 
+def test_jacobian_trace_multi_direction(pa, golden):
+    """pita_egnn_div_accumulate (K unit directions per launch, shared primal) == the trace assembled from single-direction
+    JVP launches, and == the trace of the fp64 oracle Jacobian (the reference's vmap(jacrev), utils.py:30-51)."""
+    from torch.func import jacrev, vmap
+
+    w = golden("egnn_weights_trainedlike.npz")
+    wt = {k: T(v).double() for k, v in w.items()}
+    for n, d, B in ((13, 3, 23), (4, 2, 41), (13, 3, 1), (13, 3, 300)):
+        net = make_net(pa, n, d, w)
+        gen = torch.Generator().manual_seed(3 * n + B)
+        h = torch.tensor([0.01, 0.3, 2.0, 40.0, 900.0])[torch.arange(B) % 5]
+        x = O.remove_mean(torch.randn(B, n * d, generator=gen) * (1 + h.sqrt())[:, None], n, d)
+        beta = torch.rand(B, generator=gen) + 0.7
+        tr = net.jacobian_trace(h.cuda(), x.cuda(), beta.cuda())
+        acc = torch.zeros(B, device="cuda")
+        for k in range(n * d):
+            net.jvp(h.cuda(), x.cuda(), beta.cuda(), direction=k, want_primal=False, want_tangent=False, diag_acc=acc)
+        scale = float(acc.abs().mean()) + 1.0
+        np.testing.assert_allclose(tr.cpu().numpy(), acc.cpu().numpy(), rtol=2e-5, atol=2e-5 * scale)
+        if B <= 41:
+            bb = lambda cn, xs, b: O.egnn_forward(wt, cn, xs, b, n, d)
+            one = lambda hh, xx, b: O.denoiser(bb, hh[None], xx[None], b[None])[0]
+            J = vmap(jacrev(one, argnums=1))(h.double(), x.double(), beta.double())
+            want = torch.diagonal(J, dim1=1, dim2=2).sum(-1)
+            np.testing.assert_allclose(tr.cpu().numpy(), want.numpy(), rtol=5e-5, atol=5e-5 * scale)
+
+
 def test_vjp_vs_oracle(pa, golden):
     """pita_egnn_vjp (reverse mode, one launch) against torch.autograd of the fp64 oracle denoiser: the default
     cotangent x (what grad_x E_theta needs) and a random one; ragged batches that leave tiles partly filled; and
