@@ -630,6 +630,17 @@ def integrate_sde(cfg: IntegratorConfig, x1: Tensor, drift_fn: Callable[[Tensor,
     return out
 
 
+def resample_at_end(x: Tensor, a: Tensor, t_end: Tensor, target_logp, model_energy, gamma: float, u0: float):
+    """End-of-trajectory reweighting + resampling (sde_integration.py:158-183): a_next = log p_target(x) -
+    (-E_theta(h(t_end), x) gamma(t_end)) + a, clamped at its 0.9 quantile, then systematic resampling.
+    ``model_energy(t, x)`` is EnergyNet.forward_energy at h(t).  Returns (x[ids], a_next, n_unique)."""
+    tb = t_end * torch.ones(x.shape[0], dtype=x.dtype)
+    a_next = target_logp(x) + model_energy(tb, x) * gamma + a
+    a_next = quantile_clamp(a_next, 0.9)
+    ids = sample_cat_sys(a_next, u0)
+    return x[torch.from_numpy(ids)], a_next, len(np.unique(ids))
+
+
 def negative_time_descent(x: Tensor, logp_force, n_steps: int, dt: float, n_particles: int, n_dim: int,
                           do_langevin: bool = False, noise_fn: Optional[NoiseFn] = None, mean_free: bool = True) -> Tensor:
     """sde_integration.py:353-360."""

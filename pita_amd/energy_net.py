@@ -1,8 +1,8 @@
 """Energy view of the score backbone (mirror of pita/src/models/components/energy_net.py).
 
 ``forward_energy`` (E_theta built from <F_theta(c_in x), c_in x>, :14-49) needs only backbone
-FORWARDS.  ``forward`` (grad_x E_theta, autograd in the reference :51-62) is assembled from the dim
-forward-mode derivatives of the HIP backbone (``EGNN_dynamics.jvp``).
+FORWARDS.  ``forward`` (grad_x E_theta, autograd in the reference :51-62) is one reverse-mode launch of the HIP
+backbone (``EGNN_dynamics.vjp``).
 """
 from typing import Optional
 
@@ -34,15 +34,9 @@ class EnergyNet(nn.Module):
 
     def forward(self, ht, xt, beta, pin=False, t=None, energy_function=None):
         """grad_x E_theta = ((1 + c_s) x - D - J_x D^T x)/h with D the denoiser of this backbone."""
-        if pin or self.precondition_beta or not hasattr(self.net, "jvp"):
+        if pin or self.precondition_beta or not hasattr(self.net, "vjp"):
             raise NotImplementedError("EnergyNet.forward: needs the HIP EGNN backbone, pin=False, precondition_beta=False")
-        B, D = xt.shape
-        jtx = torch.empty(B, D, device=xt.device)
-        Dx = None
-        for k in range(D):
-            out, _ = self.net.jvp(ht, xt, beta, direction=k, want_primal=(k == 0), want_tangent=False, dot_out=jtx,
-                                  dot_col=k)
-            Dx = out if k == 0 else Dx
+        Dx, jtx = self.net.vjp(ht, xt, beta)
         c_s = 1 / (1 + ht)
         return ((1 + c_s)[:, None] * xt - Dx - jtx) / ht[:, None]
 

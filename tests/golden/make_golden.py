@@ -403,6 +403,29 @@ def gen_traj_debias():
     save("em_traj_lj13_debias.npz", **out)
 
 
+def gen_traj_debias_end():
+    """The LJ13 experiment's variant (experiment/lj13.yaml:27,41): two inference chunks per step (per-chunk quantile
+    clamp, sdes.py:230) and ``resample_at_end=True`` (sde_integration.py:158-183)."""
+    wt = dict(np.load(os.path.join(HERE, "egnn_weights_trainedlike.npz")))
+    sde, sched = build_lj13_stack(wt, debias=True)
+    N, B = 8, 12
+    gamma = annealing_factor_schedules.ConstantAnnealingFactorSchedule(4 / 3)
+    integ = sde_integration.WeightedSDEIntegrator(
+        sde=sde, num_integration_steps=N, start_resampling_step=0, end_resampling_step=6, lightning_module=FakeLM(),
+        partial_annealing_factor_schedule=None, resampling_interval=3, num_negative_time_steps=0, post_mcmc_steps=0,
+        batch_size=6, no_grad=True, should_mean_free=True, resample_at_end=True)
+    e = LJ(39, 13, 3, data_path="", temperature=1.0)
+    torch.manual_seed(78)
+    x1 = base_prior.Prior(scale=3.0, n_particles=13, spatial_dim=3).sample(B)
+    with Recorder() as rec:
+        x, logw, uniq, terms, acc = integ.integrate_sde(x1.clone(), e, gamma, inverse_temperature=1.0)
+    noise = np.stack([torch.cat(rec.randn[2 * k:2 * k + 2]).numpy() for k in range(N)])  # 2 chunks of 6 per step
+    save("em_traj_lj13_debias_end.npz", x1=x1.numpy(), x_final=x.detach().numpy(), logweights=logw.detach().numpy(),
+         num_unique=np.asarray(uniq), N=N, gamma=4 / 3, beta=1.0, sigma_min=0.05, noise=noise,
+         u=np.stack([r.numpy() for r in rec.rand]), chunk=6,
+         drift_A=np.stack([t.drift_A.reshape(B).detach().numpy() for t in terms]))
+
+
 def gen_post():
     """negative-time descent + MALA on the LJ13 target (sde_integration.py:353-470)."""
     e_raw = LJ(39, 13, 3, data_path="", temperature=1.0)
@@ -484,6 +507,6 @@ def gen_traj_gmm():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["schedules", "lj", "gmm", "egnn", "mlp", "prior", "resample", "traj_nodebias",
-                             "traj_debias", "post", "traj_gmm"]
+                             "traj_debias", "traj_debias_end", "post", "traj_gmm"]
     for w in which:
         globals()["gen_" + w]()

@@ -569,6 +569,12 @@ def test_vjp_vs_oracle(pa, golden):
             Dh, vj = net.vjp(h.cuda(), x.cuda(), beta.cuda(), cot=None if c is None else c.cuda())
             assert rel(Dh, Dref.detach()) < 2e-6, (n, B, tag)
             assert rel(vj, gref) < 2e-5, (n, B, tag, rel(vj, gref))
+        # EnergyNet.forward = grad_x E_theta (energy_net.py:51-62: autograd in the reference, one VJP launch here)
+        from pita_amd.energy_net import EnergyNet
+
+        xd = x.double().requires_grad_(True)
+        (gE,) = torch.autograd.grad(O.energy_theta(bb, h.double(), xd, beta.double()).sum(), xd)
+        assert rel(EnergyNet(net).forward(h.cuda(), x.cuda(), beta.cuda()), gE) < 5e-5, (n, B)
         v = torch.randn(B, n * d, generator=gen)
         _, Jv = net.jvp(h.cuda(), x.cuda(), beta.cuda(), vx=v.cuda(), want_primal=False)
         _, JTc = net.vjp(h.cuda(), x.cuda(), beta.cuda(), cot=cot.cuda(), want_primal=False)
@@ -615,6 +621,33 @@ def test_debiased_terms_and_trajectory_golden(pa, golden):
     np.testing.assert_allclose(whole.drift_A.cpu().numpy(), torch.cat([p_.drift_A for p_ in parts]).cpu().numpy(),
                                rtol=2e-5, atol=2e-4)
     assert rel(whole.drift_X, torch.cat([p_.drift_X for p_ in parts])) < 2e-6
+
+
+def test_debiased_resample_at_end_golden(pa, golden):
+    """experiment/lj13.yaml settings: inference chunks of 6 (per-chunk quantile clamp inside one set of launches) and
+    resample_at_end=True (sde_integration.py:158-183), against the reference run em_traj_lj13_debias_end.npz."""
+    import copy
+
+    from pita_amd.energy_net import EnergyNet
+
+    g = golden("em_traj_lj13_debias_end.npz")
+    w = golden("egnn_weights_trainedlike.npz")
+    net = make_net(pa, 13, 3, w)
+    sched = pa.ElucidatingNoiseSchedule(sigma_min=0.05, sigma_max=80.0, rho=7)
+    sde = pa.VEReverseSDE(noise_schedule=sched, score_net=pa.ScoreNet(net), energy_net=EnergyNet(copy.deepcopy(net)),
+                          debias_inference=True)
+    gam = pa.ConstantAnnealingFactorSchedule(4 / 3)
+    N = int(g["N"])
+    integ = pa.WeightedSDEIntegrator(sde=sde, num_integration_steps=N, start_resampling_step=0, end_resampling_step=6,
+                                     resampling_interval=3, num_negative_time_steps=0, post_mcmc_steps=0, batch_size=6,
+                                     resample_at_end=True)
+    x, logw, uniq, _, _ = integ.integrate_sde(cu(g["x1"]), pa.LennardJonesEnergy(39, 13, 3), gam, inverse_temperature=1.0,
+                                              noise=cu(g["noise"]), resample_u=[float(u[0]) for u in g["u"]])
+    assert uniq == list(g["num_unique"])
+    assert logw.shape == (N + 1, 12)
+    np.testing.assert_allclose(logw[:N].cpu().numpy(), g["logweights"][:N], rtol=1e-2, atol=1e-2)
+    np.testing.assert_allclose(logw[N].cpu().numpy(), g["logweights"][N], rtol=2e-4)
+    assert rel(x, g["x_final"]) < 3e-3
 
 
 @pytest.mark.parametrize("n,chunk", [(12, 12), (1000, 1000), (65536, 512), (65536, 65536), (777, 100), (5, 1)])

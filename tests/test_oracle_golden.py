@@ -200,6 +200,30 @@ def test_traj_debias(golden):
     np.testing.assert_allclose(terms.divergence_score.numpy(), g["divergence_score"][0], rtol=2e-3, atol=1e-2)
 
 
+def test_traj_debias_resample_at_end(golden):
+    """The LJ13 experiment's settings: two inference chunks per step (per-chunk clamp) and resample_at_end."""
+    g = golden("em_traj_lj13_debias_end.npz")
+    bb = _lj13_backbone(golden)
+    sched, gam = O.Elucidating(0.05, 80.0, 7), O.GammaConstant(4 / 3)
+    N = int(g["N"])
+    noise, us = T(g["noise"]), g["u"]
+    cfg = O.IntegratorConfig(num_integration_steps=N, start_resampling_step=0, end_resampling_step=6,
+                             resampling_interval=3, batch_size=6)
+    drift = lambda t, xc: O.f_debiased(bb, bb, sched, gam, t, xc, 1.0)
+    umap = {2: float(us[0][0]), 5: float(us[1][0])}
+    draws = iter(range(10**6))
+    out = O.integrate_sde(cfg, T(g["x1"]), drift, sched.g, lambda i, shp: noise[i // 2][(i % 2) * 6:(i % 2) * 6 + 6], 13, 3,
+                          uniform_fn=lambda s: umap[s])
+    np.testing.assert_allclose(out["logweights"].numpy(), g["logweights"][:N], rtol=5e-3, atol=5e-3)
+    assert out["num_unique"] == list(g["num_unique"][:N])
+    t_end = torch.linspace(1.0, 0.0, N + 1)[:-1][6]
+    x, a_next, nu = O.resample_at_end(out["x"], out["logweights"][-1], t_end, lambda x: O.lj_logp(x, 13, 3),
+                                      lambda tb, x: O.energy_theta(bb, sched.h(tb), x, 1.0), 4 / 3, float(us[2][0]))
+    np.testing.assert_allclose(a_next.numpy(), g["logweights"][N], rtol=2e-4)
+    assert nu == int(g["num_unique"][N])
+    assert rel(x.numpy(), g["x_final"]) < 2e-3
+
+
 def test_post(golden):
     g = golden("post_lj13.npz")
     lf = lambda x: O.lj_logp_force(x, 13, 3)
