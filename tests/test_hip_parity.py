@@ -547,6 +547,37 @@ def test_jacobian_trace_multi_direction(pa, golden):
             np.testing.assert_allclose(tr.cpu().numpy(), want.numpy(), rtol=5e-5, atol=5e-5 * scale)
 
 
+@pytest.mark.parametrize("n,B", [(22, 9), (55, 3)])
+def test_derivative_kernels_other_shapes(pa, golden, n, B):
+    """The 22-atom (alanine dipeptide, config C4) and LJ55 (C5) instantiations of the forward-mode, reverse-mode and
+    multi-direction divergence kernels against the fp64 oracle (same weights: the EGNN does not depend on n)."""
+    from torch.func import jvp
+
+    d = 3
+    w = golden("egnn_weights_trainedlike.npz")
+    wt = {k: T(v).double() for k, v in w.items()}
+    net = make_net(pa, n, d, w)
+    gen = torch.Generator().manual_seed(n)
+    h = torch.tensor([0.05, 1.0, 30.0])[torch.arange(B) % 3]
+    x = O.remove_mean(torch.randn(B, n * d, generator=gen) * (1 + h.sqrt())[:, None], n, d)
+    beta = torch.rand(B, generator=gen) + 0.7
+    bb = lambda cn, xs, b: O.egnn_forward(wt, cn, xs, b, n, d)
+    fn = lambda hh, xx: O.denoiser(bb, hh, xx, beta.double())
+    vx, cot = torch.randn(B, n * d, generator=gen), torch.randn(B, n * d, generator=gen)
+    Dref, dref = jvp(fn, (h.double(), x.double()), (torch.zeros(B).double(), vx.double()))
+    Dh, dDh = net.jvp(h.cuda(), x.cuda(), beta.cuda(), vx=vx.cuda())
+    assert rel(Dh, Dref) < 2e-6 and rel(dDh, dref) < 2e-5
+    xd = x.double().requires_grad_(True)
+    (gref,) = torch.autograd.grad((fn(h.double(), xd) * cot.double()).sum(), xd)
+    Dv, vj = net.vjp(h.cuda(), x.cuda(), beta.cuda(), cot=cot.cuda())
+    assert rel(Dv, Dref) < 2e-6 and rel(vj, gref) < 2e-5
+    tr = net.jacobian_trace(h.cuda(), x.cuda(), beta.cuda())
+    acc = torch.zeros(B, device="cuda")
+    for k in range(n * d):
+        net.jvp(h.cuda(), x.cuda(), beta.cuda(), direction=k, want_primal=False, want_tangent=False, diag_acc=acc)
+    np.testing.assert_allclose(tr.cpu().numpy(), acc.cpu().numpy(), rtol=2e-5, atol=2e-5 * (float(acc.abs().mean()) + 1))
+
+
 def test_vjp_vs_oracle(pa, golden):
     """pita_egnn_vjp (reverse mode, one launch) against torch.autograd of the fp64 oracle denoiser: the default
     cotangent x (what grad_x E_theta needs) and a random one; ragged batches that leave tiles partly filled; and
