@@ -18,9 +18,13 @@ struct FkParams {
   int D;
 };
 
-// One thread per walker (rows are 4*D contiguous bytes; the data are tiny next to the JVP passes).
+// One wavefront per walker: lane k takes components k, k + 64, ... of the walker's row, so every array is read as
+// one contiguous 4*D-byte span (a thread-per-walker mapping measured 25x the algorithmic HBM traffic: 64 lanes x 156 B
+// strides); the three per-walker sums are wave butterflies.
 __global__ void __launch_bounds__(256) fk_assemble_kernel(FkParams p) {
-  for (long long b = (long long)blockIdx.x * 256 + threadIdx.x; b < p.B; b += (long long)gridDim.x * 256) {
+  const int lane = threadIdx.x & 63;
+  const long long nwaves = (long long)gridDim.x * 4;
+  for (long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); b < p.B; b += nwaves) {
     const float h = p.h[b], g2 = p.g2[b];
     const float c_s = 1.0f / (1.0f + h);
     const float* x = p.x + b * p.D;
@@ -29,7 +33,7 @@ __global__ void __launch_bounds__(256) fk_assemble_kernel(FkParams p) {
     const float* DS = p.D_S + b * p.D;
     float* dX = p.drift_X + b * p.D;
     float x2 = 0.f, DEx = 0.f, inner = 0.f;
-    for (int k = 0; k < p.D; ++k) {
+    for (int k = lane; k < p.D; k += 64) {
       const float xv = x[k];
       x2 = fmaf(xv, xv, x2);
       DEx = fmaf(DE[k], xv, DEx);
@@ -38,16 +42,24 @@ __global__ void __launch_bounds__(256) fk_assemble_kernel(FkParams p) {
       dX[k] = p.gamma * (-nab) * g2 * 0.5f + p.gamma * bt;             // sdes.py:172-174 (gamma_score = gamma_energy)
       inner = fmaf(-nab, bt, inner);
     }
-    const float Ut = (1.0f + c_s) / (2.0f * h) * x2 - DEx / h;
-    const float den = 2.0f * h + 2.0f * h * h;
-    const float dq = (-2.0f * h * h - 8.0f * h - 4.0f) / (den * den);  // d/dh [(1 + c_s)/(2h)]
-    const float dUdt = (dq * x2 + DEx / (h * h) - p.dot_h[b] / h) * g2;  // dh/dt = g^2
-    const float div_bt = ((p.trace_S[b] - (float)p.D) / h) * g2 * 0.5f;
-    p.drift_A[b] = p.gamma * p.gamma * inner + p.gamma * div_bt + p.gamma * dUdt + p.dgamma * Ut;  // :222-227
-    p.div_bt[b] = div_bt;
-    p.cross[b] = inner;
-    p.dUdt[b] = dUdt;
-    p.Ut[b] = Ut;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      x2 += __shfl_xor(x2, o, 64);
+      DEx += __shfl_xor(DEx, o, 64);
+      inner += __shfl_xor(inner, o, 64);
+    }
+    if (lane == 0) {
+      const float Ut = (1.0f + c_s) / (2.0f * h) * x2 - DEx / h;
+      const float den = 2.0f * h + 2.0f * h * h;
+      const float dq = (-2.0f * h * h - 8.0f * h - 4.0f) / (den * den);  // d/dh [(1 + c_s)/(2h)]
+      const float dUdt = (dq * x2 + DEx / (h * h) - p.dot_h[b] / h) * g2;  // dh/dt = g^2
+      const float div_bt = ((p.trace_S[b] - (float)p.D) / h) * g2 * 0.5f;
+      p.drift_A[b] = p.gamma * p.gamma * inner + p.gamma * div_bt + p.gamma * dUdt + p.dgamma * Ut;  // :222-227
+      p.div_bt[b] = div_bt;
+      p.cross[b] = inner;
+      p.dUdt[b] = dUdt;
+      p.Ut[b] = Ut;
+    }
   }
 }
 
@@ -122,8 +134,8 @@ extern "C" int pita_fk_assemble(const float* x, const float* h, const float* g2,
   PITA_REQUIRE(x && h && g2 && D_E && jtx_E && dot_h && D_S && trace_S && drift_X && drift_A && div_bt && cross && dUdt && Ut,
                "pita_fk_assemble: null argument");
   FkParams p{x, h, g2, D_E, jtx_E, dot_h, D_S, trace_S, gamma, dgamma, drift_X, drift_A, div_bt, cross, dUdt, Ut, B, D};
-  const long long nb = (B + 255) / 256;
-  hipLaunchKernelGGL(fk_assemble_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, (hipStream_t)stream, p);
+  const long long nb = (B + 3) / 4;  // one wave per walker, four waves per block
+  hipLaunchKernelGGL(fk_assemble_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, (hipStream_t)stream, p);
   PITA_LAUNCH_CHECK();
   return PITA_OK;
 }
