@@ -7,7 +7,9 @@
 // pita_egnn_jvp spends half of every pass recomputing the primal network.  This kernel pushes K directions
 // e_{dir0}, ..., e_{dir0+K-1} through the network together: per edge the primal MLP (activations and their derivative
 // factors) is evaluated once and the K tangent chains -- independent MFMA chains, so they also give the single wave
-// per SIMD the instruction-level parallelism it lacks in the one-direction kernel -- reuse it.  Output:
+// per SIMD the instruction-level parallelism it lacks in the one-direction kernel -- reuse it.  (Only 256 of the
+// wave's 512 registers are visible to VALU instructions, so per-node tangent state that the edge loop merely reads --
+// Wa dh_i -- is parked in LDS next to the partner tables.)  Output:
 // diag_acc[b] += sum_k (J_x D e_{dir0+k})_{dir0+k}.
 //
 // Mapping: as egnn_jvp_kernel.hip (wave = G walkers = dense 32-column tiles, lane = column x 16 features, exact 3-way
@@ -36,8 +38,8 @@ struct DivCfg {
   static constexpr int NCOLP = NT * 32;
   static constexpr int PB_F = NCOLP * PBS;
   static constexpr int POS_F = NCOLP * DIM;
-  // PB, dPB[K]; pos[2], pos0; dpos[K][2], dpos0[K]
-  static constexpr int WAVE_F = (1 + K) * PB_F + 3 * POS_F + 3 * K * POS_F;
+  // PB, dPB[K], dA[K]; pos[2], pos0; dpos[K][2], dpos0[K]
+  static constexpr int WAVE_F = (1 + 2 * K) * PB_F + 3 * POS_F + 3 * K * POS_F;
   static __host__ __device__ constexpr int vec_f(int L) { return ((VEC_EMB_F + L * VEC_LAYER_F) + 3) & ~3; }
   static __host__ __device__ constexpr size_t lds_bytes(int L) {
     return sizeof(float) * (size_t)(vec_f(L) + WAVES * WAVE_F);
@@ -63,7 +65,8 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_kernel(DivParams p) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cl = lane & 31, hh = lane >> 5;
   float* PB = lds + vec_f + wave * C::WAVE_F;
   float* dPB = PB + C::PB_F;                       // [K][PB_F]
-  float* posb = dPB + K * C::PB_F;                 // [2][POS_F]
+  float* dA = dPB + K * C::PB_F;                   // [K][PB_F]  Wa dh_i (own node): parked in LDS, not in registers
+  float* posb = dA + K * C::PB_F;                  // [2][POS_F]
   float* pos0 = posb + 2 * C::POS_F;
   float* dposb = pos0 + C::POS_F;                  // [K][2][POS_F]
   float* dpos0 = dposb + 2 * K * C::POS_F;         // [K][POS_F]
@@ -167,14 +170,22 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_kernel(DivParams p) {
 #pragma unroll
       for (int T = 0; T < NT; ++T) {
         if (T >= ntile) continue;
-        f32x16 Ai, dAi[K];
+        f32x16 Ai;
         {
           WFrag<1> wa;
           wa.load(nullptr, mats16, M_WA, lane);
           Ai = wa.mul(hf[T], lds_vec16(vl + V_B1 * EH));
+          if (l > 0) {
 #pragma unroll
-          for (int d = 0; d < K; ++d) dAi[d] = (l > 0) ? wa.mul(dhf[T][d], zero16) : zero16;
+            for (int d = 0; d < K; ++d) {
+              const f32x16 da = wa.mul(dhf[T][d], zero16);
+              f32x4* dst = reinterpret_cast<f32x4*>(dA + d * C::PB_F + col[T] * PBS + hh * 16);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) dst[q] = f32x4{da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]};
+            }
+          }
         }
+        wave_lds_fence();
         f32x16 agg = {0}, dagg[K];
         float xacc[DIM], dxacc[K][DIM];
 #pragma unroll
@@ -246,7 +257,9 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_kernel(DivParams p) {
             }
             dradial *= 2.0f;
             dea *= 2.0f;
-            f32x16 dz = dAi[d] + lds_vec16(dPB + d * C::PB_F + cj * PBS + hh * 16);
+            f32x16 dz = zero16;  // dh = 0 in the first layer
+            if (l > 0)
+              dz = lds_vec16(dA + d * C::PB_F + col[T] * PBS + hh * 16) + lds_vec16(dPB + d * C::PB_F + cj * PBS + hh * 16);
             dz = __builtin_amdgcn_mfma_f32_32x32x2f32(a_re, hh ? dea : dradial, dz, 0, 0, 0);
             dz *= g1;
             dz = w2f.mul(dz, zero16);
@@ -347,14 +360,15 @@ static size_t div_lds_bytes_of(int L) { return DivCfg<N, DIM, G, WAVES, K>::lds_
 #define PITA_DIV_SHAPE(N, DIM, G, WAVES, K) \
   DivShape { N, DIM, G, WAVES, K, egnn_div_kernel<N, DIM, G, WAVES, K>, div_lds_bytes_of<N, DIM, G, WAVES, K> }
 static const DivShape kDivShapes[] = {
-    PITA_DIV_SHAPE(4, 2, 8, 4, 4),
+    PITA_DIV_SHAPE(4, 2, 8, 4, 3),
     PITA_DIV_SHAPE(13, 3, 2, 4, 3),
     PITA_DIV_SHAPE(22, 3, 1, 4, 3),
     PITA_DIV_SHAPE(55, 3, 1, 4, 1),
 };
-// measured for LJ13 at 65 536 walkers, all 39 directions: K = 2: 117.9 ms, K = 3: 100.6 ms, K = 4: 102.8 ms (more
-// spilling), 39 single-direction JVP launches: 126 ms.  PITA_DIV_K selects an alternative for experiments.
-static const DivShape kDivAlt[] = {PITA_DIV_SHAPE(13, 3, 2, 4, 2), PITA_DIV_SHAPE(13, 3, 2, 4, 4)};
+// measured for LJ13 at 65 536 walkers, all 39 directions: K = 2: 117.9 ms, K = 3: 100.6 ms (93.3 ms with Wa dh_i parked
+// in LDS), K = 4: 102.8 ms (more register shuffling; no longer fits in LDS), 39 single-direction JVP launches: 126 ms.
+// PITA_DIV_K selects an alternative for experiments.
+static const DivShape kDivAlt[] = {PITA_DIV_SHAPE(13, 3, 2, 4, 2)};
 static const DivShape* find_div_shape(int n, int dim) {
   static const int altk = getenv("PITA_DIV_K") ? atoi(getenv("PITA_DIV_K")) : 0;
   if (altk)
