@@ -243,6 +243,12 @@ int pita_mlp_destroy(pita_mlp_t* net);
 int64_t pita_mlp_num_weights(const pita_mlp_config* cfg);
 int pita_mlp_forward(pita_mlp_t* net, const float* t, const float* x, const float* beta /*nullable*/,
                      float* out, int64_t B, void* stream);
+/* Fused not-debiased sampler for the MLP backbone: the counterpart of pita_egnn_sampler_run (same step table, noise and
+ * Philox conventions; sde_integration.py:299-351 + sdes.py:117-128 + score_net.py:13-43) with the walkers LDS-resident
+ * for all n_steps.  Requires out_dim == input_dim == n_particles * n_dim <= 64 (GMM: n_particles = 1, n_dim = 2). */
+int pita_mlp_sampler_run(pita_mlp_t* net, float* x, int64_t B, const float* step_tab, int n_steps,
+                         const float* noise /*nullable*/, uint64_t seed, uint64_t walker_offset, int64_t step0,
+                         int remove_mean, int n_particles, int n_dim, void* stream);
 
 /* ---------------------------------------------------------------- elementwise sampler pieces
  * K8: x <- x + drift*dt + (noise_scale*xi)*sqrt_dt, then optional per-walker mean removal

@@ -80,6 +80,8 @@ _PROTOS = {
     "pita_mlp_destroy": (c_int, [c_void_p]),
     "pita_mlp_num_weights": (c_int64, [POINTER(MlpConfig)]),
     "pita_mlp_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "pita_mlp_sampler_run": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_uint64, c_uint64, c_int64,
+                                     c_int, c_int, c_int, c_void_p]),
     "pita_em_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_float, c_float, c_uint64,
                              c_uint64, c_int64, c_int, c_void_p]),
     "pita_prior_sample": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_uint64, c_uint64, c_int,

@@ -60,76 +60,161 @@ __device__ __forceinline__ f32x16 mlp_bias(const float* b, int hh) {
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
 
-template <int NB>
-__global__ void __launch_bounds__(256) mlp_kernel(MlpParams p) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cl = lane & 31, hh = lane >> 5;
-  const long long ntile = (p.B + 31) / 32;
+// One 32-walker tile through the network.  xrow: this lane's walker coordinates [input_dim] (global or LDS), used as
+// xrow[var] * xscale (xscale = c_in of the EDM preconditioning in the fused sampler, 1 in the plain forward: x * 1.0f
+// is exact); emit(row, value) receives output row `row` of this lane's walker from the lane that holds it.
+template <int NB, typename Emit>
+__device__ __forceinline__ void mlp_tile(const MlpParams& p, int lane, int hh, const float* xrow, float xscale, float tv,
+                                         float bv, Emit&& emit) {
   const int half = p.emb >> 1;
-  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntile; tile += (long long)gridDim.x * 4) {
-    const long long wid = tile * 32 + cl;
-    const bool valid = wid < p.B;
-    const long long wl = valid ? wid : p.B - 1;
-    // ---- layer 0: GELU(W0 . [emb(x_0) .. emb(x_{D-1}), emb(t), (emb(beta))] + b0)
-    f32x16 z[NB];
+  // ---- layer 0: GELU(W0 . [emb(x_0) .. emb(x_{D-1}), emb(t), (emb(beta))] + b0)
+  f32x16 z[NB];
 #pragma unroll
-    for (int ob = 0; ob < NB; ++ob) z[ob] = mlp_bias(p.b0 + ob * 32, hh);
-    for (int kc = 0; kc < p.KC; ++kc) {
-      f32x16 e;
+  for (int ob = 0; ob < NB; ++ob) z[ob] = mlp_bias(p.b0 + ob * 32, hh);
+  for (int kc = 0; kc < p.KC; ++kc) {
+    f32x16 e;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int f = kc * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const int var = f / p.emb, idx = f - var * p.emb;
-        float v, scale;
-        if (var < p.input_dim) { v = p.x[wl * p.input_dim + var]; scale = 25.0f; }
-        else if (var == p.input_dim) { v = p.t[wl]; scale = 1.0f; }
-        else { v = p.beta[wl]; scale = 1.0f; }
-        const float ang = (v * scale) * p.freqs[idx < half ? idx : idx - half];
-        e[r] = idx < half ? sinf(ang) : cosf(ang);
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int f = kc * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const int var = f / p.emb, idx = f - var * p.emb;
+      float v, scale;
+      if (var < p.input_dim) { v = xrow[var] * xscale; scale = 25.0f; }
+      else if (var == p.input_dim) { v = tv; scale = 1.0f; }
+      else { v = bv; scale = 1.0f; }
+      const float ang = (v * scale) * p.freqs[idx < half ? idx : idx - half];
+      e[r] = idx < half ? sinf(ang) : cosf(ang);
+    }
 #pragma unroll
-      for (int ob = 0; ob < NB; ++ob) {
+    for (int ob = 0; ob < NB; ++ob) {
+      float wf[16];
+      mlp_load_frag(p.w0 + ((size_t)ob * p.KC + kc) * 1024, lane, wf);
+      z[ob] = mlp_gemm32(wf, e, z[ob]);
+    }
+  }
+#pragma unroll
+  for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[ob][r] = gelu_erf(z[ob][r]);
+  // ---- residual blocks: z += GELU(W_l z + b_l)
+  for (int l = 0; l < p.n_layers; ++l) {
+    f32x16 nz[NB];
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob) {
+      nz[ob] = mlp_bias(p.bl + ((size_t)l * NB + ob) * 32, hh);
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) {
         float wf[16];
-        mlp_load_frag(p.w0 + ((size_t)ob * p.KC + kc) * 1024, lane, wf);
-        z[ob] = mlp_gemm32(wf, e, z[ob]);
+        mlp_load_frag(p.wl + (((size_t)l * NB + ob) * NB + kb) * 1024, lane, wf);
+        nz[ob] = mlp_gemm32(wf, z[kb], nz[ob]);
       }
     }
 #pragma unroll
     for (int ob = 0; ob < NB; ++ob)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) z[ob][r] = gelu_erf(z[ob][r]);
-    // ---- residual blocks: z += GELU(W_l z + b_l)
-    for (int l = 0; l < p.n_layers; ++l) {
-      f32x16 nz[NB];
+      for (int r = 0; r < 16; ++r) z[ob][r] += gelu_erf(nz[ob][r]);
+  }
+  // ---- output head
+  for (int ob = 0; ob < p.NBO; ++ob) {
+    f32x16 o = mlp_bias(p.bf + ob * 32, hh);
 #pragma unroll
-      for (int ob = 0; ob < NB; ++ob) {
-        nz[ob] = mlp_bias(p.bl + ((size_t)l * NB + ob) * 32, hh);
+    for (int kb = 0; kb < NB; ++kb) {
+      float wf[16];
+      mlp_load_frag(p.wf + ((size_t)ob * NB + kb) * 1024, lane, wf);
+      o = mlp_gemm32(wf, z[kb], o);
+    }
 #pragma unroll
-        for (int kb = 0; kb < NB; ++kb) {
-          float wf[16];
-          mlp_load_frag(p.wl + (((size_t)l * NB + ob) * NB + kb) * 1024, lane, wf);
-          nz[ob] = mlp_gemm32(wf, z[kb], nz[ob]);
+    for (int r = 0; r < 16; ++r) {
+      const int row = ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (row < p.out_dim) emit(row, o[r]);
+    }
+  }
+}
+
+template <int NB>
+__global__ void __launch_bounds__(256) mlp_kernel(MlpParams p) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cl = lane & 31, hh = lane >> 5;
+  const long long ntile = (p.B + 31) / 32;
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntile; tile += (long long)gridDim.x * 4) {
+    const long long wid = tile * 32 + cl;
+    const bool valid = wid < p.B;
+    const long long wl = valid ? wid : p.B - 1;
+    mlp_tile<NB>(p, lane, hh, p.x + wl * p.input_dim, 1.0f, p.t[wl], p.beta ? p.beta[wl] : 0.f,
+                 [&](int row, float v) { if (valid) p.out[wid * p.out_dim + row] = v; });
+  }
+}
+
+// ---- fused sampler: all Euler-Maruyama steps of the not-debiased reverse SDE in one launch (the MLP counterpart of
+// egnn_kernel's mode 3; sde_integration.py:299-351 + sdes.py:117-128,245-251 + score_net.py:13-43).  A wave keeps its
+// 32 walkers in LDS for the whole launch: per step the network sees c_in x and c_noise, the lanes holding the output
+// rows drop F into LDS, and lane (walker, hh) updates the coordinates hh, hh + 2, ... of its walker with the same
+// arithmetic as the EGNN sampler / pita_em_step.
+struct MlpSamplerParams {
+  MlpParams m;
+  float* x;
+  const float* step_tab;
+  const float* noise;
+  int n_steps, remove_mean, n_particles, n_dim;
+  unsigned long long seed, walker_offset;
+  long long step0;
+};
+
+__device__ __forceinline__ void mlp_wave_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+template <int NB>
+__global__ void __launch_bounds__(256) mlp_sampler_kernel(MlpSamplerParams q) {
+  extern __shared__ float sm[];
+  const MlpParams& p = q.m;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cl = lane & 31, hh = lane >> 5;
+  const int D = p.input_dim;
+  float* xs = sm + wave * 2 * 32 * D;  // [32][D] walkers of this wave
+  float* fs = xs + 32 * D;             // [32][D] network output F
+  const long long ntile = (p.B + 31) / 32;
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntile; tile += (long long)gridDim.x * 4) {
+    const long long w0 = tile * 32;
+    const int nw = (int)((p.B - w0) < 32 ? (p.B - w0) : 32);
+    for (int i = lane; i < 32 * D; i += 64) xs[i] = (i < nw * D) ? q.x[w0 * D + i] : 0.f;
+    mlp_wave_fence();
+    const long long wid = w0 + cl;
+    float* xrow = xs + cl * D;
+    float* frow = fs + cl * D;
+    for (int s = 0; s < q.n_steps; ++s) {
+      const float* st = q.step_tab + (size_t)s * PITA_STEP_STRIDE;
+      const float c_s = st[PITA_ST_CS], c_in = st[PITA_ST_CIN], c_out = st[PITA_ST_COUT], hv = st[PITA_ST_H];
+      const float g2 = st[PITA_ST_G2], gamma = st[PITA_ST_GAMMA], dt = st[PITA_ST_DT];
+      const float noise_scale = st[PITA_ST_NOISE_SCALE], sqrt_dt = st[PITA_ST_SQRT_DT];
+      mlp_tile<NB>(p, lane, hh, xrow, c_in, st[PITA_ST_CNOISE], st[PITA_ST_BETA], [&](int row, float v) { frow[row] = v; });
+      mlp_wave_fence();
+      for (int var = hh; var < D; var += 2) {
+        const float xv = xrow[var];
+        float xi;
+        if (q.noise) {
+          xi = (cl < nw) ? q.noise[((long long)s * p.B + wid) * D + var] : 0.f;
+        } else {
+          float z4[4];
+          philox_normal4(q.seed, q.walker_offset + (unsigned long long)wid, q.step0 + s, (uint32_t)(var / q.n_dim), z4);
+          const int c = var - (var / q.n_dim) * q.n_dim;
+          xi = c == 0 ? z4[0] : (c == 1 ? z4[1] : (c == 2 ? z4[2] : z4[3]));
         }
+        const float Dth = c_s * xv + c_out * frow[var];
+        const float sc = (Dth - xv) / hv;
+        const float drift = gamma * (sc * g2);
+        xrow[var] = xv + (drift * dt + ((noise_scale * xi) * sqrt_dt));
       }
-#pragma unroll
-      for (int ob = 0; ob < NB; ++ob)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) z[ob][r] += gelu_erf(nz[ob][r]);
-    }
-    // ---- output head
-    for (int ob = 0; ob < p.NBO; ++ob) {
-      f32x16 o = mlp_bias(p.bf + ob * 32, hh);
-#pragma unroll
-      for (int kb = 0; kb < NB; ++kb) {
-        float wf[16];
-        mlp_load_frag(p.wf + ((size_t)ob * NB + kb) * 1024, lane, wf);
-        o = mlp_gemm32(wf, z[kb], o);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (valid && row < p.out_dim) p.out[wid * p.out_dim + row] = o[r];
+      mlp_wave_fence();
+      if (q.remove_mean) {  // per-dimension particle means, staged through the (now free) F rows
+        for (int var = hh; var < D; var += 2) {
+          const int c = var % q.n_dim;
+          float sum = 0.f;
+          for (int i = 0; i < q.n_particles; ++i) sum += xrow[i * q.n_dim + c];
+          frow[var] = sum / (float)q.n_particles;
+        }
+        mlp_wave_fence();
+        for (int var = hh; var < D; var += 2) xrow[var] -= frow[var];
+        mlp_wave_fence();
       }
     }
+    for (int i = lane; i < nw * D; i += 64) q.x[w0 * D + i] = xs[i];
+    mlp_wave_fence();
   }
 }
 
@@ -249,6 +334,33 @@ extern "C" int pita_mlp_forward(pita_mlp_t* net, const float* t, const float* x,
     case 1: hipLaunchKernelGGL(mlp_kernel<1>, dim3(grid), dim3(256), 0, s, p); break;
     case 2: hipLaunchKernelGGL(mlp_kernel<2>, dim3(grid), dim3(256), 0, s, p); break;
     default: hipLaunchKernelGGL(mlp_kernel<4>, dim3(grid), dim3(256), 0, s, p); break;
+  }
+  PITA_LAUNCH_CHECK();
+  return PITA_OK;
+}
+
+extern "C" int pita_mlp_sampler_run(pita_mlp_t* net, float* x, int64_t B, const float* step_tab, int n_steps,
+                                    const float* noise, uint64_t seed, uint64_t walker_offset, int64_t step0,
+                                    int remove_mean, int n_particles, int n_dim, void* stream) {
+  PITA_REQUIRE(net && x && step_tab && B >= 0 && n_steps >= 0, "pita_mlp_sampler_run: bad argument");
+  if (n_steps == 0 || B == 0) return PITA_OK;
+  const int D = net->cfg.input_dim;
+  PITA_REQUIRE(net->cfg.out_dim == D, "pita_mlp_sampler_run: the score net must map R^D to R^D");
+  PITA_REQUIRE(D <= 64, "pita_mlp_sampler_run: input_dim <= 64");
+  PITA_REQUIRE(n_particles >= 1 && n_dim >= 1 && n_dim <= 4 && n_particles * n_dim == D,
+               "pita_mlp_sampler_run: n_particles * n_dim must equal input_dim (n_dim <= 4)");
+  MlpSamplerParams q{};
+  q.m = net->p; q.m.B = B;
+  q.x = x; q.step_tab = step_tab; q.noise = noise; q.n_steps = n_steps; q.remove_mean = remove_mean;
+  q.n_particles = n_particles; q.n_dim = n_dim; q.seed = seed; q.walker_offset = walker_offset; q.step0 = step0;
+  const long long nblk = ((B + 31) / 32 + 3) / 4;
+  const unsigned grid = (unsigned)(nblk < 4096 ? nblk : 4096);
+  const size_t lds = sizeof(float) * 4 * 2 * 32 * (size_t)D;
+  hipStream_t s = (hipStream_t)stream;
+  switch (net->cfg.hidden_size / 32) {
+    case 1: hipLaunchKernelGGL(mlp_sampler_kernel<1>, dim3(grid), dim3(256), lds, s, q); break;
+    case 2: hipLaunchKernelGGL(mlp_sampler_kernel<2>, dim3(grid), dim3(256), lds, s, q); break;
+    default: hipLaunchKernelGGL(mlp_sampler_kernel<4>, dim3(grid), dim3(256), lds, s, q); break;
   }
   PITA_LAUNCH_CHECK();
   return PITA_OK;

@@ -213,7 +213,7 @@ class EGNN_dynamics(nn.Module):
         return out, vjp
 
     def sampler_run(self, x, step_tab, n_steps, noise=None, seed=0, walker_offset=0, step0=0, remove_mean=True,
-                    drift_out=None):
+                    drift_out=None, n_particles=None, n_dim=None):
         """In-place fused Euler-Maruyama steps (pita_egnn_sampler_run); x: [B, n*d] device tensor."""
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
         assert step_tab.is_cuda and step_tab.dtype == torch.float32 and step_tab.is_contiguous()

@@ -92,6 +92,27 @@ class _HipMLP(nn.Module):
         return out
 
 
+    def sampler_run(self, x, step_tab, n_steps, noise=None, seed=0, walker_offset=0, step0=0, remove_mean=True,
+                    drift_out=None, n_particles=None, n_dim=None):
+        """In-place fused Euler-Maruyama steps (pita_mlp_sampler_run); x: [B, D] device tensor.  Geometry defaults to
+        one "particle" of dimension D (the GMM convention of the integrator)."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        assert step_tab.is_cuda and step_tab.dtype == torch.float32 and step_tab.is_contiguous()
+        if drift_out is not None:
+            raise NotImplementedError("MLP fused sampler: drift_out is not provided (use the per-step path)")
+        D = x.shape[1]
+        n, d = (1, D) if n_particles is None else (int(n_particles), int(n_dim))
+        _lib.check(_lib.lib().pita_mlp_sampler_run(
+            self._native(x.device), x.data_ptr(), x.shape[0], step_tab.data_ptr(), int(n_steps), _lib.ptr(noise),
+            int(seed) & 0xFFFFFFFFFFFFFFFF, int(walker_offset), int(step0), int(bool(remove_mean)), n, d,
+            _lib.stream_ptr(x.device)), "pita_mlp_sampler_run")
+        return x
+
+    def can_fuse(self, n_particles, n_dim):
+        D = n_particles * n_dim
+        return self.input_dim == D and self.out_dim == D and D <= 64 and n_dim <= 4
+
+
 class MyMLP(_HipMLP):
     def forward(self, t, x, x_self_cond=False):
         """The third positional argument swallows beta exactly like the reference (mlp.py:244)."""

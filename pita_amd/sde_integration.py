@@ -313,10 +313,10 @@ class WeightedSDEIntegrator:
     def _run_steps(self, model, x, tab, tab_h, s0, s1, noise, key, off, n, d, mean_free, beta, sde_terms_all):
         if s1 <= s0:
             return
-        if model is not None and not self.record_terms:
+        if model is not None and not self.record_terms and (not hasattr(model, "can_fuse") or model.can_fuse(n, d)):
             nz = noise[s0:s1].contiguous() if noise is not None else None
             model.sampler_run(x, tab[s0:s1].contiguous(), s1 - s0, noise=nz, seed=key, walker_offset=off, step0=s0,
-                              remove_mean=mean_free)
+                              remove_mean=mean_free, n_particles=n, n_dim=d)
             return
         # per-step path: any backbone with forward(t, x, beta); drift through ScoreNet, update by pita_em_step
         L = _lib.lib()

@@ -208,6 +208,38 @@ def test_mlp_golden(pa, golden):
                                                      inverse_temperature=1.0, noise=cu(gt["noise"]))
     assert rel(terms[0].drift_X, gt["drift_X"][0]) < 1e-4
     assert rel(xf, gt["x_final"]) < 1e-2
+    # the fused MLP sampler (pita_mlp_sampler_run: all steps in one launch) against the per-step path and the golden
+    integ.record_terms = False
+    xfu, *_ = integ.integrate_sde(cu(gt["x1"]), pa.GMM(), pa.ConstantAnnealingFactorSchedule(1.0),
+                                  inverse_temperature=1.0, noise=cu(gt["noise"]))
+    assert rel(xfu, xf) < 1e-3 and rel(xfu, gt["x_final"]) < 1e-2
+
+
+def test_mlp_fused_sampler_particles(pa):
+    """pita_mlp_sampler_run on a particle system (2 x 3-D, mean removal, temperature-conditioned MLP): Philox noise and
+    injected noise, ragged batch, against the per-step path (pita_mlp_forward + ScoreNet + pita_em_step)."""
+    from types import SimpleNamespace
+
+    from pita_amd import mlp
+
+    torch.manual_seed(3)
+    net = mlp.MyMLPTemperature(hidden_size=64, hidden_layers=2, emb_size=64, out_dim=6, input_dim=6)
+    sched = pa.ElucidatingNoiseSchedule(sigma_min=0.05, sigma_max=80.0, rho=7)
+    sde = pa.VEReverseSDE(noise_schedule=sched, score_net=pa.ScoreNet(net), debias_inference=False)
+    geom = SimpleNamespace(n_particles=2, n_spatial_dim=3, is_molecule=True)
+    N, B = 9, 333
+    gen = torch.Generator().manual_seed(1)
+    x1 = O.remove_mean(torch.randn(B, 6, generator=gen) * 5, 2, 3).cuda()
+    nz = torch.randn(N, B, 6, generator=gen).cuda()
+    mk = lambda rec: pa.WeightedSDEIntegrator(sde=sde, num_integration_steps=N, start_resampling_step=0,
+                                              end_resampling_step=N, resampling_interval=-1, num_negative_time_steps=0,
+                                              post_mcmc_steps=0, record_terms=rec, seed=21)
+    gam = pa.ConstantAnnealingFactorSchedule(4 / 3)
+    for noise in (nz, None):
+        xa, *_ = mk(False).integrate_sde(x1, geom, gam, inverse_temperature=1.3, noise=noise)
+        xb, *_ = mk(True).integrate_sde(x1, geom, gam, inverse_temperature=1.3, noise=noise)
+        assert rel(xa, xb) < 2e-5
+        assert abs(xa.reshape(B, 2, 3).mean(1)).max() < 1e-4 and not torch.equal(xa, x1)
 
 
 # ------------------------------------------------------------------------------- sampler
