@@ -267,6 +267,15 @@ int pita_remove_mean(float* x, int64_t B, int n_particles, int n_dim, void* stre
 int pita_fill_normal(float* out, int64_t B, int n_particles, int n_dim, uint64_t seed,
                      uint64_t walker_offset, int64_t step, void* stream);
 
+/* EDM preconditioning around a backbone that is NOT one of the fused kernels (ScoreNet.denoiser / forward,
+ * pita/src/models/components/score_net.py:13-43): scale gives the backbone inputs x_in = c_in x and c_noise = ln(h)/8;
+ * combine gives D = c_s x + c_out F (times beta + (1-beta) x when beta != NULL, :36-38) and score = (D - x)/h
+ * (times beta).  D_out / score_out nullable. */
+int pita_edm_scale_input(const float* h, const float* x, float* x_scaled, float* c_noise, int64_t B, int D,
+                         void* stream);
+int pita_edm_combine(const float* h, const float* x, const float* F, const float* beta /*nullable*/, float* D_out,
+                     float* score_out, int64_t B, int D, void* stream);
+
 /* ---------------------------------------------------------------- MALA (K12)
  * sde_integration.py:28-45 mala_proposal; :362-470 accept/reject and step-size adaptation.
  * dt_dev: device double holding the step size (adapted in place by pita_mala_adapt, no host round trip).

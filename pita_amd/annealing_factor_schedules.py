@@ -13,6 +13,11 @@ def _as_tensor(t):
 
 
 class BaseAnnealingFactorSchedule:
+    """gamma(t) multiplies the score in the annealed reverse SDE (drift = gamma s_theta g^2): gamma = beta_low / beta_high
+    transports samples of temperature 1/beta_high to 1/beta_low.  The sampler evaluates gamma (and gamma' in the
+    Feynman-Kac weights) on the host, once per step, in fp32 tensors like the reference -- the values land in column
+    PITA_ST_GAMMA of the step table consumed by the fused kernels."""
+
     def gamma(self, t):
         raise NotImplementedError
 
@@ -32,6 +37,9 @@ class ConstantAnnealingFactorSchedule(BaseAnnealingFactorSchedule):  # :20-32
 
 
 class _Ramp(BaseAnnealingFactorSchedule):
+    """Common state of the time-dependent schedules: gamma moves from ``annealing_factor_start`` at ``t_start`` to
+    ``annealing_factor`` at ``t_end`` (reverse time: t_start > t_end)."""
+
     def __init__(self, annealing_factor, annealing_factor_start, t_start=1.0, t_end=0.0):
         self.annealing_factor = annealing_factor
         self.annealing_factor_start = annealing_factor_start

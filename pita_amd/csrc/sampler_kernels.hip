@@ -97,6 +97,42 @@ static int launch_elem(float* x, const float* drift, const float* noise, int64_t
   return PITA_OK;
 }
 
+// ---------------------------------------------------------------------------- EDM preconditioning around a foreign backbone
+// score_net.py:13-43 for backbones that are not fused HIP kernels (any module with forward(t, x, beta)):
+//   scale : x_in = c_in x, t_in = c_noise = ln(h)/8                       (inputs of the backbone)
+//   combine: D = c_s x + c_out F; optional beta preconditioning (:36-38); score = (D - x)/h
+__global__ void __launch_bounds__(256) edm_scale_kernel(const float* __restrict__ h, const float* __restrict__ x,
+                                                        float* __restrict__ xs, float* __restrict__ cn, long long B, int D) {
+  const long long total = B * D;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long b = e / D;
+    const float hv = h[b];
+    xs[e] = (1.0f / sqrtf(1.0f + hv)) * x[e];
+    if (e - b * D == 0) cn[b] = 0.125f * logf(hv);
+  }
+}
+
+__global__ void __launch_bounds__(256) edm_combine_kernel(const float* __restrict__ h, const float* __restrict__ x,
+                                                          const float* __restrict__ F, const float* __restrict__ beta,
+                                                          float* __restrict__ Dout, float* __restrict__ score, long long B,
+                                                          int D) {
+  const long long total = B * D;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long b = e / D;
+    const float hv = h[b], xv = x[e];
+    const float c_s = 1.0f / (1.0f + hv), c_in = 1.0f / sqrtf(1.0f + hv), c_out = sqrtf(hv) * c_in;
+    float Dv = c_s * xv + c_out * F[e];
+    float sc = (Dv - xv) / hv;
+    if (beta) {
+      const float bt = beta[b];
+      Dv = Dv * bt + (1.0f - bt) * xv;
+      sc = sc * bt;
+    }
+    if (Dout) Dout[e] = Dv;
+    if (score) score[e] = sc;
+  }
+}
+
 // ---------------------------------------------------------------------------- MALA
 // The step size lives on the device (double, like the Python float it replaces) so the adaptive chain
 // runs without a host round trip per step; the kernels round it to fp32 where torch would.
@@ -398,6 +434,30 @@ extern "C" int pita_mala_adapt(double* dt_dev, int* acc_count, int64_t total, in
   PITA_REQUIRE(dt_dev && acc_count && total > 0, "pita_mala_adapt: bad argument");
   hipLaunchKernelGGL(mala_adapt_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dt_dev, acc_count, (long long)total,
                      adaptive, rate_out);
+  PITA_LAUNCH_CHECK();
+  return PITA_OK;
+}
+
+extern "C" int pita_edm_scale_input(const float* h, const float* x, float* x_scaled, float* c_noise, int64_t B, int D,
+                                    void* stream) {
+  PITA_REQUIRE(B >= 0 && D >= 1, "pita_edm_scale_input: bad shape");
+  if (B == 0) return PITA_OK;
+  PITA_REQUIRE(h && x && x_scaled && c_noise, "pita_edm_scale_input: null argument");
+  const long long nb = (B * D + 255) / 256;
+  hipLaunchKernelGGL(edm_scale_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, (hipStream_t)stream, h, x,
+                     x_scaled, c_noise, (long long)B, D);
+  PITA_LAUNCH_CHECK();
+  return PITA_OK;
+}
+
+extern "C" int pita_edm_combine(const float* h, const float* x, const float* F, const float* beta, float* D_out,
+                                float* score_out, int64_t B, int D, void* stream) {
+  PITA_REQUIRE(B >= 0 && D >= 1, "pita_edm_combine: bad shape");
+  if (B == 0) return PITA_OK;
+  PITA_REQUIRE(h && x && F && (D_out || score_out), "pita_edm_combine: null argument");
+  const long long nb = (B * D + 255) / 256;
+  hipLaunchKernelGGL(edm_combine_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, (hipStream_t)stream, h, x, F,
+                     beta, D_out, score_out, (long long)B, D);
   PITA_LAUNCH_CHECK();
   return PITA_OK;
 }

@@ -215,6 +215,32 @@ def test_mlp_golden(pa, golden):
     assert rel(xfu, xf) < 1e-3 and rel(xfu, gt["x_final"]) < 1e-2
 
 
+@pytest.mark.parametrize("pb", [False, True])
+def test_scorenet_wrapper_kernels(pa, golden, pb):
+    """ScoreNet around a backbone without a fused EDM kernel (the HIP MLP): pita_edm_scale_input + backbone +
+    pita_edm_combine against the oracle, with and without beta preconditioning (score_net.py:21-43)."""
+    from pita_amd import mlp
+
+    g2 = golden("mlp_temp_fwd.npz")
+    w2 = {k[2:]: T(v) for k, v in g2.items() if k.startswith("w.")}
+    net = mlp.MyMLPTemperature(hidden_size=64, hidden_layers=2, emb_size=64, out_dim=3, input_dim=3)
+    net.load_state_dict(w2)
+    bb = lambda cn, xs, b: O.mlp_forward(w2, cn, xs, b, emb_size=64, hidden_layers=2, temperature_conditioned=True)
+    gen = torch.Generator().manual_seed(8)
+    B = 517
+    h = torch.tensor([0.01, 0.3, 2.0, 40.0, 900.0])[torch.arange(B) % 5]
+    x = torch.randn(B, 3, generator=gen) * (1 + h.sqrt())[:, None]
+    beta = torch.rand(B, generator=gen) + 0.5
+    sn = pa.ScoreNet(net, precondition_beta=pb)
+    Dh, sh = sn.denoiser(h.cuda(), x.cuda(), beta.cuda(), return_score=True)
+    Do = O.denoiser(bb, h, x, beta, precondition_beta=pb)
+    so = O.score(bb, h, x, beta, precondition_beta=pb)
+    assert rel(Dh, Do) < 2e-5 and rel(sh, so) < 2e-4
+    assert rel(sn(h.cuda(), x.cuda(), beta.cuda()), so) < 2e-4
+    assert torch.equal(sn.denoiser(h.cuda(), x.cuda(), beta.cuda()), Dh)
+    assert rel(sn(h.cuda(), x.cuda(), 1.3), O.score(bb, h, x, 1.3, precondition_beta=pb)) < 2e-4  # scalar beta
+
+
 def test_mlp_fused_sampler_particles(pa):
     """pita_mlp_sampler_run on a particle system (2 x 3-D, mean removal, temperature-conditioned MLP): Philox noise and
     injected noise, ragged batch, against the per-step path (pita_mlp_forward + ScoreNet + pita_em_step)."""
