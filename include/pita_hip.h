@@ -276,6 +276,11 @@ int pita_edm_scale_input(const float* h, const float* x, float* x_scaled, float*
 int pita_edm_combine(const float* h, const float* x, const float* F, const float* beta /*nullable*/, float* D_out,
                      float* score_out, int64_t B, int D, void* stream);
 
+/* E_theta(h, x) = (1 - c_s)/(2h) |x|^2 - c_out/(c_in h) <F, c_in x> from the backbone output F = F(c_noise, c_in x, beta)
+ * (EnergyNet.forward_energy, pita/src/models/components/energy_net.py:14-41; times beta when beta != NULL). */
+int pita_energy_theta(const float* h, const float* x, const float* F, const float* beta /*nullable*/, float* E,
+                      int64_t B, int D, void* stream);
+
 /* ---------------------------------------------------------------- MALA (K12)
  * sde_integration.py:28-45 mala_proposal; :362-470 accept/reject and step-size adaptation.
  * dt_dev: device double holding the step size (adapted in place by pita_mala_adapt, no host round trip).

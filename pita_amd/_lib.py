@@ -90,6 +90,7 @@ _PROTOS = {
     "pita_fill_normal": (c_int, [c_void_p, c_int64, c_int, c_int, c_uint64, c_uint64, c_int64, c_void_p]),
     "pita_edm_scale_input": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "pita_edm_combine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "pita_energy_theta": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "pita_mala_propose": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_uint64,
                                   c_uint64, c_int64, c_void_p]),
     "pita_mala_accept": (c_int, [c_void_p] * 7 + [c_int64, c_int, c_int, c_void_p, c_uint64, c_uint64, c_int64, c_int,

@@ -63,6 +63,36 @@ __global__ void __launch_bounds__(256) fk_assemble_kernel(FkParams p) {
   }
 }
 
+// E_theta(h, x) from the backbone output F = F_theta(c_noise, c_in x, beta)  (energy_net.py:33-41):
+//   E = (1 - c_s)/(2h) |x|^2 - c_out/(c_in h) <F, c_in x>   (times beta when beta != NULL: precondition_beta).
+// One wavefront per walker, like fk_assemble_kernel.
+__global__ void __launch_bounds__(256) energy_theta_kernel(const float* __restrict__ h, const float* __restrict__ x,
+                                                           const float* __restrict__ F, const float* __restrict__ beta,
+                                                           float* __restrict__ E, long long B, int D) {
+  const int lane = threadIdx.x & 63;
+  const long long nwaves = (long long)gridDim.x * 4;
+  for (long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); b < B; b += nwaves) {
+    const float hv = h[b];
+    const float c_s = 1.0f / (1.0f + hv), c_in = 1.0f / sqrtf(1.0f + hv), c_out = sqrtf(hv) * c_in;
+    float x2 = 0.f, U = 0.f;
+    for (int k = lane; k < D; k += 64) {
+      const float xv = x[b * D + k];
+      x2 = fmaf(xv, xv, x2);
+      U = fmaf(F[b * D + k], c_in * xv, U);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      x2 += __shfl_xor(x2, o, 64);
+      U += __shfl_xor(U, o, 64);
+    }
+    if (lane == 0) {
+      float e = (1.0f - c_s) / (2.0f * hv) * x2 - c_out / (c_in * hv) * U;
+      if (beta) e *= beta[b];
+      E[b] = e;
+    }
+  }
+}
+
 // ---- K11: per-chunk quantile (linear interpolation, torch.quantile semantics) + clamp, one block per chunk.
 // The two order statistics come from an exact 4-pass radix select over order-preserving integer keys.
 constexpr int QT = 1024;
@@ -147,6 +177,18 @@ extern "C" int pita_quantile_clamp(float* a, int64_t B, int64_t chunk, float q, 
   const long long nchunk = (B + chunk - 1) / chunk;
   hipLaunchKernelGGL(quantile_clamp_kernel, dim3((unsigned)nchunk), dim3(QT), 0, (hipStream_t)stream, a, (long long)B,
                      (long long)chunk, q);
+  PITA_LAUNCH_CHECK();
+  return PITA_OK;
+}
+
+extern "C" int pita_energy_theta(const float* h, const float* x, const float* F, const float* beta, float* E, int64_t B,
+                                 int D, void* stream) {
+  PITA_REQUIRE(B >= 0 && D >= 1, "pita_energy_theta: bad shape");
+  if (B == 0) return PITA_OK;
+  PITA_REQUIRE(h && x && F && E, "pita_energy_theta: null argument");
+  const long long nb = (B + 3) / 4;
+  hipLaunchKernelGGL(energy_theta_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, (hipStream_t)stream, h, x, F,
+                     beta, E, (long long)B, D);
   PITA_LAUNCH_CHECK();
   return PITA_OK;
 }
