@@ -97,8 +97,8 @@ struct WFrag<1> {
 #pragma unroll
       for (int st = 0; st < 2; ++st) w[pc][st] = p[(pc * 2 + st) * 64];
   }
-  __device__ __forceinline__ f32x16 mul(const f32x16& in, f32x16 acc) const {
-    u32x4 x[3][2];
+  // the operand split on its own, for callers that multiply one input by several weight blocks
+  static __device__ __forceinline__ void split(const f32x16& in, u32x4 (&x)[3][2]) {
 #pragma unroll
     for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -114,6 +114,8 @@ struct WFrag<1> {
         x[1][st][q] = __builtin_amdgcn_perm(b2, a2, 0x07060302u);
         x[2][st][q] = __builtin_amdgcn_perm(b3, a3, 0x07060302u);
       }
+  }
+  __device__ __forceinline__ f32x16 mul_split(const u32x4 (&x)[3][2], f32x16 acc) const {
 #pragma unroll
     for (int st = 0; st < 2; ++st) {  // smallest terms first
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w[2][st]), as_bf16x8(x[0][st]), acc, 0, 0, 0);
@@ -124,6 +126,11 @@ struct WFrag<1> {
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w[0][st]), as_bf16x8(x[0][st]), acc, 0, 0, 0);
     }
     return acc;
+  }
+  __device__ __forceinline__ f32x16 mul(const f32x16& in, f32x16 acc) const {
+    u32x4 x[3][2];
+    split(in, x);
+    return mul_split(x, acc);
   }
 };
 

@@ -1,27 +1,26 @@
-// MLP score backbone (MyMLP / MyMLPTemperature) for gfx950 on f32 MFMA.
+// MLP score backbone (MyMLP / MyMLPTemperature) for gfx950 on the bf16 matrix pipe with the exact 3-way operand split
+// (fp32-equivalent, see egnn_common.h; the first version used v_mfma_f32_32x32x2_f32, which shares the VALU datapath
+// with the sin/cos/erf work and ran 2x slower).
 //
 // Replaces (paths relative to /root/reference/pita/src/models/components/):
 //   mlp.py:11-24    SinusoidalEmbedding  (per-coordinate scale 25, time / beta scale 1)
 //   mlp.py:100-118  Block                (x + GELU(Linear(x)))
 //   mlp.py:244-267  MyMLP.forward ; mlp.py:501-524 MyMLPTemperature.forward
 //
-// Mapping: one wavefront = 32 walkers = the 32 columns of v_mfma_f32_32x32x2_f32.  Activations
+// Mapping: one wavefront = 32 walkers = the 32 columns of a 32x32 MFMA tile.  Activations
 // live in registers in the MFMA C/D layout (lane = walker column, 16 of every 32 features per
 // lane) -- the same chaining trick as the EGNN kernel, so no layer ever leaves the register
 // file.  The sinusoidal embedding is generated on the fly, 32 features at a time, straight into
 // the B-operand layout of the first GEMM (the [B, 384] embedding tensor is never materialised).
 // Weights are pre-packed into per-lane fragment order and stream from L2.
-#include "common.h"
+#include "egnn_common.h"
 
 namespace pita {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 struct MlpParams {
-  const float* w0;   // [NB][KC][1024]
-  const float* wl;   // [L][NB][NB][1024]
-  const float* wf;   // [NBO][NB][1024]
+  const unsigned* w0;   // [NB][KC] blocks of MAT_W words: bf16 three-way split fragments ([piece][k-step][lane][4])
+  const unsigned* wl;   // [L][NB][NB] blocks
+  const unsigned* wf;   // [NBO][NB] blocks
   const float* b0;   // [NB][32]  fragment order
   const float* bl;   // [L][NB][32]
   const float* bf;   // [NBO][32]
@@ -33,21 +32,6 @@ struct MlpParams {
   const float* beta;
   float* out;
 };
-
-__device__ __forceinline__ void mlp_load_frag(const float* __restrict__ pack, int lane, float (&wf)[16]) {
-  const f32x4* p = reinterpret_cast<const f32x4*>(pack) + lane;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    f32x4 v = p[q * 64];
-    wf[4 * q + 0] = v.x; wf[4 * q + 1] = v.y; wf[4 * q + 2] = v.z; wf[4 * q + 3] = v.w;
-  }
-}
-
-__device__ __forceinline__ f32x16 mlp_gemm32(const float (&wf)[16], const f32x16& in, f32x16 acc) {
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[r], in[r], acc, 0, 0, 0);
-  return acc;
-}
 
 __device__ __forceinline__ f32x16 mlp_bias(const float* b, int hh) {
   const f32x4* p = reinterpret_cast<const f32x4*>(b + hh * 16);
@@ -71,24 +55,55 @@ __device__ __forceinline__ void mlp_tile(const MlpParams& p, int lane, int hh, c
   f32x16 z[NB];
 #pragma unroll
   for (int ob = 0; ob < NB; ++ob) z[ob] = mlp_bias(p.b0 + ob * 32, hh);
-  for (int kc = 0; kc < p.KC; ++kc) {
-    f32x16 e;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int f = kc * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      const int var = f / p.emb, idx = f - var * p.emb;
-      float v, scale;
-      if (var < p.input_dim) { v = xrow[var] * xscale; scale = 25.0f; }
-      else if (var == p.input_dim) { v = tv; scale = 1.0f; }
-      else { v = bv; scale = 1.0f; }
-      const float ang = (v * scale) * p.freqs[idx < half ? idx : idx - half];
-      e[r] = idx < half ? sinf(ang) : cosf(ang);
-    }
+  auto feed = [&](const f32x16& e, int kc) {
+    u32x4 es[3][2];
+    WFrag<1>::split(e, es);  // one split per chunk, shared by the NB output blocks
 #pragma unroll
     for (int ob = 0; ob < NB; ++ob) {
-      float wf[16];
-      mlp_load_frag(p.w0 + ((size_t)ob * p.KC + kc) * 1024, lane, wf);
-      z[ob] = mlp_gemm32(wf, e, z[ob]);
+      WFrag<1> w;
+      w.load(nullptr, p.w0, ob * p.KC + kc, lane);
+      z[ob] = w.mul_split(es, z[ob]);
+    }
+  };
+  auto input_of = [&](int var, float& v, float& scale) {
+    if (var < p.input_dim) { v = xrow[var] * xscale; scale = 25.0f; }
+    else if (var == p.input_dim) { v = tv; scale = 1.0f; }
+    else { v = bv; scale = 1.0f; }
+  };
+  if ((half & 31) == 0) {
+    // a 32-feature chunk is all-sine or all-cosine of one variable, and the cosine chunk `half/32` chunks later uses the
+    // same angles: one sincosf serves both (the precise range reduction is the expensive part of either)
+    const int hc = half >> 5, per_var = 2 * hc;
+    for (int kc = 0; kc < p.KC; ++kc) {
+      const int var = kc / per_var, c = kc - var * per_var;
+      if (c >= hc) continue;  // cosine chunks are emitted together with their sine chunk
+      float v, scale;
+      input_of(var, v, scale);
+      f32x16 es_, ec_;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int idx = c * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        float sn, cs;
+        sincosf((v * scale) * p.freqs[idx], &sn, &cs);
+        es_[r] = sn;
+        ec_[r] = cs;
+      }
+      feed(es_, kc);
+      feed(ec_, kc + hc);
+    }
+  } else {
+    for (int kc = 0; kc < p.KC; ++kc) {
+      f32x16 e;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int f = kc * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const int var = f / p.emb, idx = f - var * p.emb;
+        float v, scale;
+        input_of(var, v, scale);
+        const float ang = (v * scale) * p.freqs[idx < half ? idx : idx - half];
+        e[r] = idx < half ? sinf(ang) : cosf(ang);
+      }
+      feed(e, kc);
     }
   }
 #pragma unroll
@@ -99,13 +114,16 @@ __device__ __forceinline__ void mlp_tile(const MlpParams& p, int lane, int hh, c
   for (int l = 0; l < p.n_layers; ++l) {
     f32x16 nz[NB];
 #pragma unroll
-    for (int ob = 0; ob < NB; ++ob) {
-      nz[ob] = mlp_bias(p.bl + ((size_t)l * NB + ob) * 32, hh);
+    for (int ob = 0; ob < NB; ++ob) nz[ob] = mlp_bias(p.bl + ((size_t)l * NB + ob) * 32, hh);
 #pragma unroll
-      for (int kb = 0; kb < NB; ++kb) {
-        float wf[16];
-        mlp_load_frag(p.wl + (((size_t)l * NB + ob) * NB + kb) * 1024, lane, wf);
-        nz[ob] = mlp_gemm32(wf, z[kb], nz[ob]);
+    for (int kb = 0; kb < NB; ++kb) {
+      u32x4 zs[3][2];
+      WFrag<1>::split(z[kb], zs);
+#pragma unroll
+      for (int ob = 0; ob < NB; ++ob) {
+        WFrag<1> w;
+        w.load(nullptr, p.wl, (l * NB + ob) * NB + kb, lane);
+        nz[ob] = w.mul_split(zs, nz[ob]);
       }
     }
 #pragma unroll
@@ -118,9 +136,9 @@ __device__ __forceinline__ void mlp_tile(const MlpParams& p, int lane, int hh, c
     f32x16 o = mlp_bias(p.bf + ob * 32, hh);
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
-      float wf[16];
-      mlp_load_frag(p.wf + ((size_t)ob * NB + kb) * 1024, lane, wf);
-      o = mlp_gemm32(wf, z[kb], o);
+      WFrag<1> w;
+      w.load(nullptr, p.wf, ob * NB + kb, lane);
+      o = w.mul(z[kb], o);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -251,18 +269,30 @@ extern "C" int pita_mlp_create(pita_mlp_t** out, const pita_mlp_config* cfg, con
   PITA_REQUIRE(n_weights == pita_mlp_num_weights(cfg), "pita_mlp_create: got %lld weights, expected %lld",
                (long long)n_weights, (long long)pita_mlp_num_weights(cfg));
   const int NB = H / 32, KC = C / 32, NBO = (cfg->out_dim + 31) / 32;
-  const size_t n_w0 = (size_t)NB * KC * 1024, n_wl = (size_t)L * NB * NB * 1024, n_wf = (size_t)NBO * NB * 1024;
+  const size_t n_w0 = (size_t)NB * KC * MAT_W, n_wl = (size_t)L * NB * NB * MAT_W, n_wf = (size_t)NBO * NB * MAT_W;
   const size_t n_b0 = (size_t)NB * 32, n_bl = (size_t)L * NB * 32, n_bf = (size_t)NBO * 32, n_fr = E / 2;
   const size_t total = n_w0 + n_wl + n_wf + n_b0 + n_bl + n_bf + n_fr;
   float* h = new float[total]();
   float* h_w0 = h; float* h_wl = h_w0 + n_w0; float* h_wf = h_wl + n_wl;
   float* h_b0 = h_wf + n_wf; float* h_bl = h_b0 + n_b0; float* h_bf = h_bl + n_bl; float* h_fr = h_bf + n_bf;
-  auto pack_block = [&](float* dst, const float* M, int rows, int ld, int ob, int kb) {
-    for (int q = 0; q < 4; ++q)
-      for (int lane = 0; lane < 64; ++lane)
-        for (int s = 0; s < 4; ++s) {
-          const int row = ob * 32 + (lane & 31), col = kb * 32 + mlp_kfeat(4 * q + s, lane >> 5);
-          dst[(q * 64 + lane) * 4 + s] = (row < rows) ? M[(size_t)row * ld + col] : 0.f;
+  // one 32x32 block as bf16 three-way truncation-split MFMA fragments: word q of (piece, k-step st, lane) packs the
+  // pieces of elements r = 8 st + 2 q (low half) and r + 1 (high half); same layout as the EGNN weights
+  auto trunc16 = [](float v) { unsigned u; memcpy(&u, &v, 4); u &= 0xFFFF0000u; float o; memcpy(&o, &u, 4); return o; };
+  auto hi16 = [](float v) { unsigned u; memcpy(&u, &v, 4); return u >> 16; };
+  auto pack_block = [&](float* dstf, const float* M, int rows, int ld, int ob, int kb) {
+    unsigned* dst = reinterpret_cast<unsigned*>(dstf);
+    for (int lane = 0; lane < 64; ++lane)
+      for (int st = 0; st < 2; ++st)
+        for (int qd = 0; qd < 4; ++qd) {
+          unsigned pcs[2][3];
+          for (int e = 0; e < 2; ++e) {
+            const int row = ob * 32 + (lane & 31), col = kb * 32 + mlp_kfeat(8 * st + 2 * qd + e, lane >> 5);
+            const float w = (row < rows) ? M[(size_t)row * ld + col] : 0.f;
+            const float w1 = trunc16(w), r1 = w - w1, w2 = trunc16(r1), r2 = r1 - w2;
+            pcs[e][0] = hi16(w1); pcs[e][1] = hi16(w2); pcs[e][2] = hi16(r2);
+          }
+          for (int pc = 0; pc < 3; ++pc)
+            dst[(((size_t)pc * 2 + st) * 64 + lane) * 4 + qd] = pcs[0][pc] | (pcs[1][pc] << 16);
         }
   };
   auto pack_bias = [&](float* dst, const float* b, int rows, int ob) {
@@ -276,21 +306,21 @@ extern "C" int pita_mlp_create(pita_mlp_t** out, const pita_mlp_config* cfg, con
   const float* W0 = q; q += (size_t)H * C;
   const float* B0 = q; q += H;
   for (int ob = 0; ob < NB; ++ob) {
-    for (int kc = 0; kc < KC; ++kc) pack_block(h_w0 + ((size_t)ob * KC + kc) * 1024, W0, H, C, ob, kc);
+    for (int kc = 0; kc < KC; ++kc) pack_block(h_w0 + ((size_t)ob * KC + kc) * MAT_W, W0, H, C, ob, kc);
     pack_bias(h_b0 + ob * 32, B0, H, ob);
   }
   for (int l = 0; l < L; ++l) {
     const float* Wl = q; q += (size_t)H * H;
     const float* Bl = q; q += H;
     for (int ob = 0; ob < NB; ++ob) {
-      for (int kb = 0; kb < NB; ++kb) pack_block(h_wl + (((size_t)l * NB + ob) * NB + kb) * 1024, Wl, H, H, ob, kb);
+      for (int kb = 0; kb < NB; ++kb) pack_block(h_wl + (((size_t)l * NB + ob) * NB + kb) * MAT_W, Wl, H, H, ob, kb);
       pack_bias(h_bl + ((size_t)l * NB + ob) * 32, Bl, H, ob);
     }
   }
   const float* Wf = q; q += (size_t)cfg->out_dim * H;
   const float* Bf = q;
   for (int ob = 0; ob < NBO; ++ob) {
-    for (int kb = 0; kb < NB; ++kb) pack_block(h_wf + ((size_t)ob * NB + kb) * 1024, Wf, cfg->out_dim, H, ob, kb);
+    for (int kb = 0; kb < NB; ++kb) pack_block(h_wf + ((size_t)ob * NB + kb) * MAT_W, Wf, cfg->out_dim, H, ob, kb);
     pack_bias(h_bf + ob * 32, Bf, cfg->out_dim, ob);
   }
   for (size_t i = 0; i < n_fr; ++i) h_fr[i] = freqs[i];
@@ -305,7 +335,8 @@ extern "C" int pita_mlp_create(pita_mlp_t** out, const pita_mlp_config* cfg, con
     return fail(PITA_EHIP, "pita_mlp_create: device upload failed: %s", hipGetErrorString(e));
   }
   MlpParams& p = net->p;
-  p.w0 = net->d_all; p.wl = p.w0 + n_w0; p.wf = p.wl + n_wl; p.b0 = p.wf + n_wf; p.bl = p.b0 + n_b0;
+  p.w0 = reinterpret_cast<const unsigned*>(net->d_all); p.wl = p.w0 + n_w0; p.wf = p.wl + n_wl;
+  p.b0 = net->d_all + n_w0 + n_wl + n_wf; p.bl = p.b0 + n_b0;
   p.bf = p.bl + n_bl; p.freqs = p.bf + n_bf;
   p.input_dim = cfg->input_dim; p.out_dim = cfg->out_dim; p.n_layers = L; p.emb = E;
   p.temp = cfg->temperature_conditioned; p.KC = KC; p.NBO = NBO;
