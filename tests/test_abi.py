@@ -98,3 +98,39 @@ def test_schedules_match_golden(built, golden):
                     ("sig", built.SigmoidAnnealingFactorSchedule(1.5, 1.0, t_start=0.9, t_end=0.1, sharpness=10.0))):
         np.testing.assert_allclose(sch.gamma(tt).numpy(), g[f"gamma_{nm}"], rtol=1e-7)
         np.testing.assert_allclose(sch.dgamma_dt(tt).numpy(), g[f"dgamma_{nm}"], rtol=1e-7, atol=1e-30)
+
+
+def test_header_is_plain_c_and_links_from_c(built, tmp_path):
+    """include/pita_hip.h is C99 (what a cgo / JNI / FFI binding would parse), and a plain C program can link the
+    shared library and get error codes + messages back without a GPU (argument validation precedes any HIP call)."""
+    hdr = os.path.join(ROOT, "include", "pita_hip.h")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-fsyntax-only", "-x", "c", hdr])
+    src = tmp_path / "abi_probe.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "pita_hip.h"
+int main(void) {
+  char msg[256];
+  float dummy[8] = {0};
+  if (pita_abi_version() != 1) return 10;
+  /* negative batch: rejected before anything touches the device */
+  int rc = pita_dw_logp_force(dummy, dummy, NULL, -1, 4, 2, 1.0f, 0.9f, -4.0f, 0.0f, 4.0f, NULL);
+  if (rc != PITA_EINVAL) return 11;
+  if (pita_last_error(msg, sizeof msg) <= 0 || !strstr(msg, "negative batch")) return 12;
+  pita_egnn_config cfg = {13, 3, 64 /* unsupported hidden_nf */, 3, 2, 1, 1, 15.0f, 0, 1};
+  pita_egnn_t* net = NULL;
+  rc = pita_egnn_create(&net, &cfg, dummy, 8);
+  if (rc != PITA_EUNSUPPORTED || net != NULL) return 13;
+  if (pita_egnn_num_weights(&(pita_egnn_config){13, 3, 32, 3, 2, 1, 1, 15.0f, 0, 1}) != 22533) return 14;
+  if (pita_lj_logp_force(dummy, dummy, NULL, 0, 13, 3, 1.0f, 1.0f, 1e-6f, 1.0f, 1.0f, 1.0f, NULL) != PITA_OK) return 15;
+  printf("abi ok\n");
+  return 0;
+}
+''')
+    exe = tmp_path / "abi_probe"
+    libdir = os.path.dirname(built._lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L", libdir,
+                           "-lpita_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and "abi ok" in out.stdout, (out.returncode, out.stdout, out.stderr)
