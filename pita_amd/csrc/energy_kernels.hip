@@ -123,6 +123,143 @@ __global__ void __launch_bounds__(256) pair_energy_kernel(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------------------- generic kernel with Newton's third law
+// For n <= 64 a walker's particles are the lanes of ONE wavefront (floor(64/n) walkers per wave): every unordered pair
+// is evaluated once, as the circulant (i, i + dd mod n), dd = 1 .. (n-1)/2 (+ half of dd = n/2 for even n); lane i keeps
+// its own force in registers and hands -f to partner j through an LDS table -- for a fixed dd the map i -> j is a
+// permutation and a wave's LDS operations execute in order, so the read-add-write needs no atomics and the summation
+// order is fixed.  Halves the pair arithmetic of the ordered-pair kernel above (LJ55: 1 485 instead of 2 970 pairs).
+__device__ __forceinline__ void pair_wave_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// per-dimension particle mean of one walker: lanes i < DIM sum, everyone reads (ms: DIM floats of this walker)
+template <int DIM>
+__device__ __forceinline__ void walker_mean(const float* xw, float* ms, int i, int n, float (&mean)[DIM]) {
+  if (i < DIM) {
+    float s = 0.f;
+    for (int j = 0; j < n; ++j) s += xw[j * DIM + i];
+    ms[i] = s;
+  }
+  pair_wave_fence();
+#pragma unroll
+  for (int k = 0; k < DIM; ++k) mean[k] = ms[k];
+}
+
+// f = d logp / d x_i, e = this lane's share of the energy.  fw: [n*DIM] LDS, this walker's partner-force table.
+template <int DIM, int KIND>
+__device__ __forceinline__ void pair_force_n3l(const float* xw, float* fw, float* ms, int i, int n, const PairParams& p,
+                                               float (&f)[DIM], float& e) {
+  float xi[DIM], mean[DIM];
+#pragma unroll
+  for (int k = 0; k < DIM; ++k) { f[k] = 0.f; xi[k] = xw[i * DIM + k]; fw[i * DIM + k] = 0.f; }
+  if (KIND == E_LJ) walker_mean<DIM>(xw, ms, i, n, mean);
+  e = 0.f;
+  const int nh = (n - 1) >> 1, npass = nh + ((n & 1) ? 0 : 1);
+  for (int dd = 1; dd <= npass; ++dd) {
+    asm volatile("" ::: "memory");
+    const bool on = dd <= nh || i < (n >> 1);  // the antipodal distance of an even ring: each pair once
+    int j = i + dd;
+    j = (j >= n) ? j - n : j;
+    float d[DIM], r2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+      d[k] = xi[k] - xw[j * DIM + k];
+      r2 = fmaf(d[k], d[k], r2);
+    }
+    float coef, ep;
+    if (KIND == E_LJ) {
+      r2 += p.dist_eps;
+      const float inv = __builtin_amdgcn_rcpf(r2);
+      const float s2 = p.rm2 * inv, s6 = s2 * s2 * s2;
+      ep = 2.0f * (p.eps * fmaf(s6, s6, -2.0f * s6));              // the reference sums ordered pairs
+      coef = p.eps * (12.0f * fmaf(-s6, s6, s6)) * inv;             // e'(r)/r = eps*12*(s^6 - s^12)/r^2
+    } else {
+      const float dist = sqrtf(r2);
+      const float u = dist - p.d0, u2 = u * u;
+      ep = fmaf(p.a * u2, u2, fmaf(p.b, u2, p.c));
+      coef = (u * fmaf(4.0f * p.a, u2, 2.0f * p.b)) / dist;
+    }
+    if (on) {
+      e += ep;
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) {
+        const float v = coef * d[k];
+        f[k] += v;
+        fw[j * DIM + k] -= v;
+      }
+    }
+  }
+  pair_wave_fence();
+#pragma unroll
+  for (int k = 0; k < DIM; ++k) f[k] += fw[i * DIM + k];
+  if (KIND == E_LJ) {
+    // E = ef * sum_{i != j} lj + 0.5*osc*sum |x - mean|^2
+    float osc = 0.f;
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+      const float c = xi[k] - mean[k] / (float)n;
+      osc += c * c;
+      f[k] = -p.inv_T * (2.0f * p.energy_factor * f[k] + p.osc_scale * c);
+    }
+    e = p.energy_factor * e + 0.5f * p.osc_scale * osc;
+  } else {
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) f[k] = -p.inv_T * f[k];
+  }
+}
+
+struct WaveMap {  // thread -> (walker of the block, particle) with whole walkers per wavefront
+  int w, i;
+  bool in_range;
+  __device__ WaveMap(int tid, int n) {
+    const int wpw = 64 / n, lane = tid & 63, wl = lane / n;
+    i = lane - wl * n;
+    w = (tid >> 6) * wpw + wl;
+    in_range = wl < wpw;
+  }
+};
+
+template <int DIM, int KIND>
+__global__ void __launch_bounds__(256) pair_energy_n3l_kernel(const float* __restrict__ x, float* __restrict__ logp,
+                                                              float* __restrict__ force, long long B, int n, int WB,
+                                                              PairParams p) {
+  extern __shared__ float sm[];
+  float* xs = sm;                    // [WB*n*DIM] coordinates
+  float* fs = xs + WB * n * DIM;     // [WB*n*DIM] partner forces, then total forces
+  float* es = fs + WB * n * DIM;     // [WB*n] per-particle energy partials
+  float* ms = es + WB * n;           // [WB*DIM] per-walker coordinate sums
+  const int tid = threadIdx.x;
+  const WaveMap m(tid, n);
+  const long long nblk = (B + WB - 1) / WB;
+  for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const long long w0 = blk * WB;
+    const int nw = (int)((B - w0) < WB ? (B - w0) : WB);
+    const int nfl = nw * n * DIM;
+    const float* src = x + w0 * n * DIM;
+    for (int q = tid; q < nfl; q += 256) xs[q] = src[q];
+    __syncthreads();
+    const bool act = m.in_range && m.w < nw;
+    if (act) {
+      float f[DIM], e;
+      float* fw = fs + m.w * n * DIM;
+      pair_force_n3l<DIM, KIND>(xs + m.w * n * DIM, fw, ms + m.w * DIM, m.i, n, p, f, e);
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) fw[m.i * DIM + k] = f[k];
+      es[m.w * n + m.i] = e;
+    }
+    __syncthreads();
+    if (act && m.i == 0) {
+      float s = 0.f;
+      for (int q = 0; q < n; ++q) s += es[m.w * n + q];
+      logp[w0 + m.w] = -s * p.inv_T;
+    }
+    if (force) {
+      float* dst = force + w0 * n * DIM;
+      for (int q = tid; q < nfl; q += 256) dst[q] = fs[q];
+    }
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------------------- LJ13 fast path
 // LJ13 (n = 13, d = 3) with one walker per lane(-pair): coordinates are staged once in LDS (row
 // stride 39 words = odd, so the per-lane row reads are bank-conflict free and use immediate
@@ -330,6 +467,64 @@ __global__ void __launch_bounds__(256) pair_descent_kernel(float* __restrict__ x
   }
 }
 
+// wave-local variant (n <= 64, pair_force_n3l): a walker never leaves its wavefront, so the step loop needs no
+// workgroup barrier at all
+template <int DIM, int KIND>
+__global__ void __launch_bounds__(256) pair_descent_n3l_kernel(float* __restrict__ x, const float* __restrict__ noise,
+                                                               long long B, int n, int WB, PairParams p, DescentParams q) {
+  extern __shared__ float sm[];
+  float* xs = sm;                    // [WB*n*DIM]
+  float* fs = xs + WB * n * DIM;     // [WB*n*DIM]
+  float* ms = fs + WB * n * DIM;     // [WB*DIM]
+  const int tid = threadIdx.x;
+  const WaveMap m(tid, n);
+  const long long nblk = (B + WB - 1) / WB;
+  for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const long long w0 = blk * WB;
+    const int nw = (int)((B - w0) < WB ? (B - w0) : WB);
+    const int nfl = nw * n * DIM;
+    float* gx = x + w0 * n * DIM;
+    for (int c = tid; c < nfl; c += 256) xs[c] = gx[c];
+    __syncthreads();
+    const bool act = m.in_range && m.w < nw;
+    if (act) {
+      float* xw = xs + m.w * n * DIM;
+      float* fw = fs + m.w * n * DIM;
+      float* mw = ms + m.w * DIM;
+      const int i = m.i;
+      for (int s = 0; s < q.nsteps; ++s) {
+        float f[DIM], e, v[DIM];
+        pair_force_n3l<DIM, KIND>(xw, fw, mw, i, n, p, f, e);
+        float xi[4] = {0.f, 0.f, 0.f, 0.f};
+        if (q.noise_scale != 0.f) {
+          if (noise) {
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) xi[k] = noise[(((long long)s * B + w0 + m.w) * n + i) * DIM + k];
+          } else {
+            philox_normal4(q.seed, q.walker_offset + (unsigned long long)(w0 + m.w), q.step0 + s, (uint32_t)i, xi);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) v[k] = xw[i * DIM + k] + (f[k] * q.dt + ((q.noise_scale * xi[k]) * q.sqrt_dt));
+        pair_wave_fence();
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) xw[i * DIM + k] = v[k];
+        pair_wave_fence();
+        if (q.remove_mean) {
+          float mean[DIM];
+          walker_mean<DIM>(xw, mw, i, n, mean);
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) xw[i * DIM + k] = v[k] - mean[k] / (float)n;
+          pair_wave_fence();
+        }
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < nfl; c += 256) gx[c] = xs[c];
+    __syncthreads();
+  }
+}
+
 // LJ13: 128 walkers per 256-thread block, the two halves of lj13_kernel<2>.  Half 1 hands its partial
 // forces over through LDS; half 0 adds them to its own (still in registers), applies the update and the
 // centring for all 13 particles of its walker and writes the new coordinates back to the LDS stage.
@@ -439,6 +634,19 @@ static int launch_descent(float* x, const float* noise, int64_t B, int n, int d,
     PITA_LAUNCH_CHECK();
     return PITA_OK;
   }
+  if (n <= 64) {
+    const int WB = 4 * (64 / n);
+    const long long nblk = (B + WB - 1) / WB;
+    const unsigned grid = (unsigned)(nblk < 256LL * 16 ? nblk : 256LL * 16);
+    const size_t lds = sizeof(float) * (size_t)(2 * WB * n * d + WB * d);
+    switch (d) {
+      case 1: hipLaunchKernelGGL((pair_descent_n3l_kernel<1, KIND>), dim3(grid), dim3(256), lds, s, x, noise, B, n, WB, p, q); break;
+      case 2: hipLaunchKernelGGL((pair_descent_n3l_kernel<2, KIND>), dim3(grid), dim3(256), lds, s, x, noise, B, n, WB, p, q); break;
+      default: hipLaunchKernelGGL((pair_descent_n3l_kernel<3, KIND>), dim3(grid), dim3(256), lds, s, x, noise, B, n, WB, p, q); break;
+    }
+    PITA_LAUNCH_CHECK();
+    return PITA_OK;
+  }
   const int WB = 256 / n;
   const long long nblk = (B + WB - 1) / WB;
   const unsigned grid = (unsigned)(nblk < 256LL * 16 ? nblk : 256LL * 16);
@@ -461,11 +669,24 @@ static int launch_pair(const float* x, float* logp, float* force, int64_t B, int
   PITA_REQUIRE(n >= 2 && n <= 256, "pair energy: n_particles must be in [2,256]");
   PITA_REQUIRE(d >= 1 && d <= 3, "pair energy: n_dim must be 1, 2 or 3");
   if (B == 0) return PITA_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (n <= 64) {  // whole walkers per wavefront: unordered pairs with Newton's third law
+    const int WB = 4 * (64 / n);
+    const long long nblk = (B + WB - 1) / WB;
+    const unsigned grid = (unsigned)(nblk < 256LL * 16 ? nblk : 256LL * 16);
+    const size_t lds = sizeof(float) * (size_t)(2 * WB * n * d + WB * n + WB * d);
+    switch (d) {
+      case 1: hipLaunchKernelGGL((pair_energy_n3l_kernel<1, KIND>), dim3(grid), dim3(256), lds, s, x, logp, force, B, n, WB, p); break;
+      case 2: hipLaunchKernelGGL((pair_energy_n3l_kernel<2, KIND>), dim3(grid), dim3(256), lds, s, x, logp, force, B, n, WB, p); break;
+      default: hipLaunchKernelGGL((pair_energy_n3l_kernel<3, KIND>), dim3(grid), dim3(256), lds, s, x, logp, force, B, n, WB, p); break;
+    }
+    PITA_LAUNCH_CHECK();
+    return PITA_OK;
+  }
   const int WB = 256 / n;
   const long long nblk = (B + WB - 1) / WB;
   const unsigned grid = (unsigned)(nblk < 256LL * 16 ? nblk : 256LL * 16);
   const size_t lds = sizeof(float) * (size_t)(WB * n * d + WB * n);
-  hipStream_t s = (hipStream_t)stream;
   switch (d) {
     case 1: hipLaunchKernelGGL((pair_energy_kernel<1, KIND>), dim3(grid), dim3(256), lds, s, x, logp, force, B, n, WB, p); break;
     case 2: hipLaunchKernelGGL((pair_energy_kernel<2, KIND>), dim3(grid), dim3(256), lds, s, x, logp, force, B, n, WB, p); break;
