@@ -94,7 +94,7 @@ def cpu_baseline(n_walkers, n_steps, seed=12345):
 
 def debiased_leg(pita_amd, net, dev, B, with_cpu):
     """Secondary number: the debiased Feynman-Kac regime (PITA's default; sdes.py:151-239): drift of x and of the
-    log-weights through 13 three-direction divergence launches (pita_egnn_div_accumulate) + 1 forward + 1 forward-mode
+    log-weights through 13 three-direction divergence launches (pita_egnn_div_accumulate) + 1 forward-mode
     (pita_egnn_jvp, h direction) + 1 reverse-mode launch (pita_egnn_vjp) + assembly + quantile clamp, then the EM update."""
     import copy
 
@@ -123,7 +123,7 @@ def debiased_leg(pita_amd, net, dev, B, with_cpu):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     out = {"metric": "walker-steps/s, debiased (Feynman-Kac) regime, LJ13", "value": B / dt, "walkers": B,
-           "ms_per_step": dt * 1e3, "launches_per_step": 16 + 3}
+           "ms_per_step": dt * 1e3, "launches_per_step": 15 + 3}
     if with_cpu:
         from oracle import pita_oracle as O
 

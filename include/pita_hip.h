@@ -181,7 +181,8 @@ int pita_egnn_vjp(pita_egnn_t* net, const float* h, const float* x, const float*
  * divergence the reference computes with vmap(jacrev) (pita/src/models/components/utils.py:30-51). */
 int pita_egnn_div_directions(const pita_egnn_t* net);
 int pita_egnn_div_accumulate(pita_egnn_t* net, const float* h, const float* x, const float* beta, int dir0, int ndir,
-                             float* diag_acc, int64_t B, void* stream);
+                             float* diag_acc, float* denoiser_out /*nullable: D(h, x) of the shared primal*/, int64_t B,
+                             void* stream);
 
 /* Feynman-Kac drift assembly per walker from those reductions (replaces the torch/autograd expressions of
  * sdes.py:157-227): with E = (1+c_s)|x|^2/(2h) - <D_E,x>/h,

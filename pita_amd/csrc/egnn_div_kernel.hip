@@ -29,6 +29,7 @@ struct DivParams {
   const float* beta;  // [B] or null
   int dir0, ndir;     // unit directions dir0 .. dir0 + ndir - 1 (ndir <= K)
   float* diag_acc;    // [B] += sum_k dD_k[b, dir0 + k]
+  float* out;         // [B, D] denoiser D of the primal (nullable: the caller asks for it with the first launch only)
 };
 
 template <int N, int DIM, int G, int WAVES, int K>
@@ -347,6 +348,30 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_kernel(DivParams p) {
         }
     }
     wave_lds_fence();
+    if (p.out) {  // primal denoiser D = c_s x + c_out (F - mean F), F = pos^L - pos^0 (x = pos^0 / c_in)
+      float* scr = PB;
+#pragma unroll
+      for (int T = 0; T < NT; ++T)
+        if (hh == 0) {
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) scr[col[T] * DIM + k] = posi[T][k] - p0i[T][k];
+        }
+      wave_lds_fence();
+#pragma unroll
+      for (int T = 0; T < NT; ++T) {
+        if (!(valid[T] && hh == 0)) continue;
+        const int cb = col[T] - nodei[T];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          float sum = 0.f;
+          for (int q = 0; q < N; ++q) sum += scr[(cb + q) * DIM + k];
+          const float F = (posi[T][k] - p0i[T][k]) - sum / (float)N;
+          const long long gi = (walker0 * N + col[T]) * DIM + k;
+          p.out[gi] = fmaf(c_s[T], p.x[gi], c_out[T] * F);
+        }
+      }
+      wave_lds_fence();
+    }
   }
 }
 
@@ -390,7 +415,7 @@ extern "C" int pita_egnn_div_directions(const pita_egnn_t* net) {
 }
 
 extern "C" int pita_egnn_div_accumulate(pita_egnn_t* net, const float* h, const float* x, const float* beta, int dir0,
-                                        int ndir, float* diag_acc, int64_t B, void* stream) {
+                                        int ndir, float* diag_acc, float* out, int64_t B, void* stream) {
   PITA_REQUIRE(net && B >= 0, "pita_egnn_div_accumulate: bad argument");
   if (B == 0) return PITA_OK;
   PITA_REQUIRE(h && x && diag_acc, "pita_egnn_div_accumulate: null argument");
@@ -403,7 +428,7 @@ extern "C" int pita_egnn_div_accumulate(pita_egnn_t* net, const float* h, const 
   p.mats16 = net->d_mats16; p.vecs = net->d_vecs; p.n_layers = net->cfg.n_layers; p.in_nf = net->cfg.in_node_nf;
   p.attention = net->cfg.attention; p.tanh_on = net->cfg.tanh; p.feature_layout = net->cfg.feature_layout;
   p.coord_scale = net->cfg.coords_range / (float)net->cfg.n_layers;
-  p.B = B; p.h = h; p.x = x; p.beta = beta; p.dir0 = dir0; p.ndir = ndir; p.diag_acc = diag_acc;
+  p.B = B; p.h = h; p.x = x; p.beta = beta; p.dir0 = dir0; p.ndir = ndir; p.diag_acc = diag_acc; p.out = out;
   const size_t lds = s->lds_bytes(p.n_layers);
   static thread_local const void* configured = nullptr;
   if (configured != (const void*)s->kernel) {

@@ -177,9 +177,10 @@ class EGNN_dynamics(nn.Module):
                                             _lib.stream_ptr(x_t.device)), "pita_egnn_jvp")
         return out, dout
 
-    def jacobian_trace(self, h_t, x_t, beta):
+    def jacobian_trace(self, h_t, x_t, beta, want_denoiser=False):
         """trace(J_x D_theta(h, x)) per walker, exactly: dim unit directions, K per launch sharing the primal
-        evaluation (pita_egnn_div_accumulate)."""
+        evaluation (pita_egnn_div_accumulate).  ``want_denoiser``: also return D_theta(h, x), a by-product of the
+        first launch's primal -> (trace, D)."""
         x_t = _lib.dev_tensor(x_t, "x_t")
         B, D = x_t.shape
         h_t = _lib.dev_tensor(h_t, "h_t").reshape(-1).expand(B).contiguous()
@@ -190,11 +191,13 @@ class EGNN_dynamics(nn.Module):
         if K < 1:
             raise _lib.PitaHipError("pita_egnn_div_directions: no divergence kernel for this particle system")
         trace = torch.zeros(B, device=x_t.device)
+        den = torch.empty_like(x_t) if want_denoiser else None
         st = _lib.stream_ptr(x_t.device)
         for d0 in range(0, D, K):
             _lib.check(L.pita_egnn_div_accumulate(net, h_t.data_ptr(), x_t.data_ptr(), _lib.ptr(b), d0, min(K, D - d0),
-                                                  trace.data_ptr(), B, st), "pita_egnn_div_accumulate")
-        return trace
+                                                  trace.data_ptr(), _lib.ptr(den) if d0 == 0 else None, B, st),
+                       "pita_egnn_div_accumulate")
+        return (trace, den) if want_denoiser else trace
 
     def vjp(self, h_t, x_t, beta, cot=None, want_primal=True):
         """(D, J_x D^T cot): the denoiser and its reverse-mode derivative for a per-walker cotangent (default: x_t

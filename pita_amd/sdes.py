@@ -116,12 +116,13 @@ class VEReverseSDE:
         return D_E, jtx, dot_h
 
     def _score_divergence_terms(self, model, ht, x, beta):
-        """D and trace(J_x D) of the score net's denoiser: one forward launch + the multi-direction divergence kernel
-        (dim / K launches); backbones without it use dim single-direction JVP launches."""
-        if not (hasattr(model, "jacobian_trace") and hasattr(model, "edm")):
+        """D and trace(J_x D) of the score net's denoiser from the multi-direction divergence kernel (dim / K launches;
+        D is a by-product of the first one); backbones without it use dim single-direction JVP launches."""
+        if not hasattr(model, "jacobian_trace"):
             D_S, trace, _, _ = self._denoiser_jacobian_terms(model, ht, x, beta, False)
             return D_S, trace
-        return model.edm(1, ht, x, beta), model.jacobian_trace(ht, x, beta)
+        trace, D_S = model.jacobian_trace(ht, x, beta, want_denoiser=True)
+        return D_S, trace
 
     def f_debiased(self, t, x, beta, gamma_energy, gamma_energy_schedule, clamp_chunk=None):
         assert self.energy_net is not None

@@ -591,7 +591,9 @@ def test_jacobian_trace_multi_direction(pa, golden):
         h = torch.tensor([0.01, 0.3, 2.0, 40.0, 900.0])[torch.arange(B) % 5]
         x = O.remove_mean(torch.randn(B, n * d, generator=gen) * (1 + h.sqrt())[:, None], n, d)
         beta = torch.rand(B, generator=gen) + 0.7
-        tr = net.jacobian_trace(h.cuda(), x.cuda(), beta.cuda())
+        tr, den = net.jacobian_trace(h.cuda(), x.cuda(), beta.cuda(), want_denoiser=True)
+        assert torch.equal(tr, net.jacobian_trace(h.cuda(), x.cuda(), beta.cuda()))
+        assert rel(den, net.edm(1, h.cuda(), x.cuda(), beta.cuda())) < 1e-6
         acc = torch.zeros(B, device="cuda")
         for k in range(n * d):
             net.jvp(h.cuda(), x.cuda(), beta.cuda(), direction=k, want_primal=False, want_tangent=False, diag_acc=acc)
