@@ -146,7 +146,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--walkers", type=int, default=65536, help="walkers per GPU")
+    ap.add_argument("--walkers", type=int, default=65536, help="walkers per GPU (with --strong: in total)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: --walkers is the TOTAL batch, split across ranks")
     ap.add_argument("--chunk", type=int, default=0, help="SDE steps per kernel launch (default gcd(steps, warmup))")
     ap.add_argument("--force-evals", type=int, default=200, help="LJ13 force-kernel launches for its roofline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -171,6 +172,9 @@ def main():
 
     pita_amd._lib.lib()  # fail loudly if the HIP library is missing
     B, K, W = args.walkers, args.steps, args.warmup
+    if args.strong:
+        assert B % world == 0, "--strong: --walkers must be divisible by the number of ranks"
+        B //= world
     chunk = args.chunk or (math.gcd(K, W) if W > 0 else K)
     assert K % chunk == 0 and W % chunk == 0
 
@@ -306,7 +310,7 @@ def main():
             "warmup": W,
             "ms_per_step": elapsed * 1e3 / K,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
