@@ -20,6 +20,81 @@ from .base_energy_function import BaseMoleculeEnergy
 KB_KJ_PER_MOL_K = 8.314462618e-3
 
 
+def tables_from_openmm_xml(source):
+    """Parameter tables from a serialized OpenMM ``System`` (``XmlSerializer.serialize(system)`` -- the file the
+    reference itself writes, pita/src/generate_md.py:105-106), parsed with the standard library only: no OpenMM needed
+    at run time.  Recognised forces: HarmonicBondForce, HarmonicAngleForce, PeriodicTorsionForce, NonbondedForce
+    (particles + exceptions; ``method`` 1 = CutoffNonPeriodic with ``cutoff`` / ``rfDielectric``), GBSAOBCForce, and
+    the OBC1 flavour of CustomGBForce that ``implicit/obc1.xml`` creates (per-particle ``charge, or, sr``).  Other
+    forces (CMMotionRemover, ...) carry no energy and are skipped; unknown energy-bearing forces raise.
+    Returns (tables, options) where options holds cutoff / rf_dielectric / GB dielectrics for ``ForceFieldEnergy``.
+    NOT verified against a real OpenMM file in this repository (none ships with the reference): attribute names follow
+    OpenMM's serialization proxies."""
+    import xml.etree.ElementTree as ET
+
+    root = ET.parse(source).getroot() if not str(source).lstrip().startswith("<") else ET.fromstring(source)
+    n = len(root.find("Particles").findall("Particle"))
+    t = dict(bond_idx=[], bond_par=[], angle_idx=[], angle_par=[], tors_idx=[], tors_par=[], exc_idx=[], exc_par=[])
+    opts = {}
+    F = lambda e, k: float(e.attrib[k])
+    I = lambda e, k: int(e.attrib[k])
+    for force in root.find("Forces").findall("Force"):
+        kind = force.attrib.get("type", "")
+        if kind == "HarmonicBondForce":
+            for b in force.find("Bonds").findall("Bond"):
+                t["bond_idx"].append((I(b, "p1"), I(b, "p2")))
+                t["bond_par"].append((F(b, "d"), F(b, "k")))
+        elif kind == "HarmonicAngleForce":
+            for a in force.find("Angles").findall("Angle"):
+                t["angle_idx"].append((I(a, "p1"), I(a, "p2"), I(a, "p3")))
+                t["angle_par"].append((F(a, "a"), F(a, "k")))
+        elif kind == "PeriodicTorsionForce":
+            for q in force.find("Torsions").findall("Torsion"):
+                t["tors_idx"].append((I(q, "p1"), I(q, "p2"), I(q, "p3"), I(q, "p4")))
+                t["tors_par"].append((F(q, "periodicity"), F(q, "phase"), F(q, "k")))
+        elif kind == "NonbondedForce":
+            parts = force.find("Particles").findall("Particle")
+            assert len(parts) == n, "NonbondedForce: particle count mismatch"
+            t["charge"] = [F(p_, "q") for p_ in parts]
+            t["sigma"] = [F(p_, "sig") for p_ in parts]
+            t["epsilon"] = [F(p_, "eps") for p_ in parts]
+            exc = force.find("Exceptions")
+            for e in (exc.findall("Exception") if exc is not None else []):
+                t["exc_idx"].append((I(e, "p1"), I(e, "p2")))
+                t["exc_par"].append((F(e, "q"), F(e, "sig"), F(e, "eps")))
+            method = int(force.attrib.get("method", "0"))
+            if method == 1:
+                opts["cutoff"] = float(force.attrib["cutoff"])
+                opts["rf_dielectric"] = float(force.attrib.get("rfDielectric", 78.3))
+            elif method != 0:
+                raise NotImplementedError(f"NonbondedForce method {method}: only NoCutoff / CutoffNonPeriodic are built")
+        elif kind == "GBSAOBCForce":
+            parts = force.find("Particles").findall("Particle")
+            t["gb_radius"] = [F(p_, "r") for p_ in parts]
+            t["gb_scale"] = [F(p_, "scale") for p_ in parts]
+            opts["gb_solute_dielectric"] = float(force.attrib.get("soluteDielectric", 1.0))
+            opts["gb_solvent_dielectric"] = float(force.attrib.get("solventDielectric", 78.5))
+            opts["gb_surface_area_factor"] = 4 * np.pi * float(force.attrib.get("surfaceAreaEnergy", 2.25936))
+        elif kind == "CustomGBForce":
+            names = [e.attrib["name"] for e in force.find("PerParticleParameters").findall("Parameter")]
+            if names[:3] != ["charge", "or", "sr"]:
+                raise NotImplementedError(f"CustomGBForce with per-particle parameters {names}: only the OBC1 layout is built")
+            parts = force.find("Particles").findall("Particle")
+            orad = np.array([F(p_, "param2") for p_ in parts])
+            srad = np.array([F(p_, "param3") for p_ in parts])
+            t["gb_radius"], t["gb_scale"] = (orad + 0.009).tolist(), (srad / orad).tolist()
+            glob = {e.attrib["name"]: float(e.attrib["default"]) for e in force.find("GlobalParameters").findall("Parameter")}
+            opts["gb_solute_dielectric"] = glob.get("soluteDielectric", 1.0)
+            opts["gb_solvent_dielectric"] = glob.get("solventDielectric", 78.5)
+        elif kind in ("CMMotionRemover", "MonteCarloBarostat", "AndersenThermostat"):
+            continue
+        else:
+            raise NotImplementedError(f"OpenMM force '{kind}' is not built into pita_ff_logp_force")
+    if "charge" not in t:
+        raise ValueError("no NonbondedForce in the serialized System")
+    return {k: np.asarray(v) for k, v in t.items()}, opts
+
+
 class ForceFieldEnergy(BaseMoleculeEnergy):
     def __init__(self, tables, n_particles, spatial_dim=3, temperature=300.0, data_normalization_factor=1.0,
                  cutoff=None, rf_dielectric=78.3, device="cuda", is_molecule=True, gb_solute_dielectric=1.0,
@@ -48,6 +123,14 @@ class ForceFieldEnergy(BaseMoleculeEnergy):
             assert self._t["gb_radius"].shape[0] == n_particles and self._t["gb_scale"].shape[0] == n_particles
         self._gb_par = (float(gb_solute_dielectric), float(gb_solvent_dielectric), float(gb_surface_area_factor))
         self._handle = None
+
+    @classmethod
+    def from_openmm_xml(cls, source, temperature=300.0, data_normalization_factor=0.1640, **kw):
+        """Target from the serialized OpenMM ``System`` of the reference's ALPEnergy (alp_energy.py:93-100)."""
+        tables, opts = tables_from_openmm_xml(source)
+        opts.update(kw)
+        return cls(tables, n_particles=len(tables["charge"]), temperature=temperature,
+                   data_normalization_factor=data_normalization_factor, **opts)
 
     def _native(self):
         if self._handle is None:

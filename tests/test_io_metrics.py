@@ -43,3 +43,45 @@ def test_w2_matches_oracle():
     assert abs(d["t/energy_w2"] - O.w2_1d(a, b)) < 1e-9
     assert abs(metrics._w_1d(torch.tensor(a[:500]), torch.tensor(b), 2) ** 0.5 - O.w2_1d(a[:500], b)) < 1e-9
     assert d["t/num_cropped"] == 0
+
+
+def test_openmm_system_xml_tables_roundtrip(tmp_path):
+    """tables_from_openmm_xml on a hand-written file in OpenMM's XmlSerializer layout (CPU: parsing only)."""
+    import numpy as np
+
+    from pita_amd.alp_energy import tables_from_openmm_xml
+
+    xml = """<?xml version="1.0" ?>
+<System openmmVersion="8.1" type="System" version="1">
+ <PeriodicBoxVectors><A x="2" y="0" z="0"/><B x="0" y="2" z="0"/><C x="0" y="0" z="2"/></PeriodicBoxVectors>
+ <Particles><Particle mass="12.01"/><Particle mass="1.008"/><Particle mass="14.01"/><Particle mass="16"/></Particles>
+ <Constraints/>
+ <Forces>
+  <Force forceGroup="0" name="HarmonicBondForce" type="HarmonicBondForce" usesPeriodic="0" version="2">
+   <Bonds><Bond d=".109" k="284512" p1="0" p2="1"/><Bond d=".1335" k="410031" p1="0" p2="2"/></Bonds></Force>
+  <Force forceGroup="0" type="HarmonicAngleForce" usesPeriodic="0" version="2">
+   <Angles><Angle a="2.0944" k="418.4" p1="1" p2="0" p3="2"/></Angles></Force>
+  <Force forceGroup="0" type="PeriodicTorsionForce" usesPeriodic="0" version="2">
+   <Torsions><Torsion k="10.46" p1="1" p2="0" p3="2" p4="3" periodicity="2" phase="3.14159265"/></Torsions></Force>
+  <Force alpha="0" cutoff="2" dispersionCorrection="1" forceGroup="0" method="1" rfDielectric="1" type="NonbondedForce" version="4">
+   <GlobalParameters/><ParticleOffsets/><ExceptionOffsets/>
+   <Particles><Particle eps=".4577" q=".5973" sig=".33997"/><Particle eps=".0657" q=".1123" sig=".26495"/>
+    <Particle eps=".7113" q="-.4157" sig=".325"/><Particle eps=".8786" q="-.5679" sig=".29599"/></Particles>
+   <Exceptions><Exception eps="0" p1="0" p2="1" q="0" sig="1"/><Exception eps=".1" p1="1" p2="3" q="-.053" sig=".28"/></Exceptions></Force>
+  <Force cutoff="2" forceGroup="0" method="1" soluteDielectric="1" solventDielectric="78.5" surfaceAreaEnergy="2.25936" type="GBSAOBCForce" version="2">
+   <Particles><Particle q=".5973" r=".17" scale=".72"/><Particle q=".1123" r=".13" scale=".85"/>
+    <Particle q="-.4157" r=".155" scale=".79"/><Particle q="-.5679" r=".15" scale=".85"/></Particles></Force>
+  <Force forceGroup="0" frequency="1" type="CMMotionRemover" version="1"/>
+ </Forces>
+</System>"""
+    path = tmp_path / "system.xml"
+    path.write_text(xml)
+    for src in (str(path), xml):
+        t, o = tables_from_openmm_xml(src)
+        assert t["bond_idx"].tolist() == [[0, 1], [0, 2]] and np.allclose(t["bond_par"][1], [0.1335, 410031])
+        assert t["angle_idx"].tolist() == [[1, 0, 2]] and np.allclose(t["angle_par"][0], [2.0944, 418.4])
+        assert t["tors_idx"].tolist() == [[1, 0, 2, 3]] and np.allclose(t["tors_par"][0], [2, 3.14159265, 10.46])
+        assert np.allclose(t["charge"], [0.5973, 0.1123, -0.4157, -0.5679]) and np.allclose(t["sigma"][2], 0.325)
+        assert t["exc_idx"].tolist() == [[0, 1], [1, 3]] and np.allclose(t["exc_par"][1], [-0.053, 0.28, 0.1])
+        assert np.allclose(t["gb_radius"], [0.17, 0.13, 0.155, 0.15]) and np.allclose(t["gb_scale"][0], 0.72)
+        assert o["cutoff"] == 2.0 and o["rf_dielectric"] == 1.0 and abs(o["gb_surface_area_factor"] - 28.3919551) < 1e-4
