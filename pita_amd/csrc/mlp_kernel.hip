@@ -21,6 +21,8 @@ struct MlpParams {
   const unsigned* w0;   // [NB][KC] blocks of MAT_W words: bf16 three-way split fragments ([piece][k-step][lane][4])
   const unsigned* wl;   // [L][NB][NB] blocks
   const unsigned* wf;   // [NBO][NB] blocks
+  const unsigned* stream;  // all blocks once more in the order mlp_tile consumes them (null: emb_size/2 % 32 != 0)
+  int S;
   const float* b0;   // [NB][32]  fragment order
   const float* bl;   // [L][NB][32]
   const float* bf;   // [NBO][32]
@@ -42,14 +44,92 @@ __device__ __forceinline__ f32x16 mlp_bias(const float* b, int hh) {
   return r;
 }
 
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 rounding level) on v_rcp / v_exp: the library erff
+// and sincosf (range reduction of angles up to ~1e4 rad) were 3/4 of the kernel's instructions
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float pl = 1.061405429f;
+  pl = fmaf(pl, t, -1.453152027f);
+  pl = fmaf(pl, t, 1.421413741f);
+  pl = fmaf(pl, t, -0.284496736f);
+  pl = fmaf(pl, t, 0.254829592f);
+  const float r = 1.0f - (pl * t) * __builtin_amdgcn_exp2f(-1.44269504088896341f * ax * ax);
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752f)); }
+
+// sin and cos of an fp32 angle in radians: the angle itself is the reference's fp32 value; its reduction to one
+// revolution is done in fp64 (exact to 1e-13 rev for |angle| < 1e5), then the transcendental unit evaluates
+// sin / cos of revolutions (absolute error ~1e-6, two orders below the sensitivity of sin to the fp32 rounding of such
+// angles)
+__device__ __forceinline__ void sincos_rev(float ang, float& sn, float& cs) {
+  const double r = (double)ang * 0.15915494309189535;
+  const float f = (float)(r - floor(r));
+  sn = __builtin_amdgcn_sinf(f);
+  cs = __builtin_amdgcn_cosf(f);
+}
+
+// ---- where a tile's weight blocks come from
+// GlobalWeights: every wave streams its own copy of each block from L2 (600 KB per 32-walker tile-pass for the
+//   128-wide net: the limit of the first version at large batches).
+// StreamWeights: the four waves of a workgroup walk the same block sequence in lock step; each block is fetched once
+//   per workgroup -- global -> registers while the previous block's MFMAs run, -> LDS, one barrier -- and read from LDS
+//   by all four waves (double buffered).  The host packs the blocks in consumption order (`stream`).
+struct GlobalWeights {
+  const MlpParams& p;
+  int lane;
+  __device__ __forceinline__ WFrag<1> fetch(const unsigned* base, int idx) {
+    WFrag<1> w;
+    w.load(nullptr, base, idx, lane);
+    return w;
+  }
+  __device__ __forceinline__ void done() {}
+};
+
+struct StreamWeights {
+  const unsigned* stream;  // [S][MAT_W]
+  unsigned* buf;           // LDS [2][MAT_W]
+  int S, s, cur, tid, lane;
+  uint2 pre[3];
+  __device__ __forceinline__ void prime() {
+    const uint2* g = reinterpret_cast<const uint2*>(stream);
+    uint2* l = reinterpret_cast<uint2*>(buf);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) l[tid + 256 * q] = g[tid + 256 * q];
+    s = 0;
+    cur = 0;
+    __syncthreads();
+  }
+  __device__ __forceinline__ WFrag<1> fetch(const unsigned*, int) {
+    const int nxt = (s + 1 == S) ? 0 : s + 1;
+    const uint2* g = reinterpret_cast<const uint2*>(stream + (size_t)nxt * MAT_W);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) pre[q] = g[tid + 256 * q];  // in flight while this block's MFMAs run
+    WFrag<1> w;
+    const u32x4* pl = reinterpret_cast<const u32x4*>(buf + cur * MAT_W) + lane;
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) w.w[pc][st] = pl[(pc * 2 + st) * 64];
+    return w;
+  }
+  __device__ __forceinline__ void done() {
+    uint2* l = reinterpret_cast<uint2*>(buf + (cur ^ 1) * MAT_W);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) l[tid + 256 * q] = pre[q];
+    __syncthreads();  // next block visible; everybody has read the current one
+    cur ^= 1;
+    s = (s + 1 == S) ? 0 : s + 1;
+  }
+};
 
 // One 32-walker tile through the network.  xrow: this lane's walker coordinates [input_dim] (global or LDS), used as
 // xrow[var] * xscale (xscale = c_in of the EDM preconditioning in the fused sampler, 1 in the plain forward: x * 1.0f
 // is exact); emit(row, value) receives output row `row` of this lane's walker from the lane that holds it.
-template <int NB, typename Emit>
-__device__ __forceinline__ void mlp_tile(const MlpParams& p, int lane, int hh, const float* xrow, float xscale, float tv,
-                                         float bv, Emit&& emit) {
+template <int NB, typename Weights, typename Emit>
+__device__ __forceinline__ void mlp_tile(const MlpParams& p, Weights& W, int lane, int hh, const float* xrow, float xscale,
+                                         float tv, float bv, Emit&& emit) {
   const int half = p.emb >> 1;
   // ---- layer 0: GELU(W0 . [emb(x_0) .. emb(x_{D-1}), emb(t), (emb(beta))] + b0)
   f32x16 z[NB];
@@ -60,9 +140,9 @@ __device__ __forceinline__ void mlp_tile(const MlpParams& p, int lane, int hh, c
     WFrag<1>::split(e, es);  // one split per chunk, shared by the NB output blocks
 #pragma unroll
     for (int ob = 0; ob < NB; ++ob) {
-      WFrag<1> w;
-      w.load(nullptr, p.w0, ob * p.KC + kc, lane);
+      const WFrag<1> w = W.fetch(p.w0, ob * p.KC + kc);
       z[ob] = w.mul_split(es, z[ob]);
+      W.done();
     }
   };
   auto input_of = [&](int var, float& v, float& scale) {
@@ -84,7 +164,7 @@ __device__ __forceinline__ void mlp_tile(const MlpParams& p, int lane, int hh, c
       for (int r = 0; r < 16; ++r) {
         const int idx = c * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
         float sn, cs;
-        sincosf((v * scale) * p.freqs[idx], &sn, &cs);
+        sincos_rev((v * scale) * p.freqs[idx], sn, cs);
         es_[r] = sn;
         ec_[r] = cs;
       }
@@ -100,8 +180,9 @@ __device__ __forceinline__ void mlp_tile(const MlpParams& p, int lane, int hh, c
         const int var = f / p.emb, idx = f - var * p.emb;
         float v, scale;
         input_of(var, v, scale);
-        const float ang = (v * scale) * p.freqs[idx < half ? idx : idx - half];
-        e[r] = idx < half ? sinf(ang) : cosf(ang);
+        float sn, cs;
+        sincos_rev((v * scale) * p.freqs[idx < half ? idx : idx - half], sn, cs);
+        e[r] = idx < half ? sn : cs;
       }
       feed(e, kc);
     }
@@ -121,9 +202,9 @@ __device__ __forceinline__ void mlp_tile(const MlpParams& p, int lane, int hh, c
       WFrag<1>::split(z[kb], zs);
 #pragma unroll
       for (int ob = 0; ob < NB; ++ob) {
-        WFrag<1> w;
-        w.load(nullptr, p.wl, (l * NB + ob) * NB + kb, lane);
+        const WFrag<1> w = W.fetch(p.wl, (l * NB + ob) * NB + kb);
         nz[ob] = w.mul_split(zs, nz[ob]);
+        W.done();
       }
     }
 #pragma unroll
@@ -136,9 +217,9 @@ __device__ __forceinline__ void mlp_tile(const MlpParams& p, int lane, int hh, c
     f32x16 o = mlp_bias(p.bf + ob * 32, hh);
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
-      WFrag<1> w;
-      w.load(nullptr, p.wf, ob * NB + kb, lane);
+      const WFrag<1> w = W.fetch(p.wf, ob * NB + kb);
       o = w.mul(z[kb], o);
+      W.done();
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -148,16 +229,22 @@ __device__ __forceinline__ void mlp_tile(const MlpParams& p, int lane, int hh, c
   }
 }
 
-template <int NB>
-__global__ void __launch_bounds__(256) mlp_kernel(MlpParams p) {
+template <int NB, bool STREAM>
+__global__ void __launch_bounds__(256, 2) mlp_kernel(MlpParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned wbuf[STREAM ? 2 * MAT_W : 4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cl = lane & 31, hh = lane >> 5;
-  const long long ntile = (p.B + 31) / 32;
-  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntile; tile += (long long)gridDim.x * 4) {
+  const long long ntile = (p.B + 31) / 32, ngroup = (ntile + 3) / 4;
+  StreamWeights SW{p.stream, wbuf, p.S, 0, 0, (int)threadIdx.x, lane, {}};
+  GlobalWeights GW{p, lane};
+  if (STREAM) SW.prime();
+  for (long long grp = blockIdx.x; grp < ngroup; grp += gridDim.x) {  // block-uniform trip count (barriers inside)
+    const long long tile = grp * 4 + wave;
     const long long wid = tile * 32 + cl;
     const bool valid = wid < p.B;
     const long long wl = valid ? wid : p.B - 1;
-    mlp_tile<NB>(p, lane, hh, p.x + wl * p.input_dim, 1.0f, p.t[wl], p.beta ? p.beta[wl] : 0.f,
-                 [&](int row, float v) { if (valid) p.out[wid * p.out_dim + row] = v; });
+    auto emit = [&](int row, float v) { if (valid) p.out[wid * p.out_dim + row] = v; };
+    if (STREAM) mlp_tile<NB>(p, SW, lane, hh, p.x + wl * p.input_dim, 1.0f, p.t[wl], p.beta ? p.beta[wl] : 0.f, emit);
+    else mlp_tile<NB>(p, GW, lane, hh, p.x + wl * p.input_dim, 1.0f, p.t[wl], p.beta ? p.beta[wl] : 0.f, emit);
   }
 }
 
@@ -178,18 +265,23 @@ struct MlpSamplerParams {
 
 __device__ __forceinline__ void mlp_wave_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <int NB>
-__global__ void __launch_bounds__(256) mlp_sampler_kernel(MlpSamplerParams q) {
+template <int NB, bool STREAM>
+__global__ void __launch_bounds__(256, 2) mlp_sampler_kernel(MlpSamplerParams q) {
   extern __shared__ float sm[];
+  __shared__ __attribute__((aligned(16))) unsigned wbuf[STREAM ? 2 * MAT_W : 4];
   const MlpParams& p = q.m;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cl = lane & 31, hh = lane >> 5;
   const int D = p.input_dim;
   float* xs = sm + wave * 2 * 32 * D;  // [32][D] walkers of this wave
   float* fs = xs + 32 * D;             // [32][D] network output F
-  const long long ntile = (p.B + 31) / 32;
-  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntile; tile += (long long)gridDim.x * 4) {
+  const long long ntile = (p.B + 31) / 32, ngroup = (ntile + 3) / 4;
+  StreamWeights SW{p.stream, wbuf, p.S, 0, 0, (int)threadIdx.x, lane, {}};
+  GlobalWeights GW{p, lane};
+  if (STREAM) SW.prime();
+  for (long long grp = blockIdx.x; grp < ngroup; grp += gridDim.x) {  // block-uniform trip count (barriers inside)
+    const long long tile = grp * 4 + wave;
     const long long w0 = tile * 32;
-    const int nw = (int)((p.B - w0) < 32 ? (p.B - w0) : 32);
+    const int nw = (w0 >= p.B) ? 0 : (int)((p.B - w0) < 32 ? (p.B - w0) : 32);
     for (int i = lane; i < 32 * D; i += 64) xs[i] = (i < nw * D) ? q.x[w0 * D + i] : 0.f;
     mlp_wave_fence();
     const long long wid = w0 + cl;
@@ -200,7 +292,9 @@ __global__ void __launch_bounds__(256) mlp_sampler_kernel(MlpSamplerParams q) {
       const float c_s = st[PITA_ST_CS], c_in = st[PITA_ST_CIN], c_out = st[PITA_ST_COUT], hv = st[PITA_ST_H];
       const float g2 = st[PITA_ST_G2], gamma = st[PITA_ST_GAMMA], dt = st[PITA_ST_DT];
       const float noise_scale = st[PITA_ST_NOISE_SCALE], sqrt_dt = st[PITA_ST_SQRT_DT];
-      mlp_tile<NB>(p, lane, hh, xrow, c_in, st[PITA_ST_CNOISE], st[PITA_ST_BETA], [&](int row, float v) { frow[row] = v; });
+      auto emit = [&](int row, float v) { frow[row] = v; };
+      if (STREAM) mlp_tile<NB>(p, SW, lane, hh, xrow, c_in, st[PITA_ST_CNOISE], st[PITA_ST_BETA], emit);
+      else mlp_tile<NB>(p, GW, lane, hh, xrow, c_in, st[PITA_ST_CNOISE], st[PITA_ST_BETA], emit);
       mlp_wave_fence();
       for (int var = hh; var < D; var += 2) {
         const float xv = xrow[var];
@@ -271,10 +365,14 @@ extern "C" int pita_mlp_create(pita_mlp_t** out, const pita_mlp_config* cfg, con
   const int NB = H / 32, KC = C / 32, NBO = (cfg->out_dim + 31) / 32;
   const size_t n_w0 = (size_t)NB * KC * MAT_W, n_wl = (size_t)L * NB * NB * MAT_W, n_wf = (size_t)NBO * NB * MAT_W;
   const size_t n_b0 = (size_t)NB * 32, n_bl = (size_t)L * NB * 32, n_bf = (size_t)NBO * 32, n_fr = E / 2;
-  const size_t total = n_w0 + n_wl + n_wf + n_b0 + n_bl + n_bf + n_fr;
+  const bool streamable = ((E / 2) % 32) == 0;  // pure sine / cosine chunks: the order mlp_tile consumes blocks is fixed
+  const int S = NB * KC + L * NB * NB + NBO * NB;
+  const size_t n_st = streamable ? (size_t)S * MAT_W : 0;
+  const size_t total = n_w0 + n_wl + n_wf + n_b0 + n_bl + n_bf + n_fr + n_st;
   float* h = new float[total]();
   float* h_w0 = h; float* h_wl = h_w0 + n_w0; float* h_wf = h_wl + n_wl;
   float* h_b0 = h_wf + n_wf; float* h_bl = h_b0 + n_b0; float* h_bf = h_bl + n_bl; float* h_fr = h_bf + n_bf;
+  float* h_st = h_fr + n_fr;
   // one 32x32 block as bf16 three-way truncation-split MFMA fragments: word q of (piece, k-step st, lane) packs the
   // pieces of elements r = 8 st + 2 q (low half) and r + 1 (high half); same layout as the EGNN weights
   auto trunc16 = [](float v) { unsigned u; memcpy(&u, &v, 4); u &= 0xFFFF0000u; float o; memcpy(&o, &u, 4); return o; };
@@ -324,6 +422,21 @@ extern "C" int pita_mlp_create(pita_mlp_t** out, const pita_mlp_config* cfg, con
     pack_bias(h_bf + ob * 32, Bf, cfg->out_dim, ob);
   }
   for (size_t i = 0; i < n_fr; ++i) h_fr[i] = freqs[i];
+  if (streamable) {  // the blocks once more, in mlp_tile's consumption order (see StreamWeights)
+    float* dst = h_st;
+    auto put = [&](const float* blk) { memcpy(dst, blk, sizeof(float) * MAT_W); dst += MAT_W; };
+    const int hc = (E / 2) / 32, per_var = 2 * hc;
+    for (int kc = 0; kc < KC; ++kc) {
+      if (kc % per_var >= hc) continue;
+      for (int ob = 0; ob < NB; ++ob) put(h_w0 + ((size_t)ob * KC + kc) * MAT_W);
+      for (int ob = 0; ob < NB; ++ob) put(h_w0 + ((size_t)ob * KC + kc + hc) * MAT_W);
+    }
+    for (int l = 0; l < L; ++l)
+      for (int kb = 0; kb < NB; ++kb)
+        for (int ob = 0; ob < NB; ++ob) put(h_wl + (((size_t)l * NB + ob) * NB + kb) * MAT_W);
+    for (int ob = 0; ob < NBO; ++ob)
+      for (int kb = 0; kb < NB; ++kb) put(h_wf + ((size_t)ob * NB + kb) * MAT_W);
+  }
   pita_mlp* net = new pita_mlp();
   net->cfg = *cfg;
   hipError_t e = hipMalloc(&net->d_all, total * sizeof(float));
@@ -337,6 +450,8 @@ extern "C" int pita_mlp_create(pita_mlp_t** out, const pita_mlp_config* cfg, con
   MlpParams& p = net->p;
   p.w0 = reinterpret_cast<const unsigned*>(net->d_all); p.wl = p.w0 + n_w0; p.wf = p.wl + n_wl;
   p.b0 = net->d_all + n_w0 + n_wl + n_wf; p.bl = p.b0 + n_b0;
+  p.stream = streamable ? reinterpret_cast<const unsigned*>(net->d_all + n_w0 + n_wl + n_wf + n_b0 + n_bl + n_bf + n_fr) : nullptr;
+  p.S = S;
   p.bf = p.bl + n_bl; p.freqs = p.bf + n_bf;
   p.input_dim = cfg->input_dim; p.out_dim = cfg->out_dim; p.n_layers = L; p.emb = E;
   p.temp = cfg->temperature_conditioned; p.KC = KC; p.NBO = NBO;
@@ -361,10 +476,15 @@ extern "C" int pita_mlp_forward(pita_mlp_t* net, const float* t, const float* x,
   const long long nblk = ((B + 31) / 32 + 3) / 4;
   const unsigned grid = (unsigned)(nblk < 4096 ? nblk : 4096);
   hipStream_t s = (hipStream_t)stream;
-  switch (net->cfg.hidden_size / 32) {
-    case 1: hipLaunchKernelGGL(mlp_kernel<1>, dim3(grid), dim3(256), 0, s, p); break;
-    case 2: hipLaunchKernelGGL(mlp_kernel<2>, dim3(grid), dim3(256), 0, s, p); break;
-    default: hipLaunchKernelGGL(mlp_kernel<4>, dim3(grid), dim3(256), 0, s, p); break;
+  const int nb = net->cfg.hidden_size / 32;
+  if (p.stream) {
+    if (nb == 1) hipLaunchKernelGGL((mlp_kernel<1, true>), dim3(grid), dim3(256), 0, s, p);
+    else if (nb == 2) hipLaunchKernelGGL((mlp_kernel<2, true>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((mlp_kernel<4, true>), dim3(grid), dim3(256), 0, s, p);
+  } else {
+    if (nb == 1) hipLaunchKernelGGL((mlp_kernel<1, false>), dim3(grid), dim3(256), 0, s, p);
+    else if (nb == 2) hipLaunchKernelGGL((mlp_kernel<2, false>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((mlp_kernel<4, false>), dim3(grid), dim3(256), 0, s, p);
   }
   PITA_LAUNCH_CHECK();
   return PITA_OK;
@@ -388,10 +508,15 @@ extern "C" int pita_mlp_sampler_run(pita_mlp_t* net, float* x, int64_t B, const 
   const unsigned grid = (unsigned)(nblk < 4096 ? nblk : 4096);
   const size_t lds = sizeof(float) * 4 * 2 * 32 * (size_t)D;
   hipStream_t s = (hipStream_t)stream;
-  switch (net->cfg.hidden_size / 32) {
-    case 1: hipLaunchKernelGGL(mlp_sampler_kernel<1>, dim3(grid), dim3(256), lds, s, q); break;
-    case 2: hipLaunchKernelGGL(mlp_sampler_kernel<2>, dim3(grid), dim3(256), lds, s, q); break;
-    default: hipLaunchKernelGGL(mlp_sampler_kernel<4>, dim3(grid), dim3(256), lds, s, q); break;
+  const int nb = net->cfg.hidden_size / 32;
+  if (q.m.stream) {
+    if (nb == 1) hipLaunchKernelGGL((mlp_sampler_kernel<1, true>), dim3(grid), dim3(256), lds, s, q);
+    else if (nb == 2) hipLaunchKernelGGL((mlp_sampler_kernel<2, true>), dim3(grid), dim3(256), lds, s, q);
+    else hipLaunchKernelGGL((mlp_sampler_kernel<4, true>), dim3(grid), dim3(256), lds, s, q);
+  } else {
+    if (nb == 1) hipLaunchKernelGGL((mlp_sampler_kernel<1, false>), dim3(grid), dim3(256), lds, s, q);
+    else if (nb == 2) hipLaunchKernelGGL((mlp_sampler_kernel<2, false>), dim3(grid), dim3(256), lds, s, q);
+    else hipLaunchKernelGGL((mlp_sampler_kernel<4, false>), dim3(grid), dim3(256), lds, s, q);
   }
   PITA_LAUNCH_CHECK();
   return PITA_OK;
