@@ -421,6 +421,45 @@ def test_post_processing_golden(pa, golden):
     assert rel(xa, g["x_mala_adaptive"]) < 1e-5
 
 
+def test_mala_sets_non_finite_walkers_aside(pa, golden):
+    """Quirk Q7 (sde_integration.py:366-369,400): walkers whose target log-density is not finite are taken out before
+    the chain and re-appended AFTER the valid ones (order not preserved); the chain itself runs on the valid rows with
+    the acceptance rate computed over them."""
+    g = golden("post_lj13.npz")
+    e = pa.LennardJonesEnergy(39, 13, 3)
+    x0 = torch.as_tensor(g["x0"], dtype=torch.float32)
+    B = x0.shape[0]
+    bad = torch.tensor([1, 7, B - 1])
+    x = x0.clone()
+    x[bad[0]] = float("nan")
+    x[bad[1], 5] = float("inf")
+    x[bad[2]] = torch.arange(39, dtype=torch.float32) * 3e19  # squared distances overflow -> logp = -inf
+    keep = torch.ones(B, dtype=torch.bool)
+    keep[bad] = False
+    nv = int(keep.sum())
+    steps, dt = 4, 4e-4
+    gen = torch.Generator().manual_seed(9)
+    noise = torch.randn(steps, nv, 39, generator=gen)
+    us = torch.rand(steps, nv, generator=gen)
+    integ = pa.WeightedSDEIntegrator(sde=None, num_integration_steps=1, start_resampling_step=0, end_resampling_step=1,
+                                     post_mcmc_steps=steps, dt_negative_time=dt)
+    out, rates = integ.metropolis_hastings_mala(x.cuda(), e, return_acceptance_rate=True, noise=noise.cuda(),
+                                                uniforms=us.cuda())
+    assert out.shape == x.shape and len(rates) == steps
+    tail = out[nv:].cpu()
+    assert torch.isnan(tail[0]).all() and torch.isinf(tail[1, 5]) and torch.equal(tail[2], x[bad[2]])
+    lf = lambda xx: O.lj_logp_force(xx, 13, 3)
+    xv = x0[keep].clone()
+    lp = O.lj_logp(xv, 13, 3)
+    want_rates = []
+    for k in range(steps):
+        xv, lp, acc = O.mala_step(xv, lp, lf, dt, noise[k], torch.log(us[k]))
+        xv = O.remove_mean(xv, 13, 3)
+        want_rates.append(float(acc.float().mean()))
+    np.testing.assert_allclose(rates, want_rates, atol=1e-7)
+    assert rel(out[:nv], xv) < 1e-5
+
+
 @pytest.mark.parametrize("target", ["lj13", "lj13_ragged", "lj55", "dw4"])
 @pytest.mark.parametrize("langevin", [False, True])
 def test_fused_descent_equals_per_step(pa, golden, target, langevin):
