@@ -170,6 +170,8 @@ class WeightedSDEIntegrator:
                                  inverse_temperature)
         tab = tab_h.to(dev)
         if noise is not None:
+            if tuple(noise.shape) != (N, Bg, x1.shape[1]):
+                raise ValueError(f"noise has shape {tuple(noise.shape)}, expected {(N, Bg, x1.shape[1])}")
             noise = _lib.dev_tensor(noise, "noise")[:, off:off + Bl].contiguous()
         key = self._key(0)
         self._runs += 1
@@ -347,6 +349,8 @@ class WeightedSDEIntegrator:
         nsteps = int(self.num_negative_time_steps)
         if noise is not None:
             noise = _lib.dev_tensor(noise, "noise")
+            if tuple(noise.shape) != (nsteps,) + tuple(x.shape):
+                raise ValueError(f"descent noise has shape {tuple(noise.shape)}, expected {(nsteps,) + tuple(x.shape)}")
         if fused and hasattr(energy_function, "fused_descent") and energy_function.fused_descent(
                 x, nsteps, dt, ns, sq, seed=key, walker_offset=walker_offset, step0=0,
                 remove_mean=self.should_mean_free, noise=noise) is not None:
@@ -396,11 +400,16 @@ class WeightedSDEIntegrator:
                 if Bv > 0:
                     _, grad = energy_function(x_valid, return_force=True)
                     nz = _lib.dev_tensor(noise[i], "noise") if noise is not None else None
+                    if nz is not None and tuple(nz.shape) != tuple(x_valid.shape):
+                        raise ValueError(f"MALA noise[{i}] has shape {tuple(nz.shape)}, expected {tuple(x_valid.shape)} "
+                                         "(one row per walker with a finite target log-density)")
                     _lib.check(L.pita_mala_propose(x_valid.data_ptr(), grad.data_ptr(), x_prop.data_ptr(), _lib.ptr(nz),
                                                    Bv, n, d, dt_dev.data_ptr(), key, walker_offset, i, st),
                                "pita_mala_propose")
                     logp_prop, grad_prop = energy_function(x_prop, return_force=True)
                     uu = _lib.dev_tensor(uniforms[i], "uniforms") if uniforms is not None else None
+                    if uu is not None and uu.numel() != Bv:
+                        raise ValueError(f"MALA uniforms[{i}] has {uu.numel()} entries, expected {Bv}")
                     _lib.check(L.pita_mala_accept(x_valid.data_ptr(), logp.data_ptr(), grad.data_ptr(), x_prop.data_ptr(),
                                                   logp_prop.data_ptr(), grad_prop.data_ptr(), _lib.ptr(uu), Bv, n, d,
                                                   dt_dev.data_ptr(), key, walker_offset, i, rm, count.data_ptr(), st),
