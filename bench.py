@@ -163,10 +163,34 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    # PITA_BENCH_ONE_DEVICE=1: rehearsal of the multi-rank control flow on a ONE-GPU box (all ranks share cuda:0, gloo
+    # with host staging instead of RCCL, which refuses two ranks on one device); its numbers mean nothing
+    rehearsal = world > 1 and os.environ.get("PITA_BENCH_ONE_DEVICE") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=dev)
+
+    def all_gather(dst, src):
+        if rehearsal:
+            host = torch.empty(dst.shape, dtype=dst.dtype)
+            torch.distributed.all_gather_into_tensor(host, src.cpu())
+            dst.copy_(host)
+        else:
+            torch.distributed.all_gather_into_tensor(dst, src)
+
+    def all_reduce_max(t):
+        if rehearsal:
+            h = t.cpu()
+            torch.distributed.all_reduce(h, op=torch.distributed.ReduceOp.MAX)
+            return h
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return t
 
     import pita_amd
 
@@ -209,15 +233,14 @@ def main():
         net.sampler_run(x, tab[s:s + chunk], chunk, seed=seed, walker_offset=rank * B, step0=s, remove_mean=True)
         evs[i + 1].record()
     if world > 1:  # X1: the only collective of the resampling-free path
-        torch.distributed.all_gather_into_tensor(gathered, x)
+        all_gather(gathered, x)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(all_reduce_max(t).item())
     launch_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(n_launch)]
     assert torch.isfinite(x).all(), "sampler produced non-finite walkers"
 
@@ -338,6 +361,7 @@ def main():
             out["debiased"] = debiased_leg(pita_amd, net, dev, B, with_cpu=not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if world > 1:
+        torch.distributed.barrier()  # rank 0 may still be in its force-kernel leg
         torch.distributed.destroy_process_group()
 
 
