@@ -708,6 +708,7 @@ def test_vjp_vs_oracle(pa, golden):
         v = torch.randn(B, n * d, generator=gen)
         _, Jv = net.jvp(h.cuda(), x.cuda(), beta.cuda(), vx=v.cuda(), want_primal=False)
         _, JTc = net.vjp(h.cuda(), x.cuda(), beta.cuda(), cot=cot.cuda(), want_primal=False)
+        assert torch.equal(JTc, net.vjp(h.cuda(), x.cuda(), beta.cuda(), cot=cot.cuda(), want_primal=False)[1])  # reproducible
         lhs, rhs = (cot.cuda() * Jv).sum(1), (JTc * v.cuda()).sum(1)
         np.testing.assert_allclose(lhs.cpu().numpy(), rhs.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(lhs.abs().mean()))
 
