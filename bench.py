@@ -349,6 +349,9 @@ def main():
                          "note": "fp32-accurate dense layers run as exact 3-way bf16 splits on the bf16 matrix pipe; "
                                  "algorithmic flops count the reference's un-split first edge layer, so frac can exceed 1; "
                                  "the kernel is VALU-issue-bound (activations + operand splits), see DESIGN.md",
+                         "traffic_note": "x is read once and written once per launch (20.4 MB at 65 536 walkers); everything else "
+                                         "in `traffic` is register-spill scratch (468 B/lane, outside the edge loop) going "
+                                         "to L2 / Infinity Cache at ~0.35 TB/s of the 8 TB/s available",
                          "algorithmic_flop_per_walker_step": FLOP_PER_WALKER_STEP, "ms_per_launch": avg_ms,
                          "launches": n_launch},
             "roofline_force": force_rl,
