@@ -212,21 +212,11 @@ class WeightedSDEIntegrator:
         # log-weights are identically zero here; a stride-0 view avoids N*B*4 bytes (reference stacks N copies)
         logweights = torch.zeros(1, Bg, device=dev).expand(N, Bg)
 
-        if self.resample_at_end and did_resampling:  # :158-183
-            t_end = times[min(self.end_resampling_step, N - 1)]
-            xg = comm.all_gather(x)
-            tb = torch.full((xg.shape[0],), float(t_end), device=dev)
-            target_logprob = energy_function(xg)
-            h_t = self.sde.noise_schedule.h(tb)
-            model_energy = self.sde.energy_net.forward_energy(h_t, xg, inverse_temperature)
-            a_next = target_logprob - (-model_energy * _scalar(annealing_factor_schedule.gamma(t_end)))
-            a_next = _quantile_clamp(a_next, 0.9)
-            u = next(u_iter) if u_iter is not None else None
-            ids, _ = sample_cat_sys(xg.shape[0], a_next, u)
-            xg = gather_rows(xg, ids)
-            x = xg[off:off + Bl].clone()
+        if self.resample_at_end and did_resampling:
+            x, a_next, n_unique = self._resample_at_end(x, None, comm, times, energy_function, annealing_factor_schedule,
+                                                        inverse_temperature, u_iter, off, Bl)
             logweights = torch.cat([logweights, a_next[None]])
-            num_unique_idxs.append(int(torch.unique(ids).numel()))
+            num_unique_idxs.append(n_unique)
 
         if self.num_negative_time_steps > 0:
             x = self.negative_time_descent(x, energy_function, walker_offset=off)
@@ -289,18 +279,11 @@ class WeightedSDEIntegrator:
                 sde_terms_all.append(terms)
         logweights = torch.stack(logweights)
         did_resampling = resampling_interval != -1 and resampling_interval < N
-        if self.resample_at_end and did_resampling:  # :158-183
-            t_end = times[min(self.end_resampling_step, N - 1)]
-            xg, ag = comm.all_gather(x), comm.all_gather(a)
-            tb = torch.full((xg.shape[0],), float(t_end), device=dev)
-            model_energy = self.sde.energy_net.forward_energy(self.sde.noise_schedule.h(tb), xg, beta)
-            a_next = energy_function(xg) + model_energy * _scalar(gamma_schedule.gamma(t_end)) + ag
-            a_next = _quantile_clamp(a_next, 0.9)
-            u = next(u_iter) if u_iter is not None else None
-            ids, _ = sample_cat_sys(xg.shape[0], a_next, u)
-            x = gather_rows(xg, ids)[off:off + Bl].clone()
+        if self.resample_at_end and did_resampling:
+            x, a_next, n_unique = self._resample_at_end(x, a, comm, times, energy_function, gamma_schedule, beta, u_iter,
+                                                        off, Bl)
             logweights = torch.cat([logweights, a_next[None]])
-            num_unique_idxs.append(int(torch.unique(ids).numel()))
+            num_unique_idxs.append(n_unique)
         if self.num_negative_time_steps > 0:
             x = self.negative_time_descent(x, energy_function, walker_offset=off)
         acceptance_rate_list = []
@@ -310,6 +293,23 @@ class WeightedSDEIntegrator:
             x, acceptance_rate_list = fn(x, energy_function, return_acceptance_rate=True, walker_offset=off, comm=comm,
                                          **kw)
         return comm.all_gather(x), logweights, num_unique_idxs, sde_terms_all, acceptance_rate_list
+
+    def _resample_at_end(self, x, a, comm, times, energy_function, gamma_schedule, beta, u_iter, off, Bl):
+        """End-of-trajectory reweighting (sde_integration.py:158-183): a_next = log p_target(x) + gamma E_theta(h(t_end), x)
+        (+ the running log-weights a), clamped at its 0.9 quantile, then global systematic resampling.
+        Returns (local slice of the resampled walkers, a_next over the global batch, number of distinct parents)."""
+        t_end = times[min(self.end_resampling_step, self.num_integration_steps - 1)]
+        xg = comm.all_gather(x)
+        tb = torch.full((xg.shape[0],), float(t_end), device=xg.device)
+        model_energy = self.sde.energy_net.forward_energy(self.sde.noise_schedule.h(tb), xg, beta)
+        a_next = energy_function(xg) + model_energy * _scalar(gamma_schedule.gamma(t_end))
+        if a is not None:
+            a_next = a_next + comm.all_gather(a)
+        a_next = _quantile_clamp(a_next, 0.9)
+        u = next(u_iter) if u_iter is not None else None
+        ids, _ = sample_cat_sys(xg.shape[0], a_next, u)
+        x = gather_rows(xg, ids)[off:off + Bl].clone()
+        return x, a_next, int(torch.unique(ids).numel())
 
     # ------------------------------------------------------------------ A2-A4 steps [s0, s1)
     def _run_steps(self, model, x, tab, tab_h, s0, s1, noise, key, off, n, d, mean_free, beta, sde_terms_all):
