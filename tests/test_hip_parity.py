@@ -874,6 +874,47 @@ def test_final_histograms_match_oracle_sampler(pa, golden):
         assert hip_to_ref < 4 * seed_to_seed + 1e-3 * float(np.abs(ref[0][k]).mean()), (name, hip_to_ref, seed_to_seed)
 
 
+def test_not_debiased_resample_at_end(pa, golden):
+    """resample_at_end in the not-debiased regime (sde_integration.py:158-183 with a = 0): weights
+    log p_target(x) + gamma E_theta(h(t_end), x), 0.9-quantile clamp, systematic resampling -- against the oracle."""
+    import copy
+
+    from pita_amd.energy_net import EnergyNet
+
+    w = golden("egnn_weights_trainedlike.npz")
+    net = make_net(pa, 13, 3, w)
+    N, B, end, interval = 10, 24, 8, 4
+    sched = pa.ElucidatingNoiseSchedule(sigma_min=0.05, sigma_max=80.0, rho=7)
+    gam = pa.ConstantAnnealingFactorSchedule(4 / 3)
+    sde = pa.VEReverseSDE(noise_schedule=sched, score_net=pa.ScoreNet(net), energy_net=EnergyNet(copy.deepcopy(net)),
+                          debias_inference=False)
+    gen = torch.Generator().manual_seed(123)
+    x1 = O.remove_mean(torch.randn(B, 39, generator=gen) * 3, 13, 3)
+    noise = torch.randn(N, B, 39, generator=gen)
+    events = [s for s in range(0, end) if (s + 1) % interval == 0]
+    us = {s: float(torch.rand(1, generator=gen, dtype=torch.float64)) for s in events}
+    u_end = float(torch.rand(1, generator=gen, dtype=torch.float64))
+    integ = pa.WeightedSDEIntegrator(sde=sde, num_integration_steps=N, start_resampling_step=0, end_resampling_step=end,
+                                     resampling_interval=interval, num_negative_time_steps=0, post_mcmc_steps=0,
+                                     resample_at_end=True)
+    x, logw, uniq, _, _ = integ.integrate_sde(x1.cuda(), pa.LennardJonesEnergy(39, 13, 3), gam, inverse_temperature=1.0,
+                                              noise=noise.cuda(), resample_u=[us[s] for s in events] + [u_end])
+    wt = {k: T(v) for k, v in w.items()}
+    bb = lambda cn, xs, b: O.egnn_forward(wt, cn, xs, b, 13, 3)
+    osched, ogam = O.Elucidating(0.05, 80.0, 7), O.GammaConstant(4 / 3)
+    cfg = O.IntegratorConfig(num_integration_steps=N, start_resampling_step=0, end_resampling_step=end,
+                             resampling_interval=interval)
+    ref = O.integrate_sde(cfg, x1, lambda t, xc: O.f_not_debiased(bb, osched, ogam, t, xc, 1.0), osched.g,
+                          lambda i, shp: noise[i], 13, 3, uniform_fn=lambda s: us[s])
+    t_end = torch.linspace(1.0, 0.0, N + 1)[:-1][end]
+    xe, a_next, nu = O.resample_at_end(ref["x"], torch.zeros(B), t_end, lambda xx: O.lj_logp(xx, 13, 3),
+                                       lambda tb, xx: O.energy_theta(bb, osched.h(tb), xx, 1.0), 4 / 3, u_end)
+    assert logw.shape == (N + 1, B) and uniq == ref["num_unique"] + [nu]
+    # x differs by the rounding accumulated over 10 steps; r^-12 amplifies it 12-fold in the weights
+    np.testing.assert_allclose(logw[N].cpu().numpy(), a_next.numpy(), rtol=3e-3)
+    assert rel(x, xe) < 2e-4
+
+
 @pytest.mark.parametrize("start,end,interval", [(0, 12, -1), (3, 12, -1), (2, 9, 3), (0, 12, 1), (5, 7, 2)])
 def test_integrator_window_and_resampling_semantics(pa, golden, start, end, interval):
     """A2 gates (sde_integration.py:278-297): walkers frozen before start_resampling_step, resampling events only
