@@ -586,6 +586,40 @@ def test_full_size_lj55_config(pa, golden):
     assert rel(f[idx.cuda()], fo) < 2e-5
 
 
+def test_full_size_aldp_shape(pa, golden):
+    """BASELINE config C4 per-GPU shard: 22 atoms x 3D (alanine dipeptide), EGNN score net, 4 096 walkers, and a ragged
+    batch that leaves the last group partly filled; multi-step launch == the same steps one launch at a time."""
+    for B in (4096, 4099):
+        net, tab, x = _one_step_vs_oracle(pa, golden, 22, 3, B, 0.01, subset=12, seed=B)
+    xa = x.clone()
+    net.sampler_run(xa, tab[10:16].cuda().contiguous(), 6, seed=5, step0=10)
+    xb = x.clone()
+    for k in range(10, 16):
+        net.sampler_run(xb, tab[k:k + 1].cuda().contiguous(), 1, seed=5, step0=k)
+    assert torch.equal(xa, xb)
+
+
+def test_time_only_egnn_sampler(pa, golden):
+    """The time-only EGNN (egnn.py: in_node_nf = 1, no temperature conditioning) through the fused sampler: fused ==
+    step-by-step recording path, and one step against the oracle."""
+    g = golden("egnn_notemp_lj13_fwd.npz")
+    net = make_net(pa, 13, 3, {k[2:]: v for k, v in g.items() if k.startswith("w.")}, temp=False)
+    sched = pa.ElucidatingNoiseSchedule(sigma_min=0.05, sigma_max=80.0, rho=7)
+    sde = pa.VEReverseSDE(noise_schedule=sched, score_net=pa.ScoreNet(net), debias_inference=False)
+    N, B = 6, 37
+    gen = torch.Generator().manual_seed(4)
+    x1 = O.remove_mean(torch.randn(B, 39, generator=gen) * 4, 13, 3).cuda()
+    nz = torch.randn(N, B, 39, generator=gen).cuda()
+    mk = lambda rec: pa.WeightedSDEIntegrator(sde=sde, num_integration_steps=N, start_resampling_step=0,
+                                              end_resampling_step=N, resampling_interval=-1, num_negative_time_steps=0,
+                                              post_mcmc_steps=0, record_terms=rec)
+    gam = pa.ConstantAnnealingFactorSchedule(4 / 3)
+    e = pa.LennardJonesEnergy(39, 13, 3)
+    xa, *_ = mk(False).integrate_sde(x1, e, gam, noise=nz)
+    xb, *_ = mk(True).integrate_sde(x1, e, gam, noise=nz)
+    assert rel(xa, xb) < 2e-5 and not torch.equal(xa, x1)
+
+
 # ------------------------------------------------------------------------------- debiased regime (section 8(f) N1)
 def test_jvp_vs_oracle(pa, golden):
     """pita_egnn_jvp against torch.func.jvp of the fp64 oracle denoiser: x-directions, the h-direction, mixed."""
