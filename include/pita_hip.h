@@ -291,14 +291,17 @@ int pita_energy_theta(const float* h, const float* x, const float* F, const floa
  *            reference's float blend a*new + (1-a)*old; optional mean removal (is_molecule); *acc_count += #accepted.
  *            uniforms nullable -> Philox.
  *   adapt  : rate = acc_count / total -> rate_out (nullable); adaptive: dt *= 1.1 if rate > 0.55 else dt /= 1.1;
- *            acc_count is reset.  With several ranks all-reduce acc_count first and pass the global total. */
+ *            acc_count is reset.  With several ranks all-reduce acc_count first and pass the global total.
+ *   walker_ids (device int64[B], nullable): the Philox walker key of row w; NULL = walker_offset + w.  The chain runs on
+ *            the walkers with a finite log-density only (quirk Q7), i.e. on a compacted batch: keying by the original
+ *            global index keeps the noise of a walker independent of how many were set aside before it / on other ranks. */
 int pita_mala_propose(const float* x, const float* force, float* x_prop, const float* noise, int64_t B,
                       int n_particles, int n_dim, const double* dt_dev, uint64_t seed, uint64_t walker_offset,
-                      int64_t step, void* stream);
+                      const int64_t* walker_ids /*nullable*/, int64_t step, void* stream);
 int pita_mala_accept(float* x, float* logp, const float* force, const float* x_prop, const float* logp_prop,
                      const float* force_prop, const float* uniforms, int64_t B, int n_particles, int n_dim,
-                     const double* dt_dev, uint64_t seed, uint64_t walker_offset, int64_t step, int remove_mean,
-                     int* acc_count, void* stream);
+                     const double* dt_dev, uint64_t seed, uint64_t walker_offset, const int64_t* walker_ids /*nullable*/,
+                     int64_t step, int remove_mean, int* acc_count, void* stream);
 int pita_mala_adapt(double* dt_dev, int* acc_count, int64_t total, int adaptive, float* rate_out, void* stream);
 
 /* ---------------------------------------------------------------- resampling (K10, K11)

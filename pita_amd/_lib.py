@@ -92,9 +92,9 @@ _PROTOS = {
     "pita_edm_combine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "pita_energy_theta": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "pita_mala_propose": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_uint64,
-                                  c_uint64, c_int64, c_void_p]),
-    "pita_mala_accept": (c_int, [c_void_p] * 7 + [c_int64, c_int, c_int, c_void_p, c_uint64, c_uint64, c_int64, c_int,
-                                                  c_void_p, c_void_p]),
+                                  c_uint64, c_void_p, c_int64, c_void_p]),
+    "pita_mala_accept": (c_int, [c_void_p] * 7 + [c_int64, c_int, c_int, c_void_p, c_uint64, c_uint64, c_void_p, c_int64,
+                                                  c_int, c_void_p, c_void_p]),
     "pita_mala_adapt": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "pita_resample_workspace_bytes": (c_size_t, [c_int64]),
     "pita_systematic_resample": (c_int, [c_void_p, c_int64, c_double, c_void_p, c_void_p, c_void_p]),

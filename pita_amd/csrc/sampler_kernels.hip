@@ -22,6 +22,7 @@ struct ElemParams {
   unsigned long long seed, walker_offset;
   long long step;
   int remove_mean;
+  const long long* walker_ids;  // optional: Philox walker key of row w is walker_ids[w] instead of walker_offset + w
 };
 
 template <int DIM, int OP>
@@ -152,7 +153,8 @@ __global__ void __launch_bounds__(256) mala_propose_kernel(const float* __restri
 #pragma unroll
       for (int k = 0; k < DIM; ++k) xi[k] = noise[base + k];
     } else {
-      philox_normal4(p.seed, p.walker_offset + (unsigned long long)w, p.step, (uint32_t)i, xi);
+      philox_normal4(p.seed, p.walker_ids ? (unsigned long long)p.walker_ids[w] : p.walker_offset + (unsigned long long)w,
+                     p.step, (uint32_t)i, xi);
     }
 #pragma unroll
     for (int k = 0; k < DIM; ++k) x_prop[base + k] = (x[base + k] + hdt * force[base + k]) + sdt * xi[k];
@@ -204,7 +206,9 @@ __global__ void __launch_bounds__(256) mala_accept_kernel(float* __restrict__ x,
       const float lp = logp[w0 + w], lpp = logp_prop[w0 + w];
       const float ratio = (lpp - lp) + (lqb - lqf);
       const float u = uniforms ? uniforms[w0 + w]
-                               : philox_uniform(p.seed, p.walker_offset + (unsigned long long)(w0 + w), p.step, 0xFFFFFu);
+                               : philox_uniform(p.seed, p.walker_ids ? (unsigned long long)p.walker_ids[w0 + w]
+                                                                     : p.walker_offset + (unsigned long long)(w0 + w),
+                                                p.step, 0xFFFFFu);
       const float af = (logf(u) < ratio) ? 1.0f : 0.0f;
       logp[w0 + w] = af * lpp + (1.0f - af) * lp;
       flag[w] = af;
@@ -385,14 +389,14 @@ extern "C" int pita_gather_rows(const float* src, const int64_t* ids, float* out
 }
 
 extern "C" int pita_mala_propose(const float* x, const float* force, float* x_prop, const float* noise, int64_t B, int n,
-                                 int d, const double* dt_dev, uint64_t seed, uint64_t walker_offset, int64_t step,
-                                 void* stream) {
+                                 int d, const double* dt_dev, uint64_t seed, uint64_t walker_offset,
+                                 const int64_t* walker_ids, int64_t step, void* stream) {
   PITA_REQUIRE(B >= 0, "pita_mala_propose: negative batch");
   if (B == 0) return PITA_OK;
   PITA_REQUIRE(x && force && x_prop && dt_dev, "pita_mala_propose: null argument");
   PITA_REQUIRE(n >= 1 && n <= 256 && d >= 1 && d <= 3, "pita_mala_propose: n_particles in [1,256], n_dim in [1,3]");
   ElemParams p{};
-  p.seed = seed; p.walker_offset = walker_offset; p.step = step;
+  p.seed = seed; p.walker_offset = walker_offset; p.step = step; p.walker_ids = (const long long*)walker_ids;
   const long long nb = (B * n + 255) / 256;
   const unsigned grid = (unsigned)(nb < 8192 ? nb : 8192);
   hipStream_t s = (hipStream_t)stream;
@@ -407,8 +411,8 @@ extern "C" int pita_mala_propose(const float* x, const float* force, float* x_pr
 
 extern "C" int pita_mala_accept(float* x, float* logp, const float* force, const float* x_prop, const float* logp_prop,
                                 const float* force_prop, const float* uniforms, int64_t B, int n, int d,
-                                const double* dt_dev, uint64_t seed, uint64_t walker_offset, int64_t step, int remove_mean,
-                                int* acc_count, void* stream) {
+                                const double* dt_dev, uint64_t seed, uint64_t walker_offset, const int64_t* walker_ids,
+                                int64_t step, int remove_mean, int* acc_count, void* stream) {
   PITA_REQUIRE(B >= 0, "pita_mala_accept: negative batch");
   if (B == 0) return PITA_OK;
   PITA_REQUIRE(x && logp && force && x_prop && logp_prop && force_prop && dt_dev && acc_count,
@@ -416,6 +420,7 @@ extern "C" int pita_mala_accept(float* x, float* logp, const float* force, const
   PITA_REQUIRE(n >= 1 && n <= 256 && d >= 1 && d <= 3, "pita_mala_accept: n_particles in [1,256], n_dim in [1,3]");
   ElemParams p{};
   p.seed = seed; p.walker_offset = walker_offset; p.step = step; p.remove_mean = remove_mean;
+  p.walker_ids = (const long long*)walker_ids;
   const int WB = 256 / n;
   const long long nblk = (B + WB - 1) / WB;
   const unsigned grid = (unsigned)(nblk < 256LL * 16 ? nblk : 256LL * 16);

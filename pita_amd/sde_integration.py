@@ -226,7 +226,7 @@ class WeightedSDEIntegrator:
             kw = dict(dt_init=self.dt_negative_time) if self.adaptive_mcmc else {}
             x, acceptance_rate_list = fn(x, energy_function, return_acceptance_rate=True, walker_offset=off, comm=comm,
                                          **kw)
-        x = comm.all_gather(x)  # X1: the only collective on the resampling-free path
+        x = self._gather_final(x, comm, Bl)  # X1: the only collective on the resampling-free path
         return x, logweights, num_unique_idxs, sde_terms_all, acceptance_rate_list
 
     # ------------------------------------------------------------------ debiased regime (per step; section 8(f) N1)
@@ -292,7 +292,21 @@ class WeightedSDEIntegrator:
             kw = dict(dt_init=self.dt_negative_time) if self.adaptive_mcmc else {}
             x, acceptance_rate_list = fn(x, energy_function, return_acceptance_rate=True, walker_offset=off, comm=comm,
                                          **kw)
-        return comm.all_gather(x), logweights, num_unique_idxs, sde_terms_all, acceptance_rate_list
+        return self._gather_final(x, comm, Bl), logweights, num_unique_idxs, sde_terms_all, acceptance_rate_list
+
+    def _gather_final(self, x, comm, Bl):
+        """All-gather of the final shards.  After MALA every shard is [its valid walkers, its set-aside walkers]; the
+        reference runs the chain on the gathered batch and therefore returns [all valid, all set-aside] (quirk Q7):
+        reorder to that when any rank set walkers aside."""
+        xg = comm.all_gather(x)
+        if comm.world == 1 or self.post_mcmc_steps <= 0:
+            return xg
+        nv = comm.all_gather(torch.tensor([getattr(self, "_last_mala_valid", Bl)], device=x.device, dtype=torch.int64)).tolist()
+        if min(nv) == Bl:
+            return xg
+        head = [torch.arange(r * Bl, r * Bl + nv[r]) for r in range(comm.world)]
+        tail = [torch.arange(r * Bl + nv[r], (r + 1) * Bl) for r in range(comm.world)]
+        return xg[torch.cat(head + tail).to(xg.device)]
 
     def _resample_at_end(self, x, a, comm, times, energy_function, gamma_schedule, beta, u_iter, off, Bl):
         """End-of-trajectory reweighting (sde_integration.py:158-183): a_next = log p_target(x) + gamma E_theta(h(t_end), x)
@@ -379,6 +393,9 @@ class WeightedSDEIntegrator:
         x_valid, x_invalid = x[valid].contiguous(), x[~valid]
         logp = logp_all[valid].contiguous()
         Bv = x_valid.shape[0]
+        # Philox keys follow the walkers' ORIGINAL global indices, not their position in the compacted batch
+        ids = (torch.nonzero(valid).reshape(-1) + int(walker_offset)).contiguous() if Bv < x.shape[0] else None
+        self._last_mala_valid = Bv
         total = Bv
         world = comm.world if comm is not None and torch.distributed.is_initialized() else 1
         if world > 1:
@@ -404,7 +421,7 @@ class WeightedSDEIntegrator:
                         raise ValueError(f"MALA noise[{i}] has shape {tuple(nz.shape)}, expected {tuple(x_valid.shape)} "
                                          "(one row per walker with a finite target log-density)")
                     _lib.check(L.pita_mala_propose(x_valid.data_ptr(), grad.data_ptr(), x_prop.data_ptr(), _lib.ptr(nz),
-                                                   Bv, n, d, dt_dev.data_ptr(), key, walker_offset, i, st),
+                                                   Bv, n, d, dt_dev.data_ptr(), key, walker_offset, _lib.ptr(ids), i, st),
                                "pita_mala_propose")
                     logp_prop, grad_prop = energy_function(x_prop, return_force=True)
                     uu = _lib.dev_tensor(uniforms[i], "uniforms") if uniforms is not None else None
@@ -412,8 +429,8 @@ class WeightedSDEIntegrator:
                         raise ValueError(f"MALA uniforms[{i}] has {uu.numel()} entries, expected {Bv}")
                     _lib.check(L.pita_mala_accept(x_valid.data_ptr(), logp.data_ptr(), grad.data_ptr(), x_prop.data_ptr(),
                                                   logp_prop.data_ptr(), grad_prop.data_ptr(), _lib.ptr(uu), Bv, n, d,
-                                                  dt_dev.data_ptr(), key, walker_offset, i, rm, count.data_ptr(), st),
-                               "pita_mala_accept")
+                                                  dt_dev.data_ptr(), key, walker_offset, _lib.ptr(ids), i, rm,
+                                                  count.data_ptr(), st), "pita_mala_accept")
                 if world > 1:
                     torch.distributed.all_reduce(count)
                 _lib.check(L.pita_mala_adapt(dt_dev.data_ptr(), count.data_ptr(), total, int(adaptive),
