@@ -26,6 +26,7 @@ stages = {"sde only": dict(num_negative_time_steps=0, post_mcmc_steps=0),
           "+ descent (langevin)": dict(num_negative_time_steps=5, dt_negative_time=1e-5, post_mcmc_steps=0, do_langevin=True),
           "+ MALA": dict(num_negative_time_steps=0, dt_negative_time=1e-7, post_mcmc_steps=3, adaptive_mcmc=False),
           "+ adaptive MALA": dict(num_negative_time_steps=0, dt_negative_time=1e-7, post_mcmc_steps=4, adaptive_mcmc=True),
+          "+ resample_at_end": dict(num_negative_time_steps=0, post_mcmc_steps=0, resample_at_end=True, end_resampling_step_override=9),
           "+ descent + adaptive MALA": dict(num_negative_time_steps=5, dt_negative_time=1e-5, post_mcmc_steps=3, adaptive_mcmc=True)}
 for debias in (False, True):
     sde = pa.VEReverseSDE(noise_schedule=sched, score_net=pa.ScoreNet(net), energy_net=EnergyNet(copy.deepcopy(net)),
@@ -34,8 +35,10 @@ for debias in (False, True):
     x1 = pa.Prior(scale=3.0, n_particles=13, spatial_dim=3, seed=2).sample(B)
     us = [0.123, 0.456, 0.789, 0.321, 0.654]
     for name, extra in stages.items():
-        kw = dict(sde=sde, num_integration_steps=N, start_resampling_step=0, end_resampling_step=N, resampling_interval=3,
-                  seed=11, batch_size=8, **extra)  # chunks of 8 tile both the 16-walker shards and the whole batch
+        extra = dict(extra)
+        end = extra.pop("end_resampling_step_override", None)
+        kw = dict(sde=sde, num_integration_steps=N, start_resampling_step=0,
+                  end_resampling_step=N if end is None else min(end, N - 1), resampling_interval=3, seed=11, batch_size=8, **extra)  # chunks of 8 tile both the 16-walker shards and the whole batch
         outs = []
         for lm in (None, single):  # None -> torch.distributed world; `single` -> one rank does everything
             integ = pa.WeightedSDEIntegrator(lightning_module=lm, **kw)
