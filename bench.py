@@ -1,20 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- walker-steps/s of the fused HIP annealed-SDE sampler (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config lj13|dw4|aldp22|lj55]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on): LJ13
-(13 particles x 3D), EGNN score net (hidden 32 x 3 layers, tanh, attention, temperature
-conditioned; seed-12345 initialisation, i.e. the reference's own untrained init), Elucidating
-schedule (sigma_min 0.05, sigma_max 80, rho 7), gamma = 4/3, beta = 1, diffusion_scale 1,
-NOT-debiased reverse VE-SDE, resampling off, 65 536 walkers PER GPU (weak scaling), synthetic
-walkers from the mean-free prior.  One "step" = one Euler-Maruyama step of all walkers:
-EDM-preconditioned EGNN forward + drift + noise + update + remove_mean, all inside the fused
-kernel `egnn_kernel<13,3,7,4>`; the K timed steps run as K/c launches of c = gcd(K, W) steps each
-(the warm-up uses the same launch size so every launch of the kernel in this process is equal
-and the rocprof average is comparable).  After the timed region a separately timed loop of LJ13
-log-density+force evaluations gives the HBM roofline of the pairwise-force kernel.
+Default workload (BASELINE.json configs[2], the configuration the metric is quoted on): LJ13 (13 particles x 3D), EGNN
+score net (hidden 32 x 3 layers, tanh, attention, temperature conditioned; seed-12345 initialisation, i.e. the
+reference's own untrained init), Elucidating schedule (sigma_min 0.05, sigma_max 80, rho 7), gamma = 4/3, beta = 1,
+diffusion_scale 1, NOT-debiased reverse VE-SDE, resampling off, 65 536 walkers PER GPU (weak scaling), synthetic walkers
+from the mean-free prior.  One "step" = one Euler-Maruyama step of all walkers: EDM-preconditioned EGNN forward + drift +
+noise + update + remove_mean, all inside the fused kernel `egnn_kernel<...,SAMPLER>`; the K timed steps run as K/c
+launches of c = gcd(K, W) steps each (the warm-up uses the same launch size, so every launch of the kernel in this
+process is equal and the rocprof average is comparable).  After the timed region separately timed loops give the
+roofline of the target's log-density+force kernel and the debiased (Feynman-Kac) regime.
+
+`--config` selects the other GPU configurations of BASELINE.json at their per-GPU shard (dw4: 65 536 walkers; aldp22:
+4 096 = 16 384 / 4 GPUs; lj55: 32 768 = 262 144 / 8 GPUs): same measurement, same JSON fields.
+
+`--gpus N` without a torchrun environment starts the N rank processes itself (python -m torch.distributed.run) BEFORE
+this process touches the GPU, and relays rank 0's JSON line.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 """
@@ -22,53 +26,112 @@ import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_WALKER_STEP = 4.197e6   # EGNN forward h32x3, LJ13 (2 x 2 098 304 MAC)
-LJ13_BYTES_PER_EVAL = 316        # read x (39 f32) + write force (39) + logp (1)
-PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_MFMA16_TFLOPS = 2500.0      # MI355X_MICROARCH.md: BF16/FP16 MFMA dense peak (~2.5 PF)
+PEAK_F32_VALU_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 vector peak
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak
+ACHIEVABLE_HBM_GBS = 6300.0      # MI355X_MICROARCH.md: measured float4 copy (79 % of spec)
+MFMA16_FLOP = 2 * 32 * 32 * 16   # one v_mfma_f32_32x32x16_{bf16,f16}
+MFMA32_FLOP = 2 * 32 * 32 * 2    # one v_mfma_f32_32x32x2_f32
+NOMINAL_CLOCK_HZ = 2.4e9
+
+# name -> particles, dims, walkers per GPU, sigma_min, target kind
+CONFIGS = {
+    "lj13": dict(n=13, d=3, walkers=65536, sigma_min=0.05, target="lj",
+                 label="BASELINE configs[2]: LJ13, 65 536 walkers on 1 GPU"),
+    "dw4": dict(n=4, d=2, walkers=65536, sigma_min=0.01, target="dw",
+                label="BASELINE configs[1]: DW4, 65 536 walkers on 1 GPU"),
+    "aldp22": dict(n=22, d=3, walkers=4096, sigma_min=0.01, target="ff",
+                   label="BASELINE configs[3]: 22-atom force field, 16 384 walkers over 4 GPUs = 4 096 per GPU"),
+    "lj55": dict(n=55, d=3, walkers=32768, sigma_min=0.05, target="lj",
+                 label="BASELINE configs[4]: LJ55, 262 144 walkers over 8 GPUs = 32 768 per GPU"),
+}
 
 
-def pmc_traffic(key):
-    """HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (collected with this same
-    command under rocprofv3 and corrected as MI355X_MICROARCH.md prescribes; see profiles/r01_pmc_traffic.json).  PMC
-    collection cannot run inside the timed bench itself, so the live JSON carries the last committed measurement."""
+def egnn_algorithmic_flop(n, H=32, L=3):
+    """per layer E(2H+2)H + 2EH^2 + 2EH + n 3H^2 MAC, x L, + 2 n 2 H; flop = 2 MAC
+    (LJ13: 2 098 304 MAC = 4.197 MFLOP, counted on the reference's un-split formulation)."""
+    E = n * (n - 1)
+    mac = L * (E * (2 * H + 2) * H + 2 * E * H * H + 2 * E * H + n * 3 * H * H) + 2 * n * 2 * H
+    return 2.0 * mac
+
+
+def target_bytes(n, d):
+    return (2 * n * d + 1) * 4   # read x, write force, write logp
+
+
+def pmc_summary():
+    """Per-walker-step counter summary of the sampler kernel (profiles/pmc_sampler_current.json, produced by
+    tools/pmc_summarise.py from separate rocprofv3 --pmc passes over this same command; collected and corrected as
+    MI355X_MICROARCH.md prescribes).  PMC collection cannot run inside the timed bench, so the live JSON carries the
+    last committed measurement scaled to this run's launch size."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            return json.load(f)[key]["traffic_bytes"]
+        with open(os.path.join(ROOT, "profiles", "pmc_sampler_current.json")) as f:
+            return json.load(f)
     except Exception:
         return None
 
 
-def build_model(pa, seed=12345):
+def self_launch(args):
+    """--gpus N without a torchrun environment: start the N ranks as a child job.  Nothing in this process has
+    touched the GPU yet (torch is not even imported); the child job's stdout is relayed unchanged."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def build_model(pa, n, d, seed=12345):
+    import torch
+
     torch.manual_seed(seed)
-    net = pa.EGNN_dynamics(13, 3, hidden_nf=32, n_layers=3, recurrent=True, tanh=True, attention=True,
-                           condition_time=True, condition_temperature=True, agg="sum")
-    return net
+    return pa.EGNN_dynamics(n, d, hidden_nf=32, n_layers=3, recurrent=True, tanh=True, attention=True,
+                            condition_time=True, condition_temperature=True, agg="sum")
 
 
-def cpu_baseline(n_walkers, n_steps, seed=12345):
+def make_target(pa, cfg, dev):
+    n, d = cfg["n"], cfg["d"]
+    if cfg["target"] == "lj":
+        return pa.LennardJonesEnergy(n * d, n, d, device=dev)
+    if cfg["target"] == "dw":
+        return pa.MultiDoubleWellEnergy(n * d, n, d, device=dev)
+    from pita_amd.alp_energy import ForceFieldEnergy
+    from tests._synthetic import synthetic_peptide  # synthetic tables: amber14 parameters are not in the reference tree
+
+    tabs, _ = synthetic_peptide(n)
+    return ForceFieldEnergy(tabs, n_particles=n, temperature=300.0, data_normalization_factor=0.1640, cutoff=2.0,
+                            device=dev)
+
+
+def cpu_baseline(cfg, n_walkers, n_steps, seed=12345):
     """The oracle (torch-CPU restatement of the reference's sampler, kind = "port") timed on this
     host's cores on a bounded sample of the same workload."""
+    import torch
+
     from oracle import pita_oracle as O
 
     torch.manual_seed(seed)
     import pita_amd
 
-    net = build_model(pita_amd, seed)
+    n, d = cfg["n"], cfg["d"]
+    net = build_model(pita_amd, n, d, seed)
     w = {k: v.detach().clone() for k, v in net.state_dict().items()}
-    bb = lambda cn, xs, b: O.egnn_forward(w, cn, xs, b, 13, 3)
-    sched, gam = O.Elucidating(0.05, 80.0, 7), O.GammaConstant(4 / 3)
+    bb = lambda cn, xs, b: O.egnn_forward(w, cn, xs, b, n, d)
+    sched, gam = O.Elucidating(cfg["sigma_min"], 80.0, 7), O.GammaConstant(4 / 3)
     gen = torch.Generator().manual_seed(1)
-    x1 = O.prior_from_noise(torch.randn(n_walkers, 39, generator=gen), O.prior_scale(sched, gam, 1.0), 13, 3)
+    x1 = O.prior_from_noise(torch.randn(n_walkers, n * d, generator=gen), O.prior_scale(sched, gam, 1.0), n, d)
     cfg_run = O.IntegratorConfig(num_integration_steps=n_steps, end_resampling_step=n_steps)
     drift = lambda t, xc: O.f_not_debiased(bb, sched, gam, t, xc, 1.0)
     noise_fn = lambda i, shp: torch.randn(shp, generator=gen)
@@ -81,41 +144,44 @@ def cpu_baseline(n_walkers, n_steps, seed=12345):
         for nthr in sorted({all_threads, min(16, all_threads)}, reverse=True):
             torch.set_num_threads(nthr)
             O.integrate_sde(O.IntegratorConfig(num_integration_steps=2, end_resampling_step=2), x1, drift, sched.g,
-                            noise_fn, 13, 3)  # warm-up
+                            noise_fn, n, d)  # warm-up
             t0 = time.perf_counter()
-            O.integrate_sde(probe_cfg, x1, drift, sched.g, noise_fn, 13, 3)
+            O.integrate_sde(probe_cfg, x1, drift, sched.g, noise_fn, n, d)
             probe[nthr] = time.perf_counter() - t0
         nthr = min(probe, key=probe.get)
         torch.set_num_threads(nthr)
         t0 = time.perf_counter()
-        O.integrate_sde(cfg_run, x1, drift, sched.g, noise_fn, 13, 3)
-        best = (time.perf_counter() - t0, nthr)
+        O.integrate_sde(cfg_run, x1, drift, sched.g, noise_fn, n, d)
+        dt = time.perf_counter() - t0
     torch.set_num_threads(all_threads)
-    dt, nthr = best
     return {"value": n_walkers * n_steps / dt, "unit": "walker-steps/s", "cores": nthr,
-            "kind": "port", "sample": f"oracle integrate_sde, LJ13 EGNN h32x3, {n_walkers} walkers x {n_steps} steps, "
+            "kind": "port", "sample": f"oracle integrate_sde, {n}x{d}D EGNN h32x3, {n_walkers} walkers x {n_steps} steps, "
             f"torch-CPU fp32, {dt:.1f} s with {nthr} threads (host has {os.cpu_count()} logical CPUs)"}
 
 
-def debiased_leg(pita_amd, net, dev, B, with_cpu):
+def debiased_leg(pita_amd, net, cfg, dev, B, with_cpu):
     """Secondary number: the debiased Feynman-Kac regime (PITA's default; sdes.py:151-239): drift of x and of the
-    log-weights through 13 three-direction divergence launches (pita_egnn_div_accumulate) + 1 forward-mode
+    log-weights through D/K multi-direction divergence launches (pita_egnn_div_accumulate) + 1 forward-mode
     (pita_egnn_jvp, h direction) + 1 reverse-mode launch (pita_egnn_vjp) + assembly + quantile clamp, then the EM update."""
     import copy
 
+    import numpy as np
+    import torch
+
     from pita_amd.energy_net import EnergyNet
 
-    sched = pita_amd.ElucidatingNoiseSchedule(sigma_min=0.05, sigma_max=80.0, rho=7)
+    n, d = cfg["n"], cfg["d"]
+    sched = pita_amd.ElucidatingNoiseSchedule(sigma_min=cfg["sigma_min"], sigma_max=80.0, rho=7)
     gam = pita_amd.ConstantAnnealingFactorSchedule(4 / 3)
     sde = pita_amd.VEReverseSDE(noise_schedule=sched, score_net=pita_amd.ScoreNet(net),
                                 energy_net=EnergyNet(copy.deepcopy(net)), debias_inference=True)
-    x = pita_amd.Prior(scale=3.0, n_particles=13, spatial_dim=3, device=dev, seed=7).sample(B)
+    x = pita_amd.Prior(scale=3.0, n_particles=n, spatial_dim=d, device=dev, seed=7).sample(B)
     t = torch.tensor(0.5, device=dev)
     L = pita_amd._lib.lib()
 
     def step():
         terms = sde.f(t, x, 1.0, gam, None, None, clamp_chunk=512)
-        L.pita_em_step(x.data_ptr(), terms.drift_X.data_ptr(), 0, B, 13, 3, 1e-3, 0.1, float(np.sqrt(1e-3)), 1, 0, 0, 1,
+        L.pita_em_step(x.data_ptr(), terms.drift_X.data_ptr(), 0, B, n, d, 1e-3, 0.1, float(np.sqrt(1e-3)), 1, 0, 0, 1, 0,
                        pita_amd._lib.stream_ptr(dev))
         return terms
 
@@ -127,14 +193,15 @@ def debiased_leg(pita_amd, net, dev, B, with_cpu):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    out = {"metric": "walker-steps/s, debiased (Feynman-Kac) regime, LJ13", "value": B / dt, "walkers": B,
-           "ms_per_step": dt * 1e3, "launches_per_step": 15 + 3}
+    K = max(1, L.pita_egnn_div_directions(net._native(dev)))
+    out = {"metric": f"walker-steps/s, debiased (Feynman-Kac) regime, {n}x{d}D", "value": B / dt, "walkers": B,
+           "ms_per_step": dt * 1e3, "launches_per_step": -(-n * d // K) + 2 + 3}
     if with_cpu:
         from oracle import pita_oracle as O
 
         w = {k: v.detach().clone() for k, v in net.state_dict().items()}
-        bb = lambda cn, xs, b: O.egnn_forward(w, cn, xs, b, 13, 3)
-        osched, ogam = O.Elucidating(0.05, 80.0, 7), O.GammaConstant(4 / 3)
+        bb = lambda cn, xs, b: O.egnn_forward(w, cn, xs, b, n, d)
+        osched, ogam = O.Elucidating(cfg["sigma_min"], 80.0, 7), O.GammaConstant(4 / 3)
         nb = 48
         xc = x[:nb].cpu()
         torch.set_num_threads(min(16, torch.get_num_threads()))
@@ -146,27 +213,153 @@ def debiased_leg(pita_amd, net, dev, B, with_cpu):
     return out
 
 
+def force_roofline(pita_amd, cfg, energy, x, dev, reps):
+    """The target's log-density + force kernel, separately timed at this config's batch: HBM roofline for LJ13 / DW4 /
+    the 22-atom force field (algorithmic bytes = read x + write force + write logp), fp32-VALU fraction for LJ55
+    (AI 31 flop/B is past the ridge)."""
+    import torch
+
+    n, d, B = cfg["n"], cfg["d"], x.shape[0]
+
+    def timed(fn, k):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(k):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / k
+
+    us = timed(lambda: energy(x, return_force=True), reps)
+    nbytes = target_bytes(n, d)
+    gbs = B * nbytes / (us * 1e-6) / 1e9
+    a, b = torch.empty(B * n * d, device=dev), torch.empty(B * n * d, device=dev)
+    us_copy = timed(lambda: b.copy_(a), reps)
+    out = {"kernel": {"lj": f"pita_lj_logp_force (LJ{n} logp+force)", "dw": "pita_dw_logp_force (DW4 logp+force)",
+                      "ff": "pita_ff_logp_force (22-atom force field, synthetic tables, cutoff 2 nm, no GB)"}[cfg["target"]],
+           "walkers": B, "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+           "frac_of_measured_achievable_6300": gbs / ACHIEVABLE_HBM_GBS,
+           "algorithmic_bytes_per_walker_eval": nbytes, "us_per_launch": us, "walker_evals_per_s": B / (us * 1e-6),
+           "launches": reps, "same_bytes_device_copy_us": us_copy,
+           "same_bytes_device_copy_GBs": 2 * B * n * d * 4 / (us_copy * 1e-6) / 1e9,
+           "note": "stand-alone launches through the plug-in class (output tensors allocated per call)"}
+    pm = pmc_summary()
+    key = f"force_{cfg['name']}"
+    out["traffic"] = pm[key]["traffic_bytes_per_launch"] if pm and key in pm and pm[key].get("walkers") == B else None
+    if cfg["target"] == "lj" and n == 55:  # VALU-bound: SURVEY 8(d) 1 485 pairs x 28 + 55 x 9 flop per walker-eval
+        flop = 1485 * 28 + 55 * 9
+        tf = B * flop / (us * 1e-6) / 1e12
+        out.update({"bound": "valu", "achieved": tf, "peak": PEAK_F32_VALU_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tf / PEAK_F32_VALU_TFLOPS, "hbm_GBs_for_information": gbs,
+                    "algorithmic_flop_per_walker_eval": flop})
+        out.pop("frac_of_measured_achievable_6300")
+    if cfg["target"] == "lj" and n == 13:
+        L = pita_amd._lib.lib()
+        sp = pita_amd._lib.stream_ptr(dev)
+        lp, fo = torch.empty(B, device=dev), torch.empty_like(x)
+        us_raw = timed(lambda: L.pita_lj_logp_force(x.data_ptr(), lp.data_ptr(), fo.data_ptr(), B, 13, 3, 1.0, 1.0, 1e-6,
+                                                    1.0, 1.0, 1.0, sp), reps)
+        gbs_raw = B * nbytes / (us_raw * 1e-6) / 1e9
+        out.update({"us_per_launch": us_raw, "achieved": gbs_raw, "frac": gbs_raw / PEAK_HBM_GBS,
+                    "frac_of_measured_achievable_6300": gbs_raw / ACHIEVABLE_HBM_GBS,
+                    "walker_evals_per_s": B / (us_raw * 1e-6), "note": "C-ABI calls on preallocated outputs"})
+        BIG = 1 << 21
+        xbig = x.repeat(BIG // B + 1, 1)[:BIG].contiguous()
+        lpb, fob = torch.empty(BIG, device=dev), torch.empty_like(xbig)
+        us_big = timed(lambda: L.pita_lj_logp_force(xbig.data_ptr(), lpb.data_ptr(), fob.data_ptr(), BIG, 13, 3, 1.0, 1.0,
+                                                    1e-6, 1.0, 1.0, 1.0, sp), 20)
+        gbs_big = BIG * nbytes / (us_big * 1e-6) / 1e9
+        out["large_batch"] = {"walkers": BIG, "us_per_launch": us_big, "achieved": gbs_big, "frac": gbs_big / PEAK_HBM_GBS,
+                              "frac_of_measured_achievable_6300": gbs_big / ACHIEVABLE_HBM_GBS}
+        # the force kernel where production uses it per step: negative-time descent (sde_integration.py:353-360), all
+        # steps of a launch with the walkers resident in LDS (pita_lj_descent).  HBM sees one read + one write of x
+        # per LAUNCH: the rate below is walker-evals/s; its "algorithmic-equivalent" GB/s is NOT an HBM-roofline
+        # fraction (the bytes do not move) and carries no frac
+        S_DESC = 1000
+        xd = x.clone()
+
+        def descent(noise_scale):
+            pita_amd._lib.check(L.pita_lj_descent(xd.data_ptr(), 0, B, 13, 3, 1.0, 1.0, 1e-6, 1.0, 1.0, 1.0, S_DESC, 1e-7,
+                                                  noise_scale, math.sqrt(2e-7), 1, 0, 0, 1, sp), "pita_lj_descent")
+
+        us_desc = timed(lambda: descent(0.0), 2) / S_DESC
+        us_ula = timed(lambda: descent(1.0), 2) / S_DESC
+        assert torch.isfinite(xd).all(), "descent produced non-finite walkers"
+        out["in_descent_loop"] = {"kernel": "lj13_descent_kernel (force + update + centring, walkers LDS-resident)",
+                                  "steps_per_launch": S_DESC, "us_per_step": us_desc,
+                                  "walker_evals_per_s": B / (us_desc * 1e-6),
+                                  "algorithmic_equivalent_GBs_bytes_do_not_move": B * nbytes / (us_desc * 1e-6) / 1e9,
+                                  "hbm_bytes_per_launch": 2 * B * 39 * 4, "us_per_step_with_langevin_noise": us_ula}
+    return out
+
+
+def dry_run(args, world, rank):
+    """The multi-rank protocol of the real run -- process group, barrier, timed region, max-over-ranks, rank-0 JSON,
+    final barrier -- with the kernels replaced by nothing, over gloo on the CPU."""
+    import torch
+
+    if world > 1:
+        torch.distributed.init_process_group("gloo")
+        assert torch.distributed.get_world_size() == args.gpus
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    shard = torch.full((4, 3), float(rank))
+    if world > 1:
+        gathered = torch.empty(world * 4, 3)
+        torch.distributed.all_gather_into_tensor(gathered, shard)
+        assert [float(gathered[4 * r, 0]) for r in range(world)] == [float(r) for r in range(world)]
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no kernels)", "value": None, "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "scaling": "strong" if args.strong else "weak",
+                          "config": {"backend": "gloo" if world > 1 else None}}), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--walkers", type=int, default=65536, help="walkers per GPU (with --strong: in total)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="lj13")
+    ap.add_argument("--walkers", type=int, default=0, help="walkers per GPU (default: the config's; with --strong: in total)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: --walkers is the TOTAL batch, split across ranks")
     ap.add_argument("--chunk", type=int, default=0, help="SDE steps per kernel launch (default gcd(steps, warmup))")
-    ap.add_argument("--force-evals", type=int, default=200, help="LJ13 force-kernel launches for its roofline")
+    ap.add_argument("--force-evals", type=int, default=200, help="target force-kernel launches for its roofline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-debiased", action="store_true", help="skip the secondary debiased-regime measurement")
     ap.add_argument("--cpu-walkers", type=int, default=512, help="CPU sample: the reference's own inference chunk for LJ13")
-    ap.add_argument("--cpu-steps", type=int, default=300)
+    ap.add_argument("--cpu-steps", type=int, default=0, help="CPU sample steps (default sized for ~10-20 s)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch / rendezvous / timing protocol only, no kernels and no GPU (gloo): CPU test of the "
+                         "multi-rank path; the JSON carries value null")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+
+    import numpy as np
+    import torch
+
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.dry_run:
+        return dry_run(args, world, rank)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     # PITA_BENCH_ONE_DEVICE=1: rehearsal of the multi-rank control flow on a ONE-GPU box (all ranks share cuda:0, gloo
     # with host staging instead of RCCL, which refuses two ranks on one device); its numbers mean nothing
@@ -180,6 +373,7 @@ def main():
             torch.distributed.init_process_group("gloo")
         else:
             torch.distributed.init_process_group("nccl", device_id=dev)
+        assert torch.distributed.get_world_size() == args.gpus
 
     def all_gather(dst, src):
         if rehearsal:
@@ -200,15 +394,18 @@ def main():
     import pita_amd
 
     pita_amd._lib.lib()  # fail loudly if the HIP library is missing
-    B, K, W = args.walkers, args.steps, args.warmup
+    cfg = dict(CONFIGS[args.config], name=args.config)
+    n, d = cfg["n"], cfg["d"]
+    D = n * d
+    B, K, W = (args.walkers or cfg["walkers"]), args.steps, args.warmup
     if args.strong:
         assert B % world == 0, "--strong: --walkers must be divisible by the number of ranks"
         B //= world
     chunk = args.chunk or (math.gcd(K, W) if W > 0 else K)
     assert K % chunk == 0 and W % chunk == 0
 
-    net = build_model(pita_amd)
-    sched = pita_amd.ElucidatingNoiseSchedule(sigma_min=0.05, sigma_max=80.0, rho=7)
+    net = build_model(pita_amd, n, d)
+    sched = pita_amd.ElucidatingNoiseSchedule(sigma_min=cfg["sigma_min"], sigma_max=80.0, rho=7)
     gam = pita_amd.ConstantAnnealingFactorSchedule(4 / 3)
     NGRID = 1000  # the 1000-step time grid of the reference config; K+W steps walk along it (wrapping)
     times = torch.linspace(1.0, 0.0, NGRID + 1)[:-1]
@@ -216,9 +413,8 @@ def main():
     idx = torch.arange(W + K) % NGRID
     tab = tab_h[idx].contiguous().to(dev)
     scale = float((sched.h(torch.tensor(1.0)) / gam.gamma(torch.tensor(1.0))) ** 0.5)
-    prior = pita_amd.Prior(scale=scale, n_particles=13, spatial_dim=3, device=dev, seed=12345)
+    prior = pita_amd.Prior(scale=scale, n_particles=n, spatial_dim=d, device=dev, seed=12345)
     x = prior.sample(B, walker_offset=rank * B)
-    energy = pita_amd.LennardJonesEnergy(39, 13, 3, device=dev)
     seed = 12345
 
     def run(s0, s1):
@@ -226,7 +422,7 @@ def main():
             net.sampler_run(x, tab[s:s + chunk], chunk, seed=seed, walker_offset=rank * B, step0=s, remove_mean=True)
 
     run(0, W)  # warm-up (also builds the native handle)
-    gathered = torch.empty(world * B, 39, device=dev) if world > 1 else None
+    gathered = torch.empty(world * B, D, device=dev) if world > 1 else None
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -249,88 +445,47 @@ def main():
     launch_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(n_launch)]
     assert torch.isfinite(x).all(), "sampler produced non-finite walkers"
 
-    # ---- pairwise-force kernel roofline (HBM-bound), separately timed: at the workload's 65 536 walkers, at a
-    #      streaming-size batch (2^21 walkers, 663 MB per launch) and next to a plain device copy of the same bytes
     force_rl = None
     if rank == 0 and args.force_evals > 0:
-        L = pita_amd._lib.lib()
-        sp = pita_amd._lib.stream_ptr(dev)
-
-        def time_force(xb, reps):
-            nb = xb.shape[0]
-            lp, fo = torch.empty(nb, device=dev), torch.empty_like(xb)
-            for _ in range(3):
-                L.pita_lj_logp_force(xb.data_ptr(), lp.data_ptr(), fo.data_ptr(), nb, 13, 3, 1.0, 1.0, 1e-6, 1.0, 1.0, 1.0, sp)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                L.pita_lj_logp_force(xb.data_ptr(), lp.data_ptr(), fo.data_ptr(), nb, 13, 3, 1.0, 1.0, 1e-6, 1.0, 1.0, 1.0, sp)
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) * 1e3 / reps
-
-        def time_copy(nfloat, reps):
-            a, b = torch.empty(nfloat, device=dev), torch.empty(nfloat, device=dev)
-            for _ in range(3):
-                b.copy_(a)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                b.copy_(a)
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) * 1e3 / reps
-
-        us = time_force(x, args.force_evals)
-        gbs = B * LJ13_BYTES_PER_EVAL / (us * 1e-6) / 1e9
-        BIG = 1 << 21
-        xbig = x.repeat(BIG // B + 1, 1)[:BIG].contiguous()
-        us_big = time_force(xbig, 20)
-        gbs_big = BIG * LJ13_BYTES_PER_EVAL / (us_big * 1e-6) / 1e9
-        us_copy = time_copy(B * 39, args.force_evals)  # a device copy moving the same 2 x 10.2 MB
-        # the force kernel where production uses it per step: negative-time descent (sde_integration.py:353-360),
-        # all steps of a launch with the walkers resident in LDS (pita_lj_descent); algorithmic bytes stay
-        # SURVEY 8(d)'s 316 B per walker-eval, actual HBM traffic is one read + one write of x per LAUNCH
-        S_DESC = 1000
-        xd = x.clone()
-
-        def run_descent(noise_scale):
-            pita_amd._lib.check(L.pita_lj_descent(xd.data_ptr(), 0, B, 13, 3, 1.0, 1.0, 1e-6, 1.0, 1.0, 1.0, S_DESC, 1e-7,
-                                                  noise_scale, math.sqrt(2e-7), 1, 0, 0, 1, sp), "pita_lj_descent")
-
-        def time_descent(noise_scale):
-            run_descent(noise_scale)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            run_descent(noise_scale)
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) * 1e3 / S_DESC
-
-        us_desc, us_ula = time_descent(0.0), time_descent(1.0)
-        assert torch.isfinite(xd).all(), "descent produced non-finite walkers"
-        gbs_desc = B * LJ13_BYTES_PER_EVAL / (us_desc * 1e-6) / 1e9
-        force_rl = {"kernel": "lj13_kernel<2> (LJ13 logp+force, 65 536 walkers)", "bound": "hbm", "achieved": gbs,
-                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                    "traffic": pmc_traffic("lj13_kernel<2> @65536 walkers") if B == 65536 else None,
-                    "us_per_launch": us, "walker_evals_per_s": B / (us * 1e-6), "launches": args.force_evals,
-                    "same_bytes_device_copy_us": us_copy,
-                    "same_bytes_device_copy_GBs": 2 * B * 39 * 4 / (us_copy * 1e-6) / 1e9,
-                    "large_batch": {"kernel": "lj13_kernel<1>", "walkers": BIG, "us_per_launch": us_big,
-                                    "achieved": gbs_big, "frac": gbs_big / PEAK_HBM_GBS},
-                    "in_descent_loop": {"kernel": "lj13_descent_kernel (force + update + centring, walkers LDS-resident)",
-                                        "walkers": B, "steps_per_launch": S_DESC, "us_per_step": us_desc,
-                                        "walker_evals_per_s": B / (us_desc * 1e-6), "achieved": gbs_desc,
-                                        "frac": gbs_desc / PEAK_HBM_GBS, "unit": "GB/s (algorithmic, 316 B/walker-eval)",
-                                        "hbm_bytes_per_launch": 2 * B * 39 * 4,
-                                        "us_per_step_with_langevin_noise": us_ula}}
-        del xbig
+        energy = make_target(pita_amd, cfg, dev)
+        # the sampler's walkers for the pair targets; compact synthetic conformations for the force field
+        xf = x if cfg["target"] != "ff" else pita_amd.Prior(scale=1.0, n_particles=n, spatial_dim=d, device=dev,
+                                                            seed=3).sample(B)
+        force_rl = force_roofline(pita_amd, cfg, energy, xf, dev, args.force_evals)
 
     if rank == 0:
         avg_ms = float(np.mean(launch_ms))
-        achieved = B * chunk * FLOP_PER_WALKER_STEP / (avg_ms * 1e-3) / 1e12
+        m16, m32 = net.sampler_work(B, dev)
+        exec16, exec32 = m16 * MFMA16_FLOP, m32 * MFMA32_FLOP
+        walker_steps_per_s = B * chunk / (avg_ms * 1e-3)
+        achieved = walker_steps_per_s * exec16 / 1e12
+        alg = egnn_algorithmic_flop(n)
+        # matrix-pipe occupancy at the nominal clock: 32 cycles per 32x32x16 MFMA, 64 per 32x32x2 f32 MFMA, 1024 SIMDs
+        pipe_busy = walker_steps_per_s * (m16 * 32 + m32 * 64) / (1024 * NOMINAL_CLOCK_HZ)
+        pm = pmc_summary()
+        pk = pm.get(f"sampler_{args.config}") if pm else None
+        same = pk is not None and pk.get("walkers") == B
+        roof = {"kernel": f"egnn_kernel<{n},{d},...,SAMPLER> (fused EGNN score + EDM + EM step; one launch = {chunk} steps)",
+                "bound": "mfma", "achieved": achieved, "peak": PEAK_MFMA16_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_MFMA16_TFLOPS,
+                "traffic": pk["traffic_bytes_per_walker_step"] * B * chunk if same else None,
+                "executed_mfma_flop_per_walker_step": exec16,
+                "executed_f32_mfma_flop_per_walker_step": exec32,
+                "mfma16_per_walker_step": m16, "mfma32_per_walker_step": m32,
+                "mfma_pipe_busy_frac_at_2.4GHz": pipe_busy,
+                "valu_issue_frac": pk.get("valu_issue_frac") if same else None,
+                "pmc_source": pk.get("source") if same else None,
+                "achieved_algorithmic": walker_steps_per_s * alg / 1e12,
+                "algorithmic_flop_per_walker_step": alg, "algorithmic_bytes_per_launch": 2 * B * D * 4,
+                "ms_per_launch": avg_ms, "launches": n_launch,
+                "note": "achieved/frac count the 16-bit matrix-pipe flops the kernel EXECUTES (fp32-accurate split "
+                        "products included) against the dense 16-bit MFMA peak; achieved_algorithmic counts the "
+                        "reference's fp32 formulation (SURVEY 8(d)) and has no frac.  The kernel is VALU-issue-bound "
+                        "(activations + operand splits): valu_issue_frac, DESIGN.md section 4.1"}
+        assert 0.0 < roof["frac"] <= 1.0 and pipe_busy <= 1.0, "roofline fraction must be a fraction"
         out = {
-            "metric": "walker-steps/sec (batch x T) LJ13 @ 65k walkers/GPU",
+            "metric": "walker-steps/sec (batch x T) LJ13 @ 65k walkers/GPU" if args.config == "lj13"
+                      else f"walker-steps/sec (batch x T) {args.config} @ {B} walkers/GPU",
             "value": world * B * K / elapsed,
             "unit": "walker-steps/s",
             "n_gpus": world,
@@ -342,31 +497,24 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "LJ13 (13x3D) annealed reverse VE-SDE, EGNN h32x3 score net (seed-12345 init), "
-                                   "not-debiased, resampling off, Elucidating(0.05,80,7), gamma=4/3, beta=1",
+            "config": {"workload": f"{cfg['label']}: {n}x{d}D annealed reverse VE-SDE, EGNN h32x3 score net (seed-12345 "
+                                   f"init), not-debiased, resampling off, Elucidating({cfg['sigma_min']},80,7), gamma=4/3, "
+                                   "beta=1",
                        "walkers_per_gpu": B, "global_walkers": world * B, "steps_per_launch": chunk,
-                       "parallelism": f"walker-sharded x{world}, final all_gather only"},
-            "roofline": {"kernel": "egnn_kernel<13,3,7,4,1,true> (fused EGNN score + EM step)", "bound": "mfma",
-                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": pmc_traffic("egnn_kernel<13,3,7,4,1> @65536 walkers x 100 steps")
-                         if (B == 65536 and chunk == 100) else None,
-                         "note": "fp32-accurate dense layers run as exact 3-way bf16 splits on the bf16 matrix pipe; "
-                                 "algorithmic flops count the reference's un-split first edge layer, so frac can exceed 1; "
-                                 "the kernel is VALU-issue-bound (activations + operand splits), see DESIGN.md",
-                         "traffic_note": "x is read once and written once per launch (20.4 MB at 65 536 walkers); everything else "
-                                         "in `traffic` is register-spill scratch (468 B/lane, outside the edge loop) going "
-                                         "to L2 / Infinity Cache at ~0.35 TB/s of the 8 TB/s available",
-                         "algorithmic_flop_per_walker_step": FLOP_PER_WALKER_STEP, "ms_per_launch": avg_ms,
-                         "launches": n_launch},
+                       "parallelism": f"walker-sharded x{world}, final all_gather only",
+                       "backend": ("gloo (one-device rehearsal)" if rehearsal else "nccl (RCCL)") if world > 1 else None},
+            "roofline": roof,
             "roofline_force": force_rl,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_walkers, args.cpu_steps)
+            # ~10-20 s of CPU work: the cost per walker-step grows with the number of edges
+            steps = args.cpu_steps or max(4, int(300 * 156 / (n * (n - 1))))
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_walkers, steps)
         else:
             out["cpu_baseline"] = None
         if world == 1 and not args.no_debiased:
-            out["debiased"] = debiased_leg(pita_amd, net, dev, B, with_cpu=not args.no_cpu_baseline)
+            Bd = B if n <= 22 else min(B, 4096)
+            out["debiased"] = debiased_leg(pita_amd, net, cfg, dev, Bd, with_cpu=not args.no_cpu_baseline and n <= 13)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()  # rank 0 may still be in its force-kernel leg

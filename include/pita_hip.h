@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PITA_ABI_VERSION 1
+#define PITA_ABI_VERSION 2
 
 enum {
   PITA_OK = 0,
@@ -216,10 +216,20 @@ enum {
 /* noise: nullable device [n_steps, B, D] standard normals (parity mode).  When NULL the kernel
  * draws Philox4x32-10 normals keyed by (seed, walker_offset + walker, step0 + step, particle)
  * so results do not depend on how walkers are sharded over GPUs.
- * drift_out: nullable device [B, D]; receives drift_X of the LAST step of the launch. */
+ * drift_out: nullable device [B, D]; receives drift_X of the LAST step of the launch.
+ * stats_out: nullable device double [n_steps][4]; step s ADDS (sum drift_X, sum drift_X^2, sum diffusion,
+ * sum diffusion^2) over this call's B*D elements, diffusion = noise_scale * xi (sdes.py:250).  These are the moments
+ * behind the per-step SDETerms the reference returns and only ever reduces to .mean()/.std()
+ * (sde_integration.py:150,289; energytemp_module.py:1132-1143). */
 int pita_egnn_sampler_run(pita_egnn_t* net, float* x, int64_t B, const float* step_tab,
                           int n_steps, const float* noise, uint64_t seed, uint64_t walker_offset,
-                          int64_t step0, int remove_mean, float* drift_out, void* stream);
+                          int64_t step0, int remove_mean, float* drift_out, double* stats_out, void* stream);
+
+/* Work accounting for the roofline of pita_egnn_sampler_run (bench.py): matrix-core wave-instructions executed per
+ * walker-step at batch B, counted on the kernel's own loop structure -- mfma16: v_mfma_f32_32x32x16_{bf16,f16}
+ * (32 768 flop each), mfma32: v_mfma_f32_32x32x2_f32 (4 096 flop each). */
+int pita_egnn_sampler_work(const pita_egnn_t* net, int64_t B, double* mfma16_per_walker_step,
+                           double* mfma32_per_walker_step);
 
 /* ---------------------------------------------------------------- MLP backbone (K6)
  * replaces MyMLP.forward (mlp.py:244-267) / MyMLPTemperature.forward (:501-524) incl. the
@@ -249,14 +259,19 @@ int pita_mlp_forward(pita_mlp_t* net, const float* t, const float* x, const floa
  * for all n_steps.  Requires out_dim == input_dim == n_particles * n_dim <= 64 (GMM: n_particles = 1, n_dim = 2). */
 int pita_mlp_sampler_run(pita_mlp_t* net, float* x, int64_t B, const float* step_tab, int n_steps,
                          const float* noise /*nullable*/, uint64_t seed, uint64_t walker_offset, int64_t step0,
-                         int remove_mean, int n_particles, int n_dim, void* stream);
+                         int remove_mean, int n_particles, int n_dim, double* stats_out /*nullable, as above*/,
+                         void* stream);
 
 /* ---------------------------------------------------------------- elementwise sampler pieces
  * K8: x <- x + drift*dt + (noise_scale*xi)*sqrt_dt, then optional per-walker mean removal
- * (sde_integration.py:347-349,148; data_utils.py:4-26).  noise nullable -> Philox as above. */
+ * (sde_integration.py:347-349,148; data_utils.py:4-26).  noise nullable -> Philox as above.
+ * stats_out: nullable device double [4], += the same four moments as pita_egnn_sampler_run for this one step. */
 int pita_em_step(float* x, const float* drift, const float* noise, int64_t B, int n_particles,
                  int n_dim, float dt, float noise_scale, float sqrt_dt, uint64_t seed,
-                 uint64_t walker_offset, int64_t step, int remove_mean, void* stream);
+                 uint64_t walker_offset, int64_t step, int remove_mean, double* stats_out, void* stream);
+/* out[0] += sum v, out[1] += sum v^2 (device double[2]): moments of one SDETerms field (divergence_score, cross_term,
+ * dUt_dt; sdes.py:34-41), so the integrator returns statistics instead of N x [B] host copies (sde_integration.py:289) */
+int pita_moments(const float* v, int64_t n, double* out, void* stream);
 /* K9: MeanFreePrior.sample (base_prior.py:77-83): x = scale * N(0,1) minus particle mean.
  * noise nullable -> Philox keyed (seed, walker_offset + walker, step = -1). */
 int pita_prior_sample(float* x, const float* noise, int64_t B, int n_particles, int n_dim,

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpita_hip.so")
 
 STEP_STRIDE = 16
+ABI_VERSION = 2
 ST_CS, ST_CIN, ST_COUT, ST_CNOISE, ST_H, ST_G2, ST_GAMMA, ST_DT, ST_NOISE_SCALE, ST_SQRT_DT, ST_BETA = range(11)
 
 
@@ -75,15 +76,17 @@ _PROTOS = {
     "pita_fk_assemble": (c_int, [c_void_p] * 8 + [c_float, c_float] + [c_void_p] * 6 + [c_int64, c_int, c_void_p]),
     "pita_quantile_clamp": (c_int, [c_void_p, c_int64, c_int64, c_float, c_void_p]),
     "pita_egnn_sampler_run": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_uint64, c_uint64,
-                                      c_int64, c_int, c_void_p, c_void_p]),
+                                      c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "pita_egnn_sampler_work": (c_int, [c_void_p, c_int64, POINTER(c_double), POINTER(c_double)]),
     "pita_mlp_create": (c_int, [POINTER(c_void_p), POINTER(MlpConfig), c_void_p, c_int64, c_void_p]),
     "pita_mlp_destroy": (c_int, [c_void_p]),
     "pita_mlp_num_weights": (c_int64, [POINTER(MlpConfig)]),
     "pita_mlp_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "pita_mlp_sampler_run": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_uint64, c_uint64, c_int64,
-                                     c_int, c_int, c_int, c_void_p]),
+                                     c_int, c_int, c_int, c_void_p, c_void_p]),
     "pita_em_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_float, c_float, c_uint64,
-                             c_uint64, c_int64, c_int, c_void_p]),
+                             c_uint64, c_int64, c_int, c_void_p, c_void_p]),
+    "pita_moments": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "pita_prior_sample": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_uint64, c_uint64, c_int,
                                   c_void_p]),
     "pita_remove_mean": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p]),
@@ -118,7 +121,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if L.pita_abi_version() != 1:
+        if L.pita_abi_version() != ABI_VERSION:
             raise PitaHipError("libpita_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -56,6 +56,7 @@ struct EgnnParams {
   long long step0;
   int remove_mean;
   float* drift_out;
+  double* stats_out;  // nullable [n_steps][4]: += sum / sum of squares of drift_X and of the diffusion term
 };
 
 template <int N, int DIM, int G, int WAVES>
@@ -328,6 +329,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
       } else {
         // ---- reverse-SDE Euler-Maruyama update (sdes.py:119-122,250; sde_integration.py:347-348)
         float xn[NT][DIM];
+        float st_d = 0.f, st_d2 = 0.f, st_n = 0.f, st_n2 = 0.f;  // per-lane partial moments (<= NT*DIM terms each)
 #pragma unroll
         for (int T = 0; T < NT; ++T) {
           float xi[4] = {0.f, 0.f, 0.f, 0.f};
@@ -345,8 +347,21 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
             const float drift = gamma * (sc * g2);
             if (p.drift_out && step == nsteps - 1 && valid[T] && hh == 0)
               p.drift_out[(walker0 * N + col[T]) * DIM + k] = drift;
-            xn[T][k] = xcur[T][k] + (drift * dt + ((noise_scale * xi[k]) * sqrt_dt));
+            const float dif = noise_scale * xi[k];  // sdes.py:250
+            if (p.stats_out && valid[T] && hh == 0) {
+              st_d += drift; st_d2 = fmaf(drift, drift, st_d2);
+              st_n += dif; st_n2 = fmaf(dif, dif, st_n2);
+            }
+            xn[T][k] = xcur[T][k] + (drift * dt + (dif * sqrt_dt));
             if (hh == 0) scr[col[T] * DIM + k] = xn[T][k];
+          }
+        }
+        if (p.stats_out) {  // per-step moments of the SDETerms the reference returns (sde_integration.py:150,289)
+          double m4[4] = {(double)st_d, (double)st_d2, (double)st_n, (double)st_n2};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            for (int o = 32; o > 0; o >>= 1) m4[q] += __shfl_xor(m4[q], o, 64);
+            if (lane == 0) atomicAdd(p.stats_out + (size_t)step * 4 + q, m4[q]);
           }
         }
         if (p.remove_mean) {
@@ -629,6 +644,42 @@ static int egnn_launch(pita_egnn_t* net, EgnnParams& p, void* stream) {
   return PITA_OK;
 }
 
+// MFMA wave-instructions the fused sampler executes per walker-step, counted on the kernel's own loop structure (same
+// walker quota / grouping arithmetic as the launch above): per live column tile and layer one partner-table GEMM, one
+// own-term GEMM, (N-1) edges x (one f32 k-step + two dense layers) and -- except in the last layer -- three node-model
+// GEMMs.  A dense 32x32 layer is 16 f32 MFMAs (precision 0) or 12 bf16 MFMAs (precision 1).
+extern "C" int pita_egnn_sampler_work(const pita_egnn_t* net, int64_t B, double* mfma16_per_walker_step,
+                                      double* mfma32_per_walker_step) {
+  PITA_REQUIRE(net && B > 0 && mfma16_per_walker_step && mfma32_per_walker_step, "pita_egnn_sampler_work: bad argument");
+  const EgnnShape* s = static_cast<const EgnnShape*>(net->shape);
+  const int L = net->cfg.n_layers, N = s->n, G = s->G;
+  const size_t lds = s->lds_bytes(L);
+  int blocks_per_cu = (int)((160 * 1024) / lds);
+  blocks_per_cu = blocks_per_cu < 1 ? 1 : (blocks_per_cu > 2 ? 2 : blocks_per_cu);
+  const long long ngroups = (B + G - 1) / G;
+  long long want = (ngroups + s->waves - 1) / s->waves, cap = (long long)net->n_cu * blocks_per_cu;
+  const long long total_waves = (want < cap ? want : cap) * s->waves;
+  const long long quota = (B + total_waves - 1) / total_waves;
+  double tiles = 0.0;  // live column tiles per step, summed over all waves
+  for (long long wbeg = 0; wbeg < B; wbeg += quota) {
+    const long long wend = wbeg + quota < B ? wbeg + quota : B;
+    for (long long w0 = wbeg; w0 < wend; w0 += G) {
+      const long long nw = (wend - w0) < G ? (wend - w0) : G;
+      tiles += (double)((nw * N + 31) / 32);
+    }
+  }
+  const double dense = tiles * (L * (2.0 + 2.0 * (N - 1)) + (L - 1) * 3.0);  // dense 32x32 layers per step
+  const double kstep = tiles * L * (N - 1);                                  // f32 (radial, edge_attr) k-steps
+  if (net->cfg.precision == 0) {
+    *mfma16_per_walker_step = 0.0;
+    *mfma32_per_walker_step = (16.0 * dense + kstep) / (double)B;
+  } else {
+    *mfma16_per_walker_step = 12.0 * dense / (double)B;
+    *mfma32_per_walker_step = kstep / (double)B;
+  }
+  return PITA_OK;
+}
+
 extern "C" int pita_egnn_forward(pita_egnn_t* net, const float* t, const float* x, const float* beta, float* out,
                                  int64_t B, void* stream) {
   PITA_REQUIRE(net && t && x && out && B >= 0, "pita_egnn_forward: null argument");
@@ -650,12 +701,12 @@ extern "C" int pita_egnn_edm(pita_egnn_t* net, int what, const float* h, const f
 
 extern "C" int pita_egnn_sampler_run(pita_egnn_t* net, float* x, int64_t B, const float* step_tab, int n_steps,
                                      const float* noise, uint64_t seed, uint64_t walker_offset, int64_t step0,
-                                     int remove_mean, float* drift_out, void* stream) {
+                                     int remove_mean, float* drift_out, double* stats_out, void* stream) {
   PITA_REQUIRE(net && x && step_tab && B >= 0 && n_steps >= 0, "pita_egnn_sampler_run: bad argument");
   if (n_steps == 0) return PITA_OK;
   EgnnParams p{};
   p.mode = 3; p.B = B; p.x = x; p.step_tab = step_tab; p.n_steps = n_steps; p.noise = noise;
   p.seed = seed; p.walker_offset = walker_offset; p.step0 = step0; p.remove_mean = remove_mean;
-  p.drift_out = drift_out;
+  p.drift_out = drift_out; p.stats_out = stats_out;
   return egnn_launch(net, p, stream);
 }

@@ -261,6 +261,7 @@ struct MlpSamplerParams {
   int n_steps, remove_mean, n_particles, n_dim;
   unsigned long long seed, walker_offset;
   long long step0;
+  double* stats_out;  // nullable [n_steps][4], as pita_egnn_sampler_run
 };
 
 __device__ __forceinline__ void mlp_wave_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -296,6 +297,7 @@ __global__ void __launch_bounds__(256, 2) mlp_sampler_kernel(MlpSamplerParams q)
       if (STREAM) mlp_tile<NB>(p, SW, lane, hh, xrow, c_in, st[PITA_ST_CNOISE], st[PITA_ST_BETA], emit);
       else mlp_tile<NB>(p, GW, lane, hh, xrow, c_in, st[PITA_ST_CNOISE], st[PITA_ST_BETA], emit);
       mlp_wave_fence();
+      float st_d = 0.f, st_d2 = 0.f, st_n = 0.f, st_n2 = 0.f;
       for (int var = hh; var < D; var += 2) {
         const float xv = xrow[var];
         float xi;
@@ -310,7 +312,20 @@ __global__ void __launch_bounds__(256, 2) mlp_sampler_kernel(MlpSamplerParams q)
         const float Dth = c_s * xv + c_out * frow[var];
         const float sc = (Dth - xv) / hv;
         const float drift = gamma * (sc * g2);
-        xrow[var] = xv + (drift * dt + ((noise_scale * xi) * sqrt_dt));
+        const float dif = noise_scale * xi;
+        if (q.stats_out && cl < nw) {
+          st_d += drift; st_d2 = fmaf(drift, drift, st_d2);
+          st_n += dif; st_n2 = fmaf(dif, dif, st_n2);
+        }
+        xrow[var] = xv + (drift * dt + (dif * sqrt_dt));
+      }
+      if (q.stats_out) {
+        double m4[4] = {(double)st_d, (double)st_d2, (double)st_n, (double)st_n2};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          for (int o = 32; o > 0; o >>= 1) m4[k] += __shfl_xor(m4[k], o, 64);
+          if (lane == 0) atomicAdd(q.stats_out + (size_t)s * 4 + k, m4[k]);
+        }
       }
       mlp_wave_fence();
       if (q.remove_mean) {  // per-dimension particle means, staged through the (now free) F rows
@@ -492,7 +507,7 @@ extern "C" int pita_mlp_forward(pita_mlp_t* net, const float* t, const float* x,
 
 extern "C" int pita_mlp_sampler_run(pita_mlp_t* net, float* x, int64_t B, const float* step_tab, int n_steps,
                                     const float* noise, uint64_t seed, uint64_t walker_offset, int64_t step0,
-                                    int remove_mean, int n_particles, int n_dim, void* stream) {
+                                    int remove_mean, int n_particles, int n_dim, double* stats_out, void* stream) {
   PITA_REQUIRE(net && x && step_tab && B >= 0 && n_steps >= 0, "pita_mlp_sampler_run: bad argument");
   if (n_steps == 0 || B == 0) return PITA_OK;
   const int D = net->cfg.input_dim;
@@ -504,6 +519,7 @@ extern "C" int pita_mlp_sampler_run(pita_mlp_t* net, float* x, int64_t B, const 
   q.m = net->p; q.m.B = B;
   q.x = x; q.step_tab = step_tab; q.noise = noise; q.n_steps = n_steps; q.remove_mean = remove_mean;
   q.n_particles = n_particles; q.n_dim = n_dim; q.seed = seed; q.walker_offset = walker_offset; q.step0 = step0;
+  q.stats_out = stats_out;
   const long long nblk = ((B + 31) / 32 + 3) / 4;
   const unsigned grid = (unsigned)(nblk < 4096 ? nblk : 4096);
   const size_t lds = sizeof(float) * 4 * 2 * 32 * (size_t)D;

@@ -23,7 +23,17 @@ struct ElemParams {
   long long step;
   int remove_mean;
   const long long* walker_ids;  // optional: Philox walker key of row w is walker_ids[w] instead of walker_offset + w
+  double* stats_out;            // OP_EM, nullable [4]: += sum / sum of squares of drift and of noise_scale * xi
 };
+
+// wave reduction in double + one atomic per wave (order of the atomics varies run to run at the 1e-16 level only)
+__device__ __forceinline__ void moments_commit(double* out, int nq, const float* part) {
+  for (int q = 0; q < nq; ++q) {
+    double v = (double)part[q];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out + q, v);
+  }
+}
 
 template <int DIM, int OP>
 __global__ void __launch_bounds__(256) elem_kernel(float* __restrict__ x, const float* __restrict__ drift,
@@ -38,6 +48,7 @@ __global__ void __launch_bounds__(256) elem_kernel(float* __restrict__ x, const 
     const int w = tid / n, i = tid - w * n;
     const bool act = w < nw;
     float v[DIM];
+    float mom[4] = {0.f, 0.f, 0.f, 0.f};
     if (act) {
       const long long base = ((w0 + w) * n + i) * DIM;
       float xi[4] = {0.f, 0.f, 0.f, 0.f};
@@ -51,13 +62,21 @@ __global__ void __launch_bounds__(256) elem_kernel(float* __restrict__ x, const 
       }
 #pragma unroll
       for (int k = 0; k < DIM; ++k) {
-        if (OP == OP_EM) v[k] = x[base + k] + (drift[base + k] * p.dt + ((p.noise_scale * xi[k]) * p.sqrt_dt));
+        if (OP == OP_EM) {
+          const float dr = drift[base + k], dif = p.noise_scale * xi[k];
+          v[k] = x[base + k] + (dr * p.dt + (dif * p.sqrt_dt));
+          if (p.stats_out) {
+            mom[0] += dr; mom[1] = fmaf(dr, dr, mom[1]);
+            mom[2] += dif; mom[3] = fmaf(dif, dif, mom[3]);
+          }
+        }
         if (OP == OP_PRIOR) v[k] = xi[k] * p.scale;
         if (OP == OP_RMEAN) v[k] = x[base + k];
         if (OP == OP_NORMAL) v[k] = xi[k];
         sm[(w * n + i) * DIM + k] = v[k];
       }
     }
+    if (OP == OP_EM && p.stats_out) moments_commit(p.stats_out, 4, mom);
     __syncthreads();
     if (act) {
       const long long base = ((w0 + w) * n + i) * DIM;
@@ -96,6 +115,18 @@ static int launch_elem(float* x, const float* drift, const float* noise, int64_t
   }
   PITA_LAUNCH_CHECK();
   return PITA_OK;
+}
+
+// sum and sum of squares of a device vector (per-step statistics of SDETerms fields, sde_integration.py:150)
+__global__ void __launch_bounds__(256) moments_kernel(const float* __restrict__ v, long long n, double* __restrict__ out) {
+  double s = 0.0, s2 = 0.0;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    const double a = (double)v[e];
+    s += a;
+    s2 += a * a;
+  }
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); s2 += __shfl_xor(s2, o, 64); }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(out, s); atomicAdd(out + 1, s2); }
 }
 
 // ---------------------------------------------------------------------------- EDM preconditioning around a foreign backbone
@@ -337,12 +368,23 @@ using namespace pita;
 
 extern "C" int pita_em_step(float* x, const float* drift, const float* noise, int64_t B, int n, int d, float dt,
                             float noise_scale, float sqrt_dt, uint64_t seed, uint64_t walker_offset, int64_t step,
-                            int remove_mean, void* stream) {
+                            int remove_mean, double* stats_out, void* stream) {
   PITA_REQUIRE(drift, "pita_em_step: drift is null");
   ElemParams p{};
   p.dt = dt; p.noise_scale = noise_scale; p.sqrt_dt = sqrt_dt; p.seed = seed; p.walker_offset = walker_offset;
-  p.step = step; p.remove_mean = remove_mean;
+  p.step = step; p.remove_mean = remove_mean; p.stats_out = stats_out;
   return launch_elem<OP_EM>(x, drift, noise, B, n, d, p, stream);
+}
+
+extern "C" int pita_moments(const float* v, int64_t n, double* out, void* stream) {
+  PITA_REQUIRE(n >= 0 && out, "pita_moments: bad argument");
+  if (n == 0) return PITA_OK;
+  PITA_REQUIRE(v, "pita_moments: null input");
+  const long long nb = (n + 255) / 256;
+  hipLaunchKernelGGL(moments_kernel, dim3((unsigned)(nb < 1024 ? nb : 1024)), dim3(256), 0, (hipStream_t)stream, v,
+                     (long long)n, out);
+  PITA_LAUNCH_CHECK();
+  return PITA_OK;
 }
 
 extern "C" int pita_prior_sample(float* x, const float* noise, int64_t B, int n, int d, float scale, uint64_t seed,

@@ -216,15 +216,27 @@ class EGNN_dynamics(nn.Module):
         return out, vjp
 
     def sampler_run(self, x, step_tab, n_steps, noise=None, seed=0, walker_offset=0, step0=0, remove_mean=True,
-                    drift_out=None, n_particles=None, n_dim=None):
-        """In-place fused Euler-Maruyama steps (pita_egnn_sampler_run); x: [B, n*d] device tensor."""
+                    drift_out=None, n_particles=None, n_dim=None, stats_out=None):
+        """In-place fused Euler-Maruyama steps (pita_egnn_sampler_run); x: [B, n*d] device tensor.  ``stats_out``:
+        optional contiguous float64 device tensor [n_steps, 4] that accumulates the per-step drift / diffusion moments."""
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        if stats_out is not None:
+            assert stats_out.is_cuda and stats_out.dtype == torch.float64 and stats_out.is_contiguous()
+            assert stats_out.numel() >= 4 * int(n_steps)
         assert step_tab.is_cuda and step_tab.dtype == torch.float32 and step_tab.is_contiguous()
         _lib.check(_lib.lib().pita_egnn_sampler_run(
             self._native(x.device), x.data_ptr(), x.shape[0], step_tab.data_ptr(), int(n_steps), _lib.ptr(noise),
             int(seed) & 0xFFFFFFFFFFFFFFFF, int(walker_offset), int(step0), int(bool(remove_mean)),
-            _lib.ptr(drift_out), _lib.stream_ptr(x.device)), "pita_egnn_sampler_run")
+            _lib.ptr(drift_out), _lib.ptr(stats_out), _lib.stream_ptr(x.device)), "pita_egnn_sampler_run")
         return x
+
+
+    def sampler_work(self, B, device):
+        """(16-bit MFMAs, f32 MFMAs) executed per walker-step by the fused sampler at batch B (pita_egnn_sampler_work)."""
+        a, b = ctypes.c_double(), ctypes.c_double()
+        _lib.check(_lib.lib().pita_egnn_sampler_work(self._native(device), int(B), ctypes.byref(a), ctypes.byref(b)),
+                   "pita_egnn_sampler_work")
+        return a.value, b.value
 
 
 def _as_batch(v, B, device):

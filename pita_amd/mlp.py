@@ -93,19 +93,21 @@ class _HipMLP(nn.Module):
 
 
     def sampler_run(self, x, step_tab, n_steps, noise=None, seed=0, walker_offset=0, step0=0, remove_mean=True,
-                    drift_out=None, n_particles=None, n_dim=None):
+                    drift_out=None, n_particles=None, n_dim=None, stats_out=None):
         """In-place fused Euler-Maruyama steps (pita_mlp_sampler_run); x: [B, D] device tensor.  Geometry defaults to
         one "particle" of dimension D (the GMM convention of the integrator)."""
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
         assert step_tab.is_cuda and step_tab.dtype == torch.float32 and step_tab.is_contiguous()
         if drift_out is not None:
             raise NotImplementedError("MLP fused sampler: drift_out is not provided (use the per-step path)")
+        if stats_out is not None:
+            assert stats_out.is_cuda and stats_out.dtype == torch.float64 and stats_out.is_contiguous()
         D = x.shape[1]
         n, d = (1, D) if n_particles is None else (int(n_particles), int(n_dim))
         _lib.check(_lib.lib().pita_mlp_sampler_run(
             self._native(x.device), x.data_ptr(), x.shape[0], step_tab.data_ptr(), int(n_steps), _lib.ptr(noise),
             int(seed) & 0xFFFFFFFFFFFFFFFF, int(walker_offset), int(step0), int(bool(remove_mean)), n, d,
-            _lib.stream_ptr(x.device)), "pita_mlp_sampler_run")
+            _lib.ptr(stats_out), _lib.stream_ptr(x.device)), "pita_mlp_sampler_run")
         return x
 
     def can_fuse(self, n_particles, n_dim):

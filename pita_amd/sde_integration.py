@@ -15,8 +15,10 @@ How the work is laid out on MI355X (differences from the reference are deliberat
     reference's;
   * noise is Philox4x32-10 keyed by (seed, GLOBAL walker index, step): the result does not depend
     on the number of GPUs.  ``noise=`` injects recorded normals for parity tests.
-Per-step ``SDETerms`` are only materialised with ``record_terms=True`` (the reference returns N
-CPU copies of [B,D] tensors of which only means are ever consumed).
+``sde_terms_all`` has N entries like the reference's (:150,:212).  By default each field is a ``TermStats`` (sum,
+sum of squares, count over the global batch, reduced on the device) that answers ``.mean()`` / ``.std()`` -- the only
+things the reference's callers ever ask of these tensors (energytemp_module.py:938-945,1132-1143);
+``record_terms=True`` materialises the full per-step tensors instead (per-step launch path).
 """
 import math
 
@@ -25,7 +27,7 @@ import torch
 
 from . import _lib
 from .data_utils import remove_mean
-from .sdes import SDETerms, VEReverseSDE  # noqa: F401
+from .sdes import SDETerms, TermStats, VEReverseSDE  # noqa: F401
 from .utils import gather_rows, sample_cat_sys
 
 
@@ -89,6 +91,30 @@ class _Comm:
         out = torch.empty((self.world * x.shape[0],) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
         torch.distributed.all_gather_into_tensor(out, x.contiguous())
         return out
+
+    def all_reduce_sum(self, x):
+        if self.world == 1:
+            return x
+        return self.all_gather(x[None]).reshape(self.world, *x.shape).sum(0)
+
+
+def _terms_from_stats(st4, st8, n_elem, n_walk, computed, debiased):
+    """N light SDETerms from the per-step moment buffers (host copies happen once, here).  st4: [N, 4] drift_X /
+    diffusion moments; st8: [N, 8] drift_A, divergence_score, cross_term, dUt_dt moments (debiased regime only)."""
+    h4 = st4.cpu().tolist()
+    h8 = st8.cpu().tolist() if st8 is not None else None
+    out = []
+    for k, r in enumerate(h4):
+        ne, nw = (n_elem, n_walk) if computed[k] else (0, 0)
+        t = SDETerms(drift_X=TermStats(r[0], r[1], ne), drift_A=TermStats(0.0, 0.0, nw),
+                     diffusion=TermStats(r[2], r[3], ne))
+        if debiased:
+            q = h8[k]
+            t.drift_A = TermStats(q[0], q[1], nw)
+            t.divergence_score, t.cross_term, t.dUt_dt = (TermStats(q[2], q[3], nw), TermStats(q[4], q[5], nw),
+                                                          TermStats(q[6], q[7], nw))
+        out.append(t)
+    return out
 
 
 class WeightedSDEIntegrator:
@@ -185,6 +211,7 @@ class WeightedSDEIntegrator:
             s for s in range(start, min(self.end_resampling_step, N)) if (s + 1) % resampling_interval == 0]
         num_unique_idxs = [Bg] * N
         sde_terms_all = []
+        st4 = None if self.record_terms else torch.zeros(N, 4, dtype=torch.float64, device=dev)
         model = self._backbone()
         if getattr(self.sde, "debias_inference", False):
             return self._integrate_debiased(x, comm, tab_h, times, noise, key, off, Bl, Bg, n, d, mean_free,
@@ -197,7 +224,7 @@ class WeightedSDEIntegrator:
             if stop < s:
                 continue
             self._run_steps(model, x, tab, tab_h, s, stop + 1, noise, key, off, n, d, mean_free, inverse_temperature,
-                            sde_terms_all)
+                            sde_terms_all, st4)
             s = stop + 1
             if stop in events:
                 xg = comm.all_gather(x)
@@ -211,6 +238,9 @@ class WeightedSDEIntegrator:
                     x = remove_mean(x, n, d)
         # log-weights are identically zero here; a stride-0 view avoids N*B*4 bytes (reference stacks N copies)
         logweights = torch.zeros(1, Bg, device=dev).expand(N, Bg)
+        if st4 is not None:
+            sde_terms_all = _terms_from_stats(comm.all_reduce_sum(st4), None, Bg * x1.shape[1], Bg,
+                                              [k >= start for k in range(N)], False)
 
         if self.resample_at_end and did_resampling:
             x, a_next, n_unique = self._resample_at_end(x, None, comm, times, energy_function, annealing_factor_schedule,
@@ -242,6 +272,11 @@ class WeightedSDEIntegrator:
         a = torch.zeros(Bl, device=dev)
         logweights, num_unique_idxs, sde_terms_all = [], [], []
         bs = self.batch_size or Bl
+        st4 = st8 = None
+        if not self.record_terms:
+            st4 = torch.zeros(N, 4, dtype=torch.float64, device=dev)
+            st8 = torch.zeros(N, 8, dtype=torch.float64, device=dev)
+        st = _lib.stream_ptr(dev)
         for step in range(N):
             t = times[step].to(dev)
             row = tab_h[step]
@@ -256,7 +291,11 @@ class WeightedSDEIntegrator:
             nz = noise[step].contiguous() if noise is not None else None
             _lib.check(L.pita_em_step(x.data_ptr(), drift.data_ptr(), _lib.ptr(nz), Bl, n, d, float(row[_lib.ST_DT]),
                                       float(row[_lib.ST_NOISE_SCALE]), float(row[_lib.ST_SQRT_DT]), key, off, step, 0,
-                                      _lib.stream_ptr(dev)), "pita_em_step")
+                                      _lib.ptr(st4[step]) if st4 is not None else 0, st), "pita_em_step")
+            if st8 is not None:
+                for j, v in enumerate((terms.drift_A, terms.divergence_score, terms.cross_term, terms.dUt_dt)):
+                    if v is not None:
+                        _lib.check(L.pita_moments(v.data_ptr(), Bl, st8[step, 2 * j:].data_ptr(), st), "pita_moments")
             a = a + terms.drift_A * float(row[_lib.ST_DT])
             if step >= self.end_resampling_step:
                 a = torch.zeros_like(a)
@@ -278,6 +317,9 @@ class WeightedSDEIntegrator:
             if self.record_terms:
                 sde_terms_all.append(terms)
         logweights = torch.stack(logweights)
+        if st4 is not None:
+            sde_terms_all = _terms_from_stats(comm.all_reduce_sum(st4), comm.all_reduce_sum(st8), Bg * x.shape[1], Bg,
+                                              [k >= self.start_resampling_step for k in range(N)], True)
         did_resampling = resampling_interval != -1 and resampling_interval < N
         if self.resample_at_end and did_resampling:
             x, a_next, n_unique = self._resample_at_end(x, a, comm, times, energy_function, gamma_schedule, beta, u_iter,
@@ -326,13 +368,14 @@ class WeightedSDEIntegrator:
         return x, a_next, int(torch.unique(ids).numel())
 
     # ------------------------------------------------------------------ A2-A4 steps [s0, s1)
-    def _run_steps(self, model, x, tab, tab_h, s0, s1, noise, key, off, n, d, mean_free, beta, sde_terms_all):
+    def _run_steps(self, model, x, tab, tab_h, s0, s1, noise, key, off, n, d, mean_free, beta, sde_terms_all, st4=None):
         if s1 <= s0:
             return
         if model is not None and not self.record_terms and (not hasattr(model, "can_fuse") or model.can_fuse(n, d)):
             nz = noise[s0:s1].contiguous() if noise is not None else None
             model.sampler_run(x, tab[s0:s1].contiguous(), s1 - s0, noise=nz, seed=key, walker_offset=off, step0=s0,
-                              remove_mean=mean_free, n_particles=n, n_dim=d)
+                              remove_mean=mean_free, n_particles=n, n_dim=d,
+                              stats_out=st4[s0:s1] if st4 is not None else None)
             return
         # per-step path: any backbone with forward(t, x, beta); drift through ScoreNet, update by pita_em_step
         L = _lib.lib()
@@ -346,7 +389,8 @@ class WeightedSDEIntegrator:
             _lib.check(L.pita_em_step(x.data_ptr(), drift.data_ptr(), _lib.ptr(nz), x.shape[0], n, d,
                                       float(row[_lib.ST_DT]), float(row[_lib.ST_NOISE_SCALE]),
                                       float(row[_lib.ST_SQRT_DT]), key, off, k, int(mean_free),
-                                      _lib.stream_ptr(x.device)), "pita_em_step")
+                                      _lib.ptr(st4[k]) if st4 is not None else 0, _lib.stream_ptr(x.device)),
+                       "pita_em_step")
             if self.record_terms:
                 sde_terms_all.append(SDETerms(drift_X=drift, drift_A=torch.zeros(x.shape[0], device=x.device)))
 
@@ -373,7 +417,7 @@ class WeightedSDEIntegrator:
             _, F = energy_function(x, return_force=True)
             nz = noise[k].contiguous() if noise is not None else None
             _lib.check(L.pita_em_step(x.data_ptr(), F.data_ptr(), _lib.ptr(nz), x.shape[0], n, d, dt, ns, sq, key,
-                                      walker_offset, k, int(self.should_mean_free), _lib.stream_ptr(x.device)),
+                                      walker_offset, k, int(self.should_mean_free), 0, _lib.stream_ptr(x.device)),
                        "pita_em_step")
         return x
 

@@ -44,6 +44,37 @@ class SDETerms:  # sdes.py:34-92
                                if getattr(first, f) is not None else None) for f in SDETerms._FIELDS})
 
 
+class TermStats:
+    """Moments of one ``SDETerms`` field over the GLOBAL walker batch of one step.  The reference returns the full
+    [B, D] / [B] tensors of every step as host copies (sde_integration.py:289) and its callers only ever take
+    ``.mean()`` and ``.std()`` of them (energytemp_module.py:1132-1143); the HIP integrator reduces on the device
+    (pita_egnn_sampler_run / pita_em_step / pita_moments ``stats_out``) and hands back this stand-in, which answers
+    the same two calls with 0-dim CPU tensors.  ``record_terms=True`` on the integrator gives the full tensors."""
+
+    __slots__ = ("s", "s2", "n")
+
+    def __init__(self, s, s2, n):
+        self.s, self.s2, self.n = float(s), float(s2), int(n)
+
+    def numel(self):
+        return self.n
+
+    def mean(self):
+        return torch.tensor(self.s / self.n if self.n > 0 else float("nan"), dtype=torch.float32)
+
+    def std(self):  # unbiased, like torch.Tensor.std()
+        if self.n < 2:
+            return torch.tensor(float("nan"), dtype=torch.float32)
+        var = max(self.s2 - self.s * self.s / self.n, 0.0) / (self.n - 1)
+        return torch.tensor(var ** 0.5, dtype=torch.float32)
+
+    def cpu(self):
+        return self
+
+    def __repr__(self):
+        return f"TermStats(mean={float(self.mean()):.6g}, std={float(self.std()):.6g}, n={self.n})"
+
+
 def _per_walker(t, x):
     return t * torch.ones(x.shape[0], device=x.device) if t.dim() == 0 else t
 

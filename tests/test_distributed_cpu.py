@@ -62,6 +62,80 @@ def test_shard_and_gather_world2():
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
 
 
+def _worker_reduce(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from types import SimpleNamespace
+
+        from pita_amd.sde_integration import WeightedSDEIntegrator, _Comm, _terms_from_stats
+
+        comm = _Comm(None)
+        # per-step moment buffers are summed over ranks before they become TermStats
+        st4 = torch.full((3, 4), float(rank + 1), dtype=torch.float64)
+        tot = comm.all_reduce_sum(st4)
+        assert torch.equal(tot, torch.full((3, 4), 3.0, dtype=torch.float64))
+        terms = _terms_from_stats(tot, None, 20, 4, [True] * 3, False)
+        assert len(terms) == 3 and abs(float(terms[0].diffusion.mean()) - 3.0 / 20) < 1e-7
+        # final gather after MALA: every shard is [valid, set-aside]; the result must be [all valid, all set-aside] (Q7)
+        integ = WeightedSDEIntegrator(sde=SimpleNamespace(), num_integration_steps=1, start_resampling_step=0,
+                                      end_resampling_step=1, post_mcmc_steps=2)
+        Bl = 4
+        nvalid = [3, 2][rank]
+        integ._last_mala_valid = nvalid
+        local = torch.tensor([[10.0 * rank + i] for i in range(Bl)])  # rows 0..nvalid-1 valid, the rest set aside
+        out = integ._gather_final(local, comm, Bl)
+        assert out.reshape(-1).tolist() == [0.0, 1.0, 2.0, 10.0, 11.0, 3.0, 12.0, 13.0], out.reshape(-1).tolist()
+        integ._last_mala_valid = Bl  # nothing set aside anywhere -> plain concatenation
+        out = integ._gather_final(local, comm, Bl)
+        assert out.reshape(-1).tolist() == [0.0, 1.0, 2.0, 3.0, 10.0, 11.0, 12.0, 13.0]
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_stats_reduction_and_final_gather_order_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_reduce, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` (no torchrun environment) must start two rank processes itself and report n_gpus = 2;
+    a launcher that started a different number of ranks than --gpus must be refused.  --dry-run: protocol only, gloo."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--dry-run"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 2 and out["config"]["backend"] == "gloo"
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run"], capture_output=True, text=True,
+                        timeout=300, env=env)
+    assert r1.returncode == 0 and json.loads(r1.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+    bad = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True,
+                        text=True, timeout=300, env=bad)
+    assert r2.returncode != 0 and "WORLD_SIZE=3" in (r2.stderr + r2.stdout)
+
+
 def test_single_rank_comm():
     from pita_amd.sde_integration import _Comm
 

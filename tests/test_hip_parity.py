@@ -380,7 +380,7 @@ def test_elementwise_vs_oracle(pa, golden):
     xc, drc, nzc = x.cuda().clone(), dr.cuda(), nz.cuda()  # keep the device copies alive across the async call
     L = pa._lib.lib()
     pa._lib.check(L.pita_em_step(xc.data_ptr(), drc.data_ptr(), nzc.data_ptr(), 777, 13, 3, 0.05, 1.7,
-                                 float(np.sqrt(0.05)), 0, 0, 0, 1, pa._lib.stream_ptr()))
+                                 float(np.sqrt(0.05)), 0, 0, 0, 1, 0, pa._lib.stream_ptr()))
     np.testing.assert_allclose(xc.cpu().numpy(), xo.numpy(), rtol=1e-5, atol=1e-6)
 
 
@@ -786,6 +786,103 @@ def test_debiased_terms_and_trajectory_golden(pa, golden):
     np.testing.assert_allclose(whole.drift_A.cpu().numpy(), torch.cat([p_.drift_A for p_ in parts]).cpu().numpy(),
                                rtol=2e-5, atol=2e-4)
     assert rel(whole.drift_X, torch.cat([p_.drift_X for p_ in parts])) < 2e-6
+
+
+def _replay_reference_term_logging(sde_terms):
+    """The reference caller's exact access pattern on integrate_sde's 4th return value
+    (energytemp_module.py:938-945 / 1061-1068 loop + _log_sde_term :1132-1143), minus the plotting."""
+    from dataclasses import fields
+
+    logged = {}
+    for term in fields(pa_SDETerms()):
+        if term.name == "drift_X" or term.name == "drift_A" or getattr(sde_terms[0], term.name) is None:
+            continue
+        mean = torch.stack([getattr(sde_terms[i], term.name).mean() for i in range(len(sde_terms))])
+        std = torch.stack([getattr(sde_terms[i], term.name).std() for i in range(len(sde_terms))])
+        logged[term.name] = (mean.cpu().numpy(), std.cpu().numpy())
+    return logged
+
+
+def pa_SDETerms():
+    import pita_amd
+
+    return pita_amd.SDETerms
+
+
+def test_sde_terms_default_return_serves_the_reference_caller(pa, golden):
+    """Default (record_terms=False) integrate_sde returns N indexable SDETerms whose fields answer .mean()/.std():
+    the reference's unchanged logging loop runs on them and reproduces the statistics of the reference's own
+    per-step tensors (goldens), in both regimes."""
+    import copy
+
+    # ---- not-debiased: `diffusion` is the only logged field (drift_X / drift_A are skipped by the caller)
+    g = golden("em_traj_lj13_nodebias.npz")
+    sde, sched, net = lj13_stack(pa, golden)
+    N = int(g["N"])
+    gam = pa.ConstantAnnealingFactorSchedule(4 / 3)
+    e = pa.LennardJonesEnergy(39, 13, 3)
+    integ = pa.WeightedSDEIntegrator(sde=sde, num_integration_steps=N, start_resampling_step=0, end_resampling_step=N,
+                                     resampling_interval=-1, num_negative_time_steps=0, post_mcmc_steps=0)
+    _, _, _, terms, _ = integ.integrate_sde(cu(g["x1"]), e, gam, inverse_temperature=1.0, noise=cu(g["noise"]))
+    assert len(terms) == N and terms[0].divergence_score is None
+    logged = _replay_reference_term_logging(terms)
+    assert set(logged) == {"diffusion"}
+    tab = pa.sde_integration.build_step_table(sched, gam, torch.linspace(1.0, 0.0, N + 1)[:-1], 1.0 / N, 1.0, 1.0)
+    dif = tab[:, pa._lib.ST_NOISE_SCALE][:, None, None] * torch.tensor(g["noise"])  # sdes.py:250
+    np.testing.assert_allclose(logged["diffusion"][0], dif.mean(dim=(1, 2)).numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(logged["diffusion"][1], dif.reshape(N, -1).std(dim=1).numpy(), rtol=1e-5)
+    dX = torch.tensor(g["drift_X"])
+    got = np.array([[float(t.drift_X.mean()), float(t.drift_X.std())] for t in terms])
+    # atol: means are sums of mean-free drifts (~1e-6 relative cancellation residue)
+    np.testing.assert_allclose(got[:, 1], dX.reshape(N, -1).std(dim=1).numpy(), rtol=3e-3)
+    np.testing.assert_allclose(got[:, 0], dX.mean(dim=(1, 2)).numpy(), atol=1e-3 * float(dX.abs().max()))
+    assert all(t.drift_A.numel() == 32 and float(t.drift_A.mean()) == 0.0 for t in terms)
+    # same statistics from the per-step launch path (pita_em_step stats_out): a foreign backbone takes this route
+    integ2 = pa.WeightedSDEIntegrator(sde=pa.VEReverseSDE(noise_schedule=sched, score_net=pa.ScoreNet(_Foreign(net)),
+                                                          debias_inference=False),
+                                      num_integration_steps=N, start_resampling_step=0, end_resampling_step=N,
+                                      resampling_interval=-1, num_negative_time_steps=0, post_mcmc_steps=0)
+    _, _, _, terms2, _ = integ2.integrate_sde(cu(g["x1"]), e, gam, inverse_temperature=1.0, noise=cu(g["noise"]))
+    got2 = np.array([[float(t.diffusion.mean()), float(t.diffusion.std()), float(t.drift_X.std())] for t in terms2])
+    np.testing.assert_allclose(got2[:, 1], logged["diffusion"][1], rtol=1e-6)
+    np.testing.assert_allclose(got2[:, 2], got[:, 1], rtol=1e-4)
+
+    # ---- debiased: divergence_score / cross_term / dUt_dt / diffusion are logged
+    g = golden("em_traj_lj13_debias.npz")
+    w = golden("egnn_weights_trainedlike.npz")
+    net = make_net(pa, 13, 3, w)
+    from pita_amd.energy_net import EnergyNet
+
+    sde = pa.VEReverseSDE(noise_schedule=sched, score_net=pa.ScoreNet(net), energy_net=EnergyNet(copy.deepcopy(net)),
+                          debias_inference=True)
+    N = int(g["N"])
+    integ = pa.WeightedSDEIntegrator(sde=sde, num_integration_steps=N, start_resampling_step=1, end_resampling_step=7,
+                                     resampling_interval=2, num_negative_time_steps=0, post_mcmc_steps=0, batch_size=12)
+    _, _, _, terms, _ = integ.integrate_sde(cu(g["x1"]), e, gam, inverse_temperature=1.0, noise=cu(g["noise"]),
+                                            resample_u=[float(u[0]) for u in g["u"]])
+    assert len(terms) == N
+    logged = _replay_reference_term_logging(terms)
+    assert set(logged) == {"divergence_score", "cross_term", "dUt_dt", "diffusion"}
+    for name in ("divergence_score", "cross_term", "dUt_dt"):
+        ref = torch.tensor(g[name])  # [N, B] of the reference run
+        # step 0 lies before start_resampling_step: the walkers are frozen there and the HIP integrator does not
+        # evaluate the drift terms (documented: their statistics are NaN); compare the steps that move walkers
+        assert np.isnan(logged[name][0][0])
+        np.testing.assert_allclose(logged[name][0][1:], ref.mean(dim=1).numpy()[1:], rtol=2e-2, atol=5e-2)
+        np.testing.assert_allclose(logged[name][1][1:], ref.std(dim=1).numpy()[1:], rtol=2e-2, atol=5e-2)
+    dA = np.array([float(t.drift_A.mean()) for t in terms])
+    np.testing.assert_allclose(dA[1:], torch.tensor(g["drift_A"]).mean(dim=1).numpy()[1:], rtol=2e-2, atol=5e-2)
+
+
+class _Foreign(torch.nn.Module):
+    """A backbone the integrator cannot fuse (no sampler_run / edm): only forward(t, x, beta)."""
+
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+
+    def forward(self, t, x, beta):
+        return self.net.forward(t, x, beta)
 
 
 def test_debiased_resample_at_end_golden(pa, golden):

@@ -18,7 +18,7 @@ libs = []
 for path in sys.argv[1:]:
     L = ctypes.CDLL(path)
     L.pita_egnn_create.argtypes = [POINTER(c_void_p), POINTER(EgnnConfig), c_void_p, c_int64]
-    L.pita_egnn_sampler_run.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_uint64, c_uint64, c_int64, c_int, c_void_p, c_void_p]
+    L.pita_egnn_sampler_run.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_uint64, c_uint64, c_int64, c_int, c_void_p, c_void_p, c_void_p]
     cfg = EgnnConfig(13, 3, 32, 3, 2, 1, 1, 15.0, 0, 1)
     h = c_void_p()
     assert L.pita_egnn_create(ctypes.byref(h), ctypes.byref(cfg), flat.ctypes.data_as(c_void_p), len(flat)) == 0
@@ -27,8 +27,8 @@ sp = torch.cuda.current_stream().cuda_stream
 for rep in range(3):
     for path, L, h in libs:
         x = x0.clone()
-        L.pita_egnn_sampler_run(h, x.data_ptr(), B, tab.data_ptr(), S, None, 3, 0, 0, 1, None, sp); torch.cuda.synchronize()
+        L.pita_egnn_sampler_run(h, x.data_ptr(), B, tab.data_ptr(), S, None, 3, 0, 0, 1, None, None, sp); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        L.pita_egnn_sampler_run(h, x.data_ptr(), B, tab.data_ptr(), S, None, 3, 0, 0, 1, None, sp); torch.cuda.synchronize()
+        L.pita_egnn_sampler_run(h, x.data_ptr(), B, tab.data_ptr(), S, None, 3, 0, 0, 1, None, None, sp); torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         print(f"{path}: {dt*1e3:.2f} ms per {S}-step launch -> {B*S/dt:.3e} walker-steps/s", flush=True)

@@ -21,6 +21,7 @@ gam = pa.ConstantAnnealingFactorSchedule(4 / 3)
 e = pa.LennardJonesEnergy(39, 13, 3)
 single = SimpleNamespace(trainer=SimpleNamespace(world_size=1, global_rank=0))
 ok = True
+terms_ok = True
 stages = {"sde only": dict(num_negative_time_steps=0, post_mcmc_steps=0),
           "+ descent": dict(num_negative_time_steps=5, dt_negative_time=1e-5, post_mcmc_steps=0),
           "+ descent (langevin)": dict(num_negative_time_steps=5, dt_negative_time=1e-5, post_mcmc_steps=0, do_langevin=True),
@@ -39,11 +40,14 @@ for debias in (False, True):
         end = extra.pop("end_resampling_step_override", None)
         kw = dict(sde=sde, num_integration_steps=N, start_resampling_step=0,
                   end_resampling_step=N if end is None else min(end, N - 1), resampling_interval=3, seed=11, batch_size=8, **extra)  # chunks of 8 tile both the 16-walker shards and the whole batch
-        outs = []
+        outs, stats = [], []
         for lm in (None, single):  # None -> torch.distributed world; `single` -> one rank does everything
             integ = pa.WeightedSDEIntegrator(lightning_module=lm, **kw)
-            x, logw, uniq, _, acc = integ.integrate_sde(x1, e, gam, inverse_temperature=1.0, resample_u=us)
+            x, logw, uniq, terms, acc = integ.integrate_sde(x1, e, gam, inverse_temperature=1.0, resample_u=us)
             outs.append((x.cpu(), logw.cpu(), uniq, acc))
+            stats.append([(float(t.diffusion.mean()), float(t.diffusion.std()), float(t.drift_X.std()), t.diffusion.numel())
+                          for t in terms])
+        terms_ok = terms_ok and len(stats[0]) == N and np.allclose(stats[0], stats[1], rtol=1e-5, atol=1e-7)
         xa, xb = outs[0][0], outs[1][0]
         bit = torch.equal(xa, xb)
         close = torch.allclose(xa, xb, rtol=1e-4, atol=1e-5)
@@ -53,6 +57,8 @@ for debias in (False, True):
             print(f"debias={debias} {name}: x {'bitwise' if bit else 'allclose' if close else 'DIFFERENT (max %.3g)' % float((xa - xb).abs().max())}, "
                   f"unique {outs[0][2] == outs[1][2]}, rates {outs[0][3]} vs {outs[1][3]}, finite logp {finite}/{B}", flush=True)
         ok = ok and same
+if rank == 0:
+    print("per-step SDETerms statistics, 2 ranks vs 1 rank: " + ("terms identical" if terms_ok else "TERMS DIFFER"), flush=True)
 torch.distributed.barrier()
 torch.distributed.destroy_process_group()
-sys.exit(0 if ok else 1)
+sys.exit(0 if (ok and terms_ok) else 1)
