@@ -93,12 +93,12 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def build_model(pa, n, d, seed=12345):
+def build_model(pa, n, d, seed=12345, precision=None):
     import torch
 
     torch.manual_seed(seed)
     return pa.EGNN_dynamics(n, d, hidden_nf=32, n_layers=3, recurrent=True, tanh=True, attention=True,
-                            condition_time=True, condition_temperature=True, agg="sum")
+                            condition_time=True, condition_temperature=True, agg="sum", precision=precision)
 
 
 def make_target(pa, cfg, dev):
@@ -339,6 +339,8 @@ def main():
     ap.add_argument("--no-debiased", action="store_true", help="skip the secondary debiased-regime measurement")
     ap.add_argument("--cpu-walkers", type=int, default=512, help="CPU sample: the reference's own inference chunk for LJ13")
     ap.add_argument("--cpu-steps", type=int, default=0, help="CPU sample steps (default sized for ~10-20 s)")
+    ap.add_argument("--precision", choices=["f32", "bf16x3", "f16x2"], default=None,
+                    help="dense-layer arithmetic of the EGNN kernel (default: the library's)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / timing protocol only, no kernels and no GPU (gloo): CPU test of the "
                          "multi-rank path; the JSON carries value null")
@@ -404,7 +406,7 @@ def main():
     chunk = args.chunk or (math.gcd(K, W) if W > 0 else K)
     assert K % chunk == 0 and W % chunk == 0
 
-    net = build_model(pita_amd, n, d)
+    net = build_model(pita_amd, n, d, precision=args.precision)
     sched = pita_amd.ElucidatingNoiseSchedule(sigma_min=cfg["sigma_min"], sigma_max=80.0, rho=7)
     gam = pita_amd.ConstantAnnealingFactorSchedule(4 / 3)
     NGRID = 1000  # the 1000-step time grid of the reference config; K+W steps walk along it (wrapping)
@@ -478,6 +480,7 @@ def main():
                 "achieved_algorithmic": walker_steps_per_s * alg / 1e12,
                 "algorithmic_flop_per_walker_step": alg, "algorithmic_bytes_per_launch": 2 * B * D * 4,
                 "ms_per_launch": avg_ms, "launches": n_launch,
+                "dense_layer_arithmetic": {0: "f32 MFMA", 1: "bf16 MFMA, 3-piece split", 2: "f16 MFMA, 2-piece split"}[net.precision],
                 "note": "achieved/frac count the 16-bit matrix-pipe flops the kernel EXECUTES (fp32-accurate split "
                         "products included) against the dense 16-bit MFMA peak; achieved_algorithmic counts the "
                         "reference's fp32 formulation (SURVEY 8(d)) and has no frac.  The kernel is VALU-issue-bound "

@@ -131,10 +131,14 @@ typedef struct {
   float coords_range;   /* 15.0 in the reference */
   int feature_layout;   /* 0 = "pita": the reference's t/beta interleave quirk
                            (egnn_temp_conditioned.py:68-78); 1 = per-node (t, beta) */
-  int precision;        /* arithmetic of the dense layers, both fp32-accurate:
+  int precision;        /* arithmetic of the dense layers, all fp32-accurate:
                            0 = v_mfma_f32_32x32x2_f32 (bit-exact fp32 fmaf chains),
                            1 = bf16 matrix pipe with an exact 3-way operand split (6 products,
-                               error <= 2^-24 |w||x|: fp32-equivalent, not bit-identical to 0) */
+                               error <= 2^-24 |w||x|: fp32-equivalent, not bit-identical to 0),
+                           2 = f16 matrix pipe with a 2-way round-to-nearest operand split (3 products,
+                               each operand within 2^-24 relative; operands travel scaled by 16, so
+                               |activations| must stay below 4094; forward / fused sampler only -- the
+                               derivative kernels of the same handle run mode 1) */
 } pita_egnn_config;
 
 /* `weights` is a HOST pointer to the reference state_dict flattened in its own key order:

@@ -134,6 +134,77 @@ struct WFrag<1> {
   }
 };
 
+// PREC 2: the f16 matrix pipe with a TWO-piece round-to-nearest split for the PER-EDGE dense layers (W2, Wc1) and
+//   the node output layer Wn2, whose inputs are SiLU outputs; the per-node layers that read the node features or the
+//   message aggregate (Wa, Wb, Wn1a, Wn1b: unbounded sums) stay on the PREC 1 path.
+//   x1 = f16(x), x2 = f16(x - x1) (the remainder is exact in fp32), so |x - x1 - x2| <= 2^-24 |x|: the size of one
+//   fp32 rounding.  Weights are split the same way on the host; the three products W2X1, W1X2, W1X1 (each exact in the
+//   fp32 accumulator) leave out W2X2 <= 2^-24 |w||x|.  Half the MFMAs of PREC 1, and 4 VALU instructions per operand
+//   pair instead of 11 (v_cvt_pk_f16_f32, two v_fma_mix_f32, v_cvt_pk_f16_f32).
+//   f16 has a 5-bit exponent.  Low end: the second piece of |x| < 2^-2 falls into the f16 denormals (honoured by the
+//   MFMA: tools/ubench/isa_rates.hip), absolute granularity 2^-24; weights (|w| ~ 0.1) therefore travel scaled by
+//   F16_SW = 16 (exact power of two; their low piece is then normal down to |w| = 2^-6), activations by F16_SX, and the
+//   accumulator holds F16_SX F16_SW times the true sum.  High end: F16_SX |activation| must stay below 65504; beyond
+//   that the conversion gives inf, the products NaN, and the launch wrapper recomputes the affected walkers on the
+//   PREC 1 path (egnn_kernel.hip: repair launch), so the limit costs time, never correctness.
+constexpr float F16_SX = 1.0f, F16_SW = 16.0f;
+constexpr float F16_UNSCALE = 1.0f / (F16_SX * F16_SW);
+constexpr int MAT_WH = 1024;  // 32-bit words per f16-split packed matrix: [piece 2][kstep 2][lane 64][4]
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f16x8 as_f16x8(u32x4 v) { return __builtin_bit_cast(f16x8, v); }
+// x - float(low / high half of pk) in ONE instruction (the compiler would emit v_cvt_f32_f16 + v_sub_f32); exact
+__device__ __forceinline__ float f16_rem_lo(unsigned pk, float x) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(x));
+  return r;
+}
+__device__ __forceinline__ float f16_rem_hi(unsigned pk, float x) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(x));
+  return r;
+}
+
+template <>
+struct WFrag<2> {
+  u32x4 w[2][2];  // [piece][k-step], 8 f16 each
+  __device__ __forceinline__ void load(const float* __restrict__, const unsigned* __restrict__ m16, int mat, int lane) {
+    const u32x4* p = reinterpret_cast<const u32x4*>(m16 + (size_t)mat * MAT_WH) + lane;
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) w[pc][st] = p[(pc * 2 + st) * 64];
+  }
+  // `in` carries F16_SX times the true activations
+  static __device__ __forceinline__ void split(const f32x16& in, u32x4 (&x)[2][2]) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float a = in[8 * st + 2 * q], b = in[8 * st + 2 * q + 1];
+        const unsigned p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, f16x2));
+        const float ra = f16_rem_lo(p1, a), rb = f16_rem_hi(p1, b);
+        x[0][st][q] = p1;
+        x[1][st][q] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{ra, rb}, f16x2));
+      }
+  }
+  __device__ __forceinline__ f32x16 mul_split(const u32x4 (&x)[2][2], f32x16 acc) const {
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {  // smallest terms first
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(w[1][st]), as_f16x8(x[0][st]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(w[0][st]), as_f16x8(x[1][st]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(w[0][st]), as_f16x8(x[0][st]), acc, 0, 0, 0);
+    }
+    return acc;
+  }
+  __device__ __forceinline__ f32x16 mul(const f32x16& in, f32x16 acc) const {
+    u32x4 x[2][2];
+    split(in, x);
+    return mul_split(x, acc);
+  }
+};
+
 // ---- packed fp32 helpers.  Measured on gfx950: a wave64 VALU instruction occupies its SIMD's issue for 4 cycles
 // (8 for v_exp/v_rcp) whether it is v_mul_f32 or v_pk_mul_f32, so packed math (2 lanes-worth of fp32 per
 // instruction) halves the issue cost of every mul/add/fma around the transcendentals.
@@ -160,6 +231,37 @@ __device__ __forceinline__ void silu16(f32x16& m) {
     m[2 * q + 1] = y.y;
   }
 }
+// PREC 2 forms.  silu16_out: true-scale pre-activation in, F16_SX-scaled activation out (the scale rides on the
+// reciprocal's argument: no extra instruction).  silu16_acc: the MFMA accumulator (F16_SX F16_SW times the true
+// pre-activation) in, F16_SX-scaled activation out: one multiply more per element.
+__device__ __forceinline__ f32x2 silu2_scaled(f32x2 v) {
+  f32x2 e;
+  e.x = __builtin_amdgcn_exp2f(v.x);
+  e.y = __builtin_amdgcn_exp2f(v.y);
+  const f32x2 c = {1.0f / F16_SX, 1.0f / F16_SX};
+  const f32x2 d = __builtin_elementwise_fma(e, c, c);
+  f32x2 r;
+  r.x = __builtin_amdgcn_rcpf(d.x);
+  r.y = __builtin_amdgcn_rcpf(d.y);
+  return v * r;
+}
+__device__ __forceinline__ void silu16_out(f32x16& m) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const f32x2 y = silu2_scaled(f32x2{m[2 * q], m[2 * q + 1]});
+    m[2 * q] = y.x;
+    m[2 * q + 1] = y.y;
+  }
+}
+__device__ __forceinline__ void silu16_acc(f32x16& m) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const f32x2 y = silu2_scaled(f32x2{m[2 * q], m[2 * q + 1]} * F16_UNSCALE);
+    m[2 * q] = y.x;
+    m[2 * q + 1] = y.y;
+  }
+}
+
 __device__ __forceinline__ float dot16(const f32x16& w, const f32x16& m) {
   f32x2 acc = {0.f, 0.f};
 #pragma unroll
@@ -178,10 +280,14 @@ __device__ __forceinline__ float xhalf_sum(float v) {
 struct pita_egnn {
   pita_egnn_config cfg;
   unsigned* d_mats16 = nullptr;  // [L][M_COUNT][3][2][64][4]  bf16-split fragments
+  unsigned* d_mats16h = nullptr; // [L][M_COUNT][2][2][64][4]  f16-split fragments of F16_SW x the matrices (forward only)
   float* d_mats = nullptr;       // [L][M_COUNT][4][64][4]     f32 fragments
   float* d_vecs = nullptr;       // [VEC_EMB_F + L*VEC_LAYER_F]
+  float* d_vecs_h = nullptr;     // the same vectors with the PREC 2 scale factors folded in
   const void* shape = nullptr;   // pita::EgnnShape of egnn_kernel.hip
   int n_cu = 256;
   float* d_ws = nullptr;         // reverse-mode checkpoint scratch (egnn_vjp_kernel.hip), grown on demand
   size_t ws_bytes = 0;
+  void* d_bk = nullptr;          // precision 2 sampler: walker backup + owed-moments markers for the repair launch
+  size_t bk_bytes = 0;
 };

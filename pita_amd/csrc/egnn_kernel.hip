@@ -35,7 +35,8 @@
 namespace pita {
 
 struct EgnnParams {
-  const unsigned* mats16;  // [L][M_COUNT][3][2][64][4]  bf16-split fragments (PREC 1)
+  const unsigned* mats16;  // [L][M_COUNT][3][2][64][4]  bf16-split fragments (PREC 1, and the per-node layers of PREC 2)
+  const unsigned* mats16h; // [L][M_COUNT][2][2][64][4]  f16-split fragments (PREC 2: W2, Wc1, Wn2)
   const float* mats;  // [L][M_COUNT][4][64][4]
   const float* vecs;  // [VEC_EMB_F + L*VEC_LAYER_F]
   int n_layers, in_nf, attention, tanh_on, feature_layout;
@@ -57,6 +58,12 @@ struct EgnnParams {
   int remove_mean;
   float* drift_out;
   double* stats_out;  // nullable [n_steps][4]: += sum / sum of squares of drift_X and of the diffusion term
+  // PREC 2 runs as two launches (egnn_launch): the f16 kernel, then the PREC 1 kernel with repair = 1, which recomputes
+  // exactly those walker groups whose results came out non-finite (an activation beyond the f16 range) and exits at
+  // once everywhere else
+  int repair;
+  const float* x_backup;  // mode 3: the walkers as they were before the f16 launch
+  int* bad_from;          // mode 3 with stats_out: [B*N] first step whose moments the f16 launch left out (INT_MAX: none)
 };
 
 template <int N, int DIM, int G, int WAVES>
@@ -125,6 +132,29 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
 #pragma unroll
       for (int k = 0; k < DIM; ++k) xcur[T][k] = valid[T] ? src[(walker0 * N + col[T]) * DIM + k] : 0.0f;
     }
+    int bad_from[NT];  // per (walker, particle): first step whose moments are still owed (see EgnnParams::repair)
+#pragma unroll
+    for (int T = 0; T < NT; ++T) bad_from[T] = 0x7fffffff;
+    if (PREC != 2 && p.repair) {
+      bool bad = false;
+#pragma unroll
+      for (int T = 0; T < NT; ++T)
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          const float v = (mode == 3) ? xcur[T][k] : (valid[T] ? p.out[(walker0 * N + col[T]) * DIM + k] : 0.0f);
+          bad = bad || !__builtin_isfinite(v);
+        }
+      if (!__any(bad)) continue;  // wave-uniform: this group's f16 result stands
+      if (mode == 3) {
+#pragma unroll
+        for (int T = 0; T < NT; ++T) {
+#pragma unroll
+          for (int k = 0; k < DIM; ++k)
+            xcur[T][k] = valid[T] ? p.x_backup[(walker0 * N + col[T]) * DIM + k] : 0.0f;
+          if (p.stats_out && p.bad_from && valid[T]) bad_from[T] = p.bad_from[walker0 * N + col[T]];
+        }
+      }
+    }
 
     const int nsteps = (mode == 3) ? p.n_steps : 1;
     for (int step = 0; step < nsteps; ++step) {
@@ -191,12 +221,18 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
       float* posnext = posbuf1;
       for (int l = 0; l < L; ++l) {
         const float* mats = p.mats + (size_t)l * M_COUNT * MAT_F;
-        const unsigned* mats16 = p.mats16 + (size_t)l * M_COUNT * MAT_W;
+        const unsigned* mats16 = p.mats16 + (size_t)l * M_COUNT * MAT_W;    // bf16 three-piece fragments
+        const unsigned* mats16h = p.mats16h + (size_t)l * M_COUNT * MAT_WH;  // f16 two-piece fragments (PREC 2)
+        constexpr int NPREC = PREC == 2 ? 1 : PREC;                          // arithmetic of the per-node layers
         const float* vl = lds + VEC_EMB_F + l * VEC_LAYER_F + hh * 16;
         const bool last = (l == L - 1);
+        // the last layer's aggregate is dead: a multiplier instead of 16 selects (and it undoes the PREC 2 scale)
+        const float aggw = last ? 0.0f : (PREC == 2 ? 1.0f / F16_SX : 1.0f);
+        // PREC 2: SiLU outputs travel F16_SX-scaled and the accumulators of W2 / Wc1 / Wn2 hold F16_SX F16_SW x their
+        // true value (egnn_common.h); the bias / gate / head vectors arrive pre-scaled from the host (pita_egnn_create)
         // ---- partner table PB[col] = Wb h_col
         {
-          WFrag<PREC> wb;
+          WFrag<NPREC> wb;
           wb.load(mats, mats16, M_WB, lane);
 #pragma unroll
           for (int T = 0; T < NT; ++T) {
@@ -213,8 +249,8 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
         wave_lds_fence();
 
         WFrag<PREC> w2f, wc1f;
-        w2f.load(mats, mats16, M_W2, lane);
-        wc1f.load(mats, mats16, M_WC1, lane);
+        w2f.load(mats, PREC == 2 ? mats16h : mats16, M_W2, lane);
+        wc1f.load(mats, PREC == 2 ? mats16h : mats16, M_WC1, lane);
         // A operand of the extra k-step that adds w_r*radial + w_e*edge_attr: A[out][k] = (w_r | w_e)
         const float a_re = lds[VEC_EMB_F + l * VEC_LAYER_F + V_WRE * EH + lane];
         const float b_att = lds[VEC_EMB_F + l * VEC_LAYER_F + V_COUNT * EH];
@@ -225,7 +261,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
           // own first-layer term  Ai = Wa h_i + b1
           f32x16 Ai;
           {
-            WFrag<PREC> wa;
+            WFrag<NPREC> wa;
             wa.load(mats, mats16, M_WA, lane);
             Ai = wa.mul(hfeat[T], lds_vec16(vl + V_B1 * EH));
           }
@@ -252,22 +288,25 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
             // edge MLP layer 1 (:232-237,:270-271): Wa h_i + Wb h_j + b1, then one k-step [w_r|w_e]·[radial;ea]
             f32x16 m = Ai + lds_vec16(PB + cj * PBS + hh * 16);
             m = __builtin_amdgcn_mfma_f32_32x32x2f32(a_re, hh ? ea : radial, m, 0, 0, 0);
-            silu16(m);
+            if (PREC == 2) silu16_out(m); else silu16(m);
             m = w2f.mul(m, lds_vec16(vl + V_B2 * EH));
-            silu16(m);
+            if (PREC == 2) silu16_acc(m); else silu16(m);
             if (p.attention) {  // :259-260,:273-275
               const float att = fast_sigmoid(xhalf_sum(dot16(lds_vec16(vl + V_WATT * EH), m)) + b_att);
               m *= att;
             }
-            if (!last) agg += m;  // node_model aggregation (:284)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) agg[r] = fmaf(m[r], aggw, agg[r]);  // node_model aggregation (:284)
             // coordinate head (:245-256,:297-298)
             f32x16 c1 = wc1f.mul(m, lds_vec16(vl + V_BC1 * EH));
-            silu16(c1);
+            if (PREC == 2) silu16_acc(c1); else silu16(c1);
             float cs = xhalf_sum(dot16(lds_vec16(vl + V_WC2 * EH), c1));
             if (p.tanh_on) cs = accurate_tanh(cs) * p.coord_scale;
-            const float nrm = sqrtf(radial + 1e-8f) + 1.0f;
+            // 1 / (|d| + 1) on the transcendental unit (v_sqrt_f32, v_rcp_f32: ~1 ulp each) instead of the IEEE
+            // division / square-root expansions (~45 instructions per edge)
+            const float inrm = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(radial + 1e-8f) + 1.0f);
 #pragma unroll
-            for (int k = 0; k < DIM; ++k) xacc[k] = fmaf(df[k] / nrm, cs, xacc[k]);
+            for (int k = 0; k < DIM; ++k) xacc[k] = fmaf(df[k] * inrm, cs, xacc[k]);
           }
           // coordinate update (:306,:318): other tiles still read the old coordinates
 #pragma unroll
@@ -276,14 +315,16 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
             if (hh == 0) posnext[col[T] * DIM + k] = posi[T][k];
           }
           if (!last) {  // node model (:239-243,:284-291), recurrent
-            WFrag<PREC> wn;
+            WFrag<NPREC> wn;
             wn.load(mats, mats16, M_WN1A, lane);
             f32x16 n1 = wn.mul(hfeat[T], lds_vec16(vl + V_BN1 * EH));
             wn.load(mats, mats16, M_WN1B, lane);
             n1 = wn.mul(agg, n1);
-            silu16(n1);
-            wn.load(mats, mats16, M_WN2, lane);
-            f32x16 o = wn.mul(n1, lds_vec16(vl + V_BN2 * EH));
+            if (PREC == 2) silu16_out(n1); else silu16(n1);
+            WFrag<PREC> wo;
+            wo.load(mats, PREC == 2 ? mats16h : mats16, M_WN2, lane);
+            f32x16 o = wo.mul(n1, lds_vec16(vl + V_BN2 * EH));
+            if (PREC == 2) o *= F16_UNSCALE;
             hfeat[T] += o;
           }
         }
@@ -349,8 +390,17 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
               p.drift_out[(walker0 * N + col[T]) * DIM + k] = drift;
             const float dif = noise_scale * xi[k];  // sdes.py:250
             if (p.stats_out && valid[T] && hh == 0) {
-              st_d += drift; st_d2 = fmaf(drift, drift, st_d2);
-              st_n += dif; st_n2 = fmaf(dif, dif, st_n2);
+              bool take = true;
+              if (PREC == 2) {  // leave non-finite values to the repair launch and remember from which step on
+                take = __builtin_isfinite(drift);
+                if (!take && bad_from[T] == 0x7fffffff) bad_from[T] = step;
+              } else if (p.repair) {
+                take = step >= bad_from[T];
+              }
+              if (take) {
+                st_d += drift; st_d2 = fmaf(drift, drift, st_d2);
+                st_n += dif; st_n2 = fmaf(dif, dif, st_n2);
+              }
             }
             xn[T][k] = xcur[T][k] + (drift * dt + (dif * sqrt_dt));
             if (hh == 0) scr[col[T] * DIM + k] = xn[T][k];
@@ -387,10 +437,12 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
 
     if (mode == 3) {
 #pragma unroll
-      for (int T = 0; T < NT; ++T)
+      for (int T = 0; T < NT; ++T) {
 #pragma unroll
         for (int k = 0; k < DIM; ++k)
           if (valid[T] && hh == 0) p.x[(walker0 * N + col[T]) * DIM + k] = xcur[T][k];
+        if (PREC == 2 && p.stats_out && p.bad_from && valid[T] && hh == 0) p.bad_from[walker0 * N + col[T]] = bad_from[T];
+      }
     }
     wave_lds_fence();
   }
@@ -400,7 +452,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
 
 struct EgnnShape {
   int n, dim, G, waves;
-  void (*kernel[2][2])(EgnnParams);  // [PREC][SAMPLER]
+  void (*kernel[3][2])(EgnnParams);  // [PREC][SAMPLER]
   size_t (*lds_bytes)(int);
 };
 
@@ -409,7 +461,8 @@ static size_t lds_bytes_of(int L) { return EgnnCfg<N, DIM, G, WAVES>::lds_bytes(
 
 #define PITA_EGNN_SHAPE(N, DIM, G, WAVES) \
   EgnnShape { N, DIM, G, WAVES, {{egnn_kernel<N, DIM, G, WAVES, 0, false>, egnn_kernel<N, DIM, G, WAVES, 0, true>}, \
-                                 {egnn_kernel<N, DIM, G, WAVES, 1, false>, egnn_kernel<N, DIM, G, WAVES, 1, true>}}, \
+                                 {egnn_kernel<N, DIM, G, WAVES, 1, false>, egnn_kernel<N, DIM, G, WAVES, 1, true>}, \
+                                 {egnn_kernel<N, DIM, G, WAVES, 2, false>, egnn_kernel<N, DIM, G, WAVES, 2, true>}}, \
               lds_bytes_of<N, DIM, G, WAVES> }
 
 // Instantiated (n_particles, n_dim) shapes: DW4, LJ13, alanine dipeptide (22 atoms), LJ55.
@@ -440,7 +493,8 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
   if (cfg->hidden_nf != EH)
     return fail(PITA_EUNSUPPORTED, "pita_egnn_create: hidden_nf=%d (the HIP kernel implements 32)", cfg->hidden_nf);
   PITA_REQUIRE(cfg->in_node_nf == 1 || cfg->in_node_nf == 2, "in_node_nf must be 1 or 2");
-  PITA_REQUIRE(cfg->precision == 0 || cfg->precision == 1, "precision must be 0 (f32 MFMA) or 1 (bf16x3 split)");
+  PITA_REQUIRE(cfg->precision >= 0 && cfg->precision <= 2,
+               "precision must be 0 (f32 MFMA), 1 (bf16 three-piece split) or 2 (f16 two-piece split)");
   PITA_REQUIRE(cfg->n_layers >= 1 && cfg->n_layers <= 16, "n_layers out of range");
   PITA_REQUIRE(n_weights == pita_egnn_num_weights(cfg), "pita_egnn_create: got %lld weights, expected %lld",
                (long long)n_weights, (long long)pita_egnn_num_weights(cfg));
@@ -456,6 +510,9 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
   float* h_vecs = new float[n_vecs]();
   const size_t n_mats16 = (size_t)L * M_COUNT * MAT_W;
   unsigned* h_mats16 = new unsigned[n_mats16];
+  const size_t n_mats16h = (size_t)L * M_COUNT * MAT_WH;
+  unsigned* h_mats16h = new unsigned[n_mats16h]();
+  float* h_vecs_h = new float[n_vecs]();
   // walk the state_dict order
   const float* q = w;
   const float* emb_w = q; q += H * nf;
@@ -498,6 +555,23 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
             dst[(((size_t)pc * 2 + st) * 64 + lane) * 4 + qd] = pcs[0][pc] | (pcs[1][pc] << 16);
         }
   };
+  // f16 two-piece round-to-nearest split of F16_SW x the same fragments (PREC 2): [piece][kstep][lane][4]
+  auto f16_bits = [](float v) { _Float16 h = (_Float16)v; unsigned short u; memcpy(&u, &h, 2); return (unsigned)u; };
+  auto pack_mat16h = [&](unsigned* dst, const float* M, int ld, int col0, float sc) {
+    for (int lane = 0; lane < 64; ++lane)
+      for (int st = 0; st < 2; ++st)
+        for (int qd = 0; qd < 4; ++qd) {
+          unsigned pcs[2][2];
+          for (int e = 0; e < 2; ++e) {
+            const float w = F16_SW * (sc * M[(lane & 31) * ld + col0 + kfeat(8 * st + 2 * qd + e, lane >> 5)]);
+            const _Float16 w1 = (_Float16)w;
+            pcs[e][0] = f16_bits((float)w1);
+            pcs[e][1] = f16_bits(w - (float)w1);
+          }
+          for (int pc = 0; pc < 2; ++pc)
+            dst[(((size_t)pc * 2 + st) * 64 + lane) * 4 + qd] = pcs[0][pc] | (pcs[1][pc] << 16);
+        }
+  };
   auto pack_vec = [&](float* dst, const float* v, int stride, float sc) {
     for (int hh = 0; hh < 2; ++hh)
       for (int r = 0; r < 16; ++r) dst[hh * 16 + r] = sc * v[kfeat(r, hh) * stride];
@@ -526,6 +600,14 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
     pack_mat16(m16 + M_WN1A * MAT_W, n0w, 2 * H, 0, kS);
     pack_mat16(m16 + M_WN1B * MAT_W, n0w, 2 * H, H, 1.0f);
     pack_mat16(m16 + M_WN2 * MAT_W, n2w, H, 0, kSi);
+    unsigned* m16h = h_mats16h + (size_t)l * M_COUNT * MAT_WH;
+    pack_mat16h(m16h + M_WA * MAT_WH, e0w, 2 * H + 2, 0, kS);
+    pack_mat16h(m16h + M_WB * MAT_WH, e0w, 2 * H + 2, H, kS);
+    pack_mat16h(m16h + M_W2 * MAT_WH, e2w, H, 0, 1.0f);
+    pack_mat16h(m16h + M_WC1 * MAT_WH, c0w, H, 0, 1.0f);
+    pack_mat16h(m16h + M_WN1A * MAT_WH, n0w, 2 * H, 0, kS);
+    pack_mat16h(m16h + M_WN1B * MAT_WH, n0w, 2 * H, H, 1.0f);
+    pack_mat16h(m16h + M_WN2 * MAT_WH, n2w, H, 0, kSi);
     pack_mat(mats + M_WA * MAT_F, e0w, 2 * H + 2, 0, kS);
     pack_mat(mats + M_WB * MAT_F, e0w, 2 * H + 2, H, kS);
     pack_mat(mats + M_W2 * MAT_F, e2w, H, 0, 1.0f);
@@ -563,13 +645,28 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
     pack_vec(vecs + V_WRF * EH, e0w + 2 * H, 2 * H + 2, 1.0f);
     pack_vec(vecs + V_WEF * EH, e0w + 2 * H + 1, 2 * H + 2, 1.0f);
     vecs[V_COUNT * EH] = ab ? ab[0] : 0.f;
+    {  // PREC 2 copy: biases that initialise an f16-path accumulator (W2, Wc1, Wn2) x F16_SX F16_SW, vectors that
+       // consume F16_SX-scaled SiLU outputs (attention gate, coordinate head) / F16_SX
+      float* vh = h_vecs_h + VEC_EMB_F + (size_t)l * VEC_LAYER_F;
+      memcpy(vh, vecs, sizeof(float) * VEC_LAYER_F);
+      const float up = F16_SX * F16_SW, dn = 1.0f / F16_SX;
+      for (int o = 0; o < H; ++o) {
+        vh[V_B2 * EH + o] *= up; vh[V_BC1 * EH + o] *= up; vh[V_BN2 * EH + o] *= up;
+        vh[V_WATT * EH + o] *= dn; vh[V_WC2 * EH + o] *= dn;
+      }
+    }
   }
+  memcpy(h_vecs_h, h_vecs, sizeof(float) * VEC_EMB_F);
   pita_egnn* net = new pita_egnn();
   net->cfg = *cfg;
   net->shape = shape;
   hipError_t e1 = hipMalloc(&net->d_mats, n_mats * sizeof(float));
   hipError_t e2 = hipMalloc(&net->d_vecs, n_vecs * sizeof(float));
   hipError_t e0 = hipMalloc(&net->d_mats16, n_mats16 * sizeof(unsigned));
+  if (e0 == hipSuccess) e0 = hipMalloc(&net->d_mats16h, n_mats16h * sizeof(unsigned));
+  if (e0 == hipSuccess) e0 = hipMalloc(&net->d_vecs_h, n_vecs * sizeof(float));
+  if (e0 == hipSuccess) e0 = hipMemcpy(net->d_mats16h, h_mats16h, n_mats16h * sizeof(unsigned), hipMemcpyHostToDevice);
+  if (e0 == hipSuccess) e0 = hipMemcpy(net->d_vecs_h, h_vecs_h, n_vecs * sizeof(float), hipMemcpyHostToDevice);
   if (e1 == hipSuccess && e2 == hipSuccess && e0 == hipSuccess) {
     e1 = hipMemcpy(net->d_mats, h_mats, n_mats * sizeof(float), hipMemcpyHostToDevice);
     e2 = hipMemcpy(net->d_vecs, h_vecs, n_vecs * sizeof(float), hipMemcpyHostToDevice);
@@ -579,10 +676,14 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
   delete[] h_mats;
   delete[] h_vecs;
   delete[] h_mats16;
+  delete[] h_mats16h;
+  delete[] h_vecs_h;
   if (e1 != hipSuccess || e2 != hipSuccess) {
     (void)hipFree(net->d_mats);
     (void)hipFree(net->d_vecs);
     (void)hipFree(net->d_mats16);
+    (void)hipFree(net->d_mats16h);
+    (void)hipFree(net->d_vecs_h);
     delete net;
     return fail(PITA_EHIP, "pita_egnn_create: device upload failed: %s",
                 hipGetErrorString(e1 != hipSuccess ? e1 : e2));
@@ -594,7 +695,7 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
   // opt in to the LDS the kernel needs (static limit is 64 KiB)
   size_t lds = shape->lds_bytes(L);
   hipError_t e3 = hipSuccess;
-  for (int a = 0; a < 2 && e3 == hipSuccess; ++a)
+  for (int a = 0; a < 3 && e3 == hipSuccess; ++a)
     for (int b = 0; b < 2 && e3 == hipSuccess; ++b)
       e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(shape->kernel[a][b]),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -611,16 +712,21 @@ extern "C" int pita_egnn_destroy(pita_egnn_t* net) {
   (void)hipFree(net->d_mats);
   (void)hipFree(net->d_vecs);
   (void)hipFree(net->d_mats16);
+  (void)hipFree(net->d_mats16h);
+  (void)hipFree(net->d_vecs_h);
   (void)hipFree(net->d_ws);
+  (void)hipFree(net->d_bk);
   delete net;
   return PITA_OK;
 }
 
 static int egnn_launch(pita_egnn_t* net, EgnnParams& p, void* stream) {
   const EgnnShape* s = static_cast<const EgnnShape*>(net->shape);
+  const int prec = net->cfg.precision;
   p.mats = net->d_mats;
   p.mats16 = net->d_mats16;
-  p.vecs = net->d_vecs;
+  p.mats16h = net->d_mats16h;
+  p.vecs = prec == 2 ? net->d_vecs_h : net->d_vecs;
   p.n_layers = net->cfg.n_layers;
   p.in_nf = net->cfg.in_node_nf;
   p.attention = net->cfg.attention;
@@ -638,16 +744,39 @@ static int egnn_launch(pita_egnn_t* net, EgnnParams& p, void* stream) {
   // forward modes: one group per wave (plain grid); sampler mode: persistent grid-stride
   unsigned grid = (unsigned)(want < cap ? want : cap);
   if (p.mode != 3) grid = (unsigned)want;
-  const int prec = net->cfg.precision == 1 ? 1 : 0;
-  hipLaunchKernelGGL(s->kernel[prec][p.mode == 3 ? 1 : 0], dim3(grid), dim3(s->waves * 64), lds, (hipStream_t)stream, p);
+  const int smp = p.mode == 3 ? 1 : 0;
+  if (prec == 2 && smp) {  // keep the walkers: the repair launch restarts the affected groups from them
+    const size_t need = sizeof(float) * (size_t)p.B * s->n * s->dim + sizeof(int) * (size_t)p.B * s->n;
+    if (need > net->bk_bytes) {
+      PITA_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));  // an earlier launch may still use the old buffer
+      (void)hipFree(net->d_bk);
+      net->d_bk = nullptr;
+      net->bk_bytes = 0;
+      PITA_HIP_CHECK(hipMalloc(&net->d_bk, need));
+      net->bk_bytes = need;
+    }
+    float* xb = static_cast<float*>(net->d_bk);
+    PITA_HIP_CHECK(hipMemcpyAsync(xb, p.x, sizeof(float) * (size_t)p.B * s->n * s->dim, hipMemcpyDeviceToDevice,
+                                  (hipStream_t)stream));
+    p.x_backup = xb;
+    p.bad_from = reinterpret_cast<int*>(xb + (size_t)p.B * s->n * s->dim);
+  }
+  hipLaunchKernelGGL(s->kernel[prec][smp], dim3(grid), dim3(s->waves * 64), lds, (hipStream_t)stream, p);
   PITA_LAUNCH_CHECK();
+  if (prec == 2) {
+    p.repair = 1;
+    p.vecs = net->d_vecs;  // the PREC 1 kernel takes the unscaled vectors
+    hipLaunchKernelGGL(s->kernel[1][smp], dim3(grid), dim3(s->waves * 64), lds, (hipStream_t)stream, p);
+    PITA_LAUNCH_CHECK();
+  }
   return PITA_OK;
 }
 
 // MFMA wave-instructions the fused sampler executes per walker-step, counted on the kernel's own loop structure (same
 // walker quota / grouping arithmetic as the launch above): per live column tile and layer one partner-table GEMM, one
 // own-term GEMM, (N-1) edges x (one f32 k-step + two dense layers) and -- except in the last layer -- three node-model
-// GEMMs.  A dense 32x32 layer is 16 f32 MFMAs (precision 0) or 12 bf16 MFMAs (precision 1).
+// GEMMs.  A dense 32x32 layer is 16 f32 MFMAs (precision 0), 12 bf16 MFMAs (precision 1) or -- the per-edge layers and
+// Wn2 in precision 2 -- 6 f16 MFMAs.
 extern "C" int pita_egnn_sampler_work(const pita_egnn_t* net, int64_t B, double* mfma16_per_walker_step,
                                       double* mfma32_per_walker_step) {
   PITA_REQUIRE(net && B > 0 && mfma16_per_walker_step && mfma32_per_walker_step, "pita_egnn_sampler_work: bad argument");
@@ -668,13 +797,14 @@ extern "C" int pita_egnn_sampler_work(const pita_egnn_t* net, int64_t B, double*
       tiles += (double)((nw * N + 31) / 32);
     }
   }
-  const double dense = tiles * (L * (2.0 + 2.0 * (N - 1)) + (L - 1) * 3.0);  // dense 32x32 layers per step
-  const double kstep = tiles * L * (N - 1);                                  // f32 (radial, edge_attr) k-steps
+  const double node_dense = tiles * (L * 2.0 + (L - 1) * 2.0);                // Wb, Wa per layer; Wn1a, Wn1b
+  const double edge_dense = tiles * (L * 2.0 * (N - 1) + (L - 1) * 1.0);      // W2, Wc1 per edge; Wn2
+  const double kstep = tiles * L * (N - 1);                                   // f32 (radial, edge_attr) k-steps
   if (net->cfg.precision == 0) {
     *mfma16_per_walker_step = 0.0;
-    *mfma32_per_walker_step = (16.0 * dense + kstep) / (double)B;
+    *mfma32_per_walker_step = (16.0 * (node_dense + edge_dense) + kstep) / (double)B;
   } else {
-    *mfma16_per_walker_step = 12.0 * dense / (double)B;
+    *mfma16_per_walker_step = (12.0 * node_dense + (net->cfg.precision == 2 ? 6.0 : 12.0) * edge_dense) / (double)B;
     *mfma32_per_walker_step = kstep / (double)B;
   }
   return PITA_OK;

@@ -7,12 +7,16 @@ the reference's weights and its ``state_dict`` / Lightning checkpoints load unch
 of EGNN.forward (:172-194) and E_GCL (:197-356) lives in pita_amd/csrc/egnn_kernel.hip.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
 import torch.nn as nn
 
 from . import _lib
+
+
+DEFAULT_PRECISION = "bf16x3"  # dense-layer arithmetic of the HIP EGNN when the caller does not choose (see EGNN_dynamics)
 
 
 class _GCLParams(nn.Module):
@@ -57,7 +61,7 @@ class EGNN(nn.Module):
 class EGNN_dynamics(nn.Module):
     def __init__(self, n_particles, n_dimension, hidden_nf=64, act_fn=torch.nn.SiLU(), n_layers=4, recurrent=True,
                  attention=False, condition_time=True, tanh=False, agg="sum", energy=False, add_virtual=False,
-                 condition_temperature=False, feature_layout="pita", precision="bf16x3"):
+                 condition_temperature=False, feature_layout="pita", precision=None):
         super().__init__()
         if energy or add_virtual or not condition_time:
             raise NotImplementedError("HIP EGNN_dynamics implements energy=False, add_virtual=False, condition_time=True")
@@ -68,9 +72,11 @@ class EGNN_dynamics(nn.Module):
         self.condition_time, self.condition_temperature = condition_time, condition_temperature
         # "pita" keeps the reference's t/beta interleave quirk (:68-78); "correct" gives (t, beta) per node
         self.feature_layout = {"pita": 0, "correct": 1}[feature_layout]
-        # dense-layer arithmetic, both fp32-accurate: "f32" = f32 MFMA (bit-exact fmaf chains), "bf16x3" = bf16
-        # matrix pipe with an exact three-way operand split (see csrc/egnn_kernel.hip)
-        self.precision = {"f32": 0, "bf16x3": 1}[precision]
+        # dense-layer arithmetic, all fp32-accurate: "f32" = f32 MFMA (bit-exact fmaf chains), "bf16x3" = bf16 matrix
+        # pipe with an exact three-way operand split, "f16x2" = f16 matrix pipe with a two-way round-to-nearest split
+        # and power-of-two operand scaling (|activations| < 4094; see csrc/egnn_common.h)
+        precision = precision or os.environ.get("PITA_EGNN_PRECISION", DEFAULT_PRECISION)
+        self.precision = {"f32": 0, "bf16x3": 1, "f16x2": 2}[precision]
         self.counter = 0
         self._handle = None
         self._handle_key = None

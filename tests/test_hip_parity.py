@@ -109,12 +109,12 @@ def make_net(pa, n, d, weights, temp=True, **kw):
     return net
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2"])
 @pytest.mark.parametrize("name", ["lj13", "dw4", "lj55"])
 @pytest.mark.parametrize("tag,wfile", [("init", "egnn_weights_seed12345.npz"), ("trained", "egnn_weights_trainedlike.npz")])
 def test_egnn_golden(pa, golden, name, tag, wfile, precision):
-    """Both dense-layer arithmetic modes (f32 MFMA; bf16 matrix pipe with exact 3-way split) must be
-    fp32-accurate: within 4x the reference's own fp32-vs-fp64 error."""
+    """All dense-layer arithmetic modes (f32 MFMA; bf16 matrix pipe with exact 3-way split; f16 matrix pipe with 2-way
+    round-to-nearest split) must be fp32-accurate: within 4x the reference's own fp32-vs-fp64 error."""
     g = golden(f"egnn_{name}_fwd.npz")
     w = golden(wfile)
     n, d = int(g["n"]), int(g["d"])
@@ -138,6 +138,47 @@ def test_egnn_golden(pa, golden, name, tag, wfile, precision):
         m = g["h"] == hv
         tol = 1e-4 if hv > 0.05 else 5e-3  # (D - x)/h amplifies fp32 rounding by 1/h
         assert rel(sc[m], g[f"score_{tag}"][m]) < tol, hv
+
+
+def test_f16x2_out_of_range_walkers_are_recomputed_on_the_bf16_path(pa, golden):
+    """precision="f16x2" has a range limit (SiLU outputs beyond 65504 overflow f16).  The launch wrapper follows the f16
+    kernel with a repair launch of the bf16x3 kernel that recomputes exactly the walker groups whose results are
+    non-finite: far-out walkers (where the reference's fp32 arithmetic is still finite) must come out equal to the
+    bf16x3 result, ordinary walkers must keep their f16x2 result, and the per-step moments must count every walker once."""
+    w = golden("egnn_weights_trainedlike.npz")
+    nf, nb = make_net(pa, 13, 3, w, precision="f16x2"), make_net(pa, 13, 3, w, precision="bf16x3")
+    gen = torch.Generator().manual_seed(77)
+    B = 70  # ten 7-walker groups: 0-4 ordinary, 5-9 far out (pair distances ~1e3: edge pre-activations ~1e5)
+    x = torch.randn(B, 39, generator=gen)
+    x[35:] *= 1000.0
+    x = O.remove_mean(x, 13, 3).cuda()
+    t, b = torch.full((B,), -0.3).cuda(), torch.full((B,), 1.0).cuda()
+    Ff, Fb = nf(t, x, b), nb(t, x, b)
+    assert torch.isfinite(Ff).all() and torch.isfinite(Fb).all()
+    assert torch.equal(Ff[35:], Fb[35:])                      # recomputed by the bf16x3 kernel
+    assert not torch.equal(Ff[:35], Fb[:35]) and rel(Ff[:35], Fb[:35]) < 1e-6   # untouched f16x2 results
+    ref = O.egnn_forward({k: T(v) for k, v in w.items()}, t.cpu().double(), x.cpu().double(), b.cpu().double(), 13, 3)
+    assert rel(Ff, ref) < 2e-5
+    # fused sampler, with the per-step moments the integrator asks for
+    sched = pa.ElucidatingNoiseSchedule(sigma_min=0.05, sigma_max=80.0, rho=7)
+    gam = pa.ConstantAnnealingFactorSchedule(4 / 3)
+    N = 5
+    tab = pa.sde_integration.build_step_table(sched, gam, torch.linspace(0.2, 0.0, N + 1)[:-1], 0.2 / N, 1.0, 1.0).cuda()
+    sf, sb = (torch.zeros(N, 4, dtype=torch.float64, device="cuda") for _ in range(2))
+    df, db = torch.empty_like(x), torch.empty_like(x)
+    xf = nf.sampler_run(x.clone(), tab, N, seed=3, stats_out=sf, drift_out=df)
+    xb = nb.sampler_run(x.clone(), tab, N, seed=3, stats_out=sb, drift_out=db)
+    assert torch.isfinite(xf).all()
+    assert torch.equal(xf[35:], xb[35:]) and torch.equal(df[35:], db[35:])
+    assert not torch.equal(xf[:35], xb[:35]) and rel(xf[:35], xb[:35]) < 1e-5
+    sfh, sbh = sf.cpu().numpy(), sb.cpu().numpy()   # every walker counted exactly once
+    np.testing.assert_allclose(sfh[:, [1, 3]], sbh[:, [1, 3]], rtol=1e-6)
+    # plain sums of mean-free drifts cancel to ~0: compare on the scale of the summands (fp32 lane partials, B*39 terms)
+    scale = np.sqrt(sbh[:, [1, 3]] * B * 39)
+    assert (np.abs(sfh[:, [0, 2]] - sbh[:, [0, 2]]) < 1e-6 * scale).all()
+    # the same ordinary walkers alone: their result does not depend on who else is in the batch
+    xa = nf.sampler_run(x[:35].clone(), tab, N, seed=3)
+    assert torch.equal(xa, xf[:35])
 
 
 def test_egnn_notemp_and_layouts(pa, golden):
