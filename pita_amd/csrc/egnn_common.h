@@ -134,9 +134,7 @@ struct WFrag<1> {
   }
 };
 
-// PREC 2: the f16 matrix pipe with a TWO-piece round-to-nearest split for the PER-EDGE dense layers (W2, Wc1) and
-//   the node output layer Wn2, whose inputs are SiLU outputs; the per-node layers that read the node features or the
-//   message aggregate (Wa, Wb, Wn1a, Wn1b: unbounded sums) stay on the PREC 1 path.
+// PREC 2: the f16 matrix pipe with a TWO-piece round-to-nearest split.
 //   x1 = f16(x), x2 = f16(x - x1) (the remainder is exact in fp32), so |x - x1 - x2| <= 2^-24 |x|: the size of one
 //   fp32 rounding.  Weights are split the same way on the host; the three products W2X1, W1X2, W1X1 (each exact in the
 //   fp32 accumulator) leave out W2X2 <= 2^-24 |w||x|.  Half the MFMAs of PREC 1, and 4 VALU instructions per operand
@@ -148,6 +146,7 @@ struct WFrag<1> {
 //   that the conversion gives inf, the products NaN, and the launch wrapper recomputes the affected walkers on the
 //   PREC 1 path (egnn_kernel.hip: repair launch), so the limit costs time, never correctness.
 constexpr float F16_SX = 1.0f, F16_SW = 16.0f;
+constexpr bool F16_NODE_LAYERS = true;  // false: Wa, Wb, Wn1a, Wn1b (inputs: node features, message aggregate) stay on PREC 1
 constexpr float F16_UNSCALE = 1.0f / (F16_SX * F16_SW);
 constexpr int MAT_WH = 1024;  // 32-bit words per f16-split packed matrix: [piece 2][kstep 2][lane 64][4]
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

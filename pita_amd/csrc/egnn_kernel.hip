@@ -73,7 +73,7 @@ struct EgnnCfg {
   static constexpr int NCOLP = NT * 32;
   static constexpr int PB_F = NCOLP * PBS;
   static constexpr int POS_F = NCOLP * DIM;
-  static constexpr int WAVE_F = PB_F + 3 * POS_F;  // partner table, pos[2], pos0
+  static constexpr int WAVE_F = PB_F + 4 * POS_F;  // partner table, pos[2], pos0, walkers (x of the current step)
   static __host__ __device__ constexpr int vec_f(int L) { return ((VEC_EMB_F + L * VEC_LAYER_F) + 3) & ~3; }
   static __host__ __device__ constexpr size_t lds_bytes(int L) {
     return sizeof(float) * (size_t)(vec_f(L) + WAVES * WAVE_F);
@@ -82,8 +82,8 @@ struct EgnnCfg {
 
 // SAMPLER = true: mode 3 only (per-step scalars are wave-uniform -> SGPRs); false: modes 0-2 (per-walker t / h / beta).
 // Separate instantiations keep the fused sampler's register budget free of the forward modes' per-column scalars.
-template <int N, int DIM, int G, int WAVES, int PREC, bool SAMPLER>
-__global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
+template <int N, int DIM, int G, int WAVES, int PREC, bool SAMPLER, int OCC = 2>
+__global__ void __launch_bounds__(WAVES * 64, OCC) egnn_kernel(EgnnParams p) {
   const int mode = SAMPLER ? 3 : p.mode;
   using C = EgnnCfg<N, DIM, G, WAVES>;
   constexpr int NT = C::NT;
@@ -102,6 +102,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
   float* posbuf0 = PB + C::PB_F;
   float* posbuf1 = posbuf0 + C::POS_F;
   float* pos0 = posbuf1 + C::POS_F;
+  float* xbuf = pos0 + C::POS_F;  // the walkers' unscaled coordinates: parked in LDS across the layers, not in registers
   const float* vemb = lds;
 
   // Work split: every wave gets the same contiguous quota of walkers (65 536 walkers on 2 048 resident waves =
@@ -119,7 +120,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
     int col[NT], nodei[NT];
     bool valid[NT];
     long long wid[NT];
-    float xcur[NT][DIM];
+    float xcur[NT][DIM];  // transient: the walkers as loaded; they live in xbuf (LDS) from here on
 #pragma unroll
     for (int T = 0; T < NT; ++T) {
       col[T] = T * 32 + cl;
@@ -135,16 +136,35 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
     int bad_from[NT];  // per (walker, particle): first step whose moments are still owed (see EgnnParams::repair)
 #pragma unroll
     for (int T = 0; T < NT; ++T) bad_from[T] = 0x7fffffff;
+    bool mine[NT];  // this column's walker takes the results of this launch (repair launch: only the non-finite ones)
+#pragma unroll
+    for (int T = 0; T < NT; ++T) mine[T] = valid[T];
     if (PREC != 2 && p.repair) {
       bool bad = false;
+      float* flag = PB;  // per-column flag table (the partner table is not live yet)
 #pragma unroll
-      for (int T = 0; T < NT; ++T)
+      for (int T = 0; T < NT; ++T) {
+        bool b = false;
 #pragma unroll
         for (int k = 0; k < DIM; ++k) {
           const float v = (mode == 3) ? xcur[T][k] : (valid[T] ? p.out[(walker0 * N + col[T]) * DIM + k] : 0.0f);
-          bad = bad || !__builtin_isfinite(v);
+          b = b || !__builtin_isfinite(v);
         }
+        if (hh == 0) flag[col[T]] = b ? 1.0f : 0.0f;
+        bad = bad || b;
+      }
       if (!__any(bad)) continue;  // wave-uniform: this group's f16 result stands
+      // walker granularity: the group is recomputed, but only walkers with a non-finite particle are overwritten, so
+      // a walker's result never depends on its neighbours in the batch
+      wave_lds_fence();
+#pragma unroll
+      for (int T = 0; T < NT; ++T) {
+        const int cb = (col[T] < ncol) ? col[T] - nodei[T] : 0;
+        float any = 0.f;
+        for (int q = 0; q < N; ++q) any += flag[cb + q];
+        mine[T] = valid[T] && any != 0.f;
+      }
+      wave_lds_fence();
       if (mode == 3) {
 #pragma unroll
         for (int T = 0; T < NT; ++T) {
@@ -156,20 +176,34 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
       }
     }
 
+#pragma unroll
+    for (int T = 0; T < NT; ++T)
+#pragma unroll
+      for (int k = 0; k < DIM; ++k)
+        if (hh == 0) xbuf[col[T] * DIM + k] = xcur[T][k];
+    wave_lds_fence();
+
     const int nsteps = (mode == 3) ? p.n_steps : 1;
     for (int step = 0; step < nsteps; ++step) {
       // ---- per-column scalars of this evaluation
       float c_s[NT], c_in[NT], c_out[NT], tfeat[NT], hval[NT], bfeat[NT];
       float g2 = 0.f, gamma = 0.f, dt = 0.f, noise_scale = 0.f, sqrt_dt = 0.f;
       if (mode == 3) {
+        // wave-uniform per-step scalars: through v_readfirstlane into SGPRs (a plain load of the table would occupy a
+        // dozen VGPRs per lane for the whole step: the pointer is not known to be read-only, so no scalar load)
         const float* st = p.step_tab + (size_t)step * PITA_STEP_STRIDE;
+        auto uni = [&](int i) {
+          return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, st[i])));
+        };
+        const float u_cs = uni(PITA_ST_CS), u_cin = uni(PITA_ST_CIN), u_cout = uni(PITA_ST_COUT),
+                    u_cn = uni(PITA_ST_CNOISE), u_h = uni(PITA_ST_H), u_b = uni(PITA_ST_BETA);
 #pragma unroll
         for (int T = 0; T < NT; ++T) {
-          c_s[T] = st[PITA_ST_CS]; c_in[T] = st[PITA_ST_CIN]; c_out[T] = st[PITA_ST_COUT];
-          tfeat[T] = st[PITA_ST_CNOISE]; hval[T] = st[PITA_ST_H]; bfeat[T] = st[PITA_ST_BETA];
+          c_s[T] = u_cs; c_in[T] = u_cin; c_out[T] = u_cout;
+          tfeat[T] = u_cn; hval[T] = u_h; bfeat[T] = u_b;
         }
-        g2 = st[PITA_ST_G2]; gamma = st[PITA_ST_GAMMA]; dt = st[PITA_ST_DT];
-        noise_scale = st[PITA_ST_NOISE_SCALE]; sqrt_dt = st[PITA_ST_SQRT_DT];
+        g2 = uni(PITA_ST_G2); gamma = uni(PITA_ST_GAMMA); dt = uni(PITA_ST_DT);
+        noise_scale = uni(PITA_ST_NOISE_SCALE); sqrt_dt = uni(PITA_ST_SQRT_DT);
       } else {
 #pragma unroll
         for (int T = 0; T < NT; ++T) {
@@ -188,17 +222,17 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
       }
 
       // ---- scaled input coordinates -> registers + LDS (pos0 = input geometry, frozen edge_attr)
-      float posi[NT][DIM], p0i[NT][DIM];
+      // (positions live in the LDS tables pos0 / poscur between uses: each tile reloads its own column)
       f32x16 hfeat[NT];
 #pragma unroll
       for (int T = 0; T < NT; ++T) {
 #pragma unroll
         for (int k = 0; k < DIM; ++k) {
-          posi[T][k] = (mode == 0) ? xcur[T][k] : c_in[T] * xcur[T][k];
-          p0i[T][k] = posi[T][k];
+          const float xc = xbuf[col[T] * DIM + k];
+          const float ps = (mode == 0) ? xc : c_in[T] * xc;
           if (hh == 0) {
-            pos0[col[T] * DIM + k] = posi[T][k];
-            posbuf0[col[T] * DIM + k] = posi[T][k];
+            pos0[col[T] * DIM + k] = ps;
+            posbuf0[col[T] * DIM + k] = ps;
           }
         }
         // initial node features (egnn_temp_conditioned.py:63-78) and embedding (:179)
@@ -223,7 +257,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
         const float* mats = p.mats + (size_t)l * M_COUNT * MAT_F;
         const unsigned* mats16 = p.mats16 + (size_t)l * M_COUNT * MAT_W;    // bf16 three-piece fragments
         const unsigned* mats16h = p.mats16h + (size_t)l * M_COUNT * MAT_WH;  // f16 two-piece fragments (PREC 2)
-        constexpr int NPREC = PREC == 2 ? 1 : PREC;                          // arithmetic of the per-node layers
+        constexpr int NPREC = (PREC == 2 && !F16_NODE_LAYERS) ? 1 : PREC;    // arithmetic of the per-node layers
+        constexpr bool NODE16 = (PREC == 2 && F16_NODE_LAYERS);
+        const unsigned* matsn = NODE16 ? mats16h : mats16;
         const float* vl = lds + VEC_EMB_F + l * VEC_LAYER_F + hh * 16;
         const bool last = (l == L - 1);
         // the last layer's aggregate is dead: a multiplier instead of 16 selects (and it undoes the PREC 2 scale)
@@ -233,12 +269,13 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
         // ---- partner table PB[col] = Wb h_col
         {
           WFrag<NPREC> wb;
-          wb.load(mats, mats16, M_WB, lane);
+          wb.load(mats, matsn, M_WB, lane);
 #pragma unroll
           for (int T = 0; T < NT; ++T) {
             if (T >= ntile) continue;
             f32x16 z = {0};
             f32x16 pb = wb.mul(hfeat[T], z);
+            if (NODE16) pb *= F16_UNSCALE;
             f32x4* dst = reinterpret_cast<f32x4*>(PB + col[T] * PBS + hh * 16);
             dst[0] = f32x4{pb[0], pb[1], pb[2], pb[3]};
             dst[1] = f32x4{pb[4], pb[5], pb[6], pb[7]};
@@ -262,13 +299,18 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
           f32x16 Ai;
           {
             WFrag<NPREC> wa;
-            wa.load(mats, mats16, M_WA, lane);
+            wa.load(mats, matsn, M_WA, lane);
             Ai = wa.mul(hfeat[T], lds_vec16(vl + V_B1 * EH));
+            if (NODE16) Ai *= F16_UNSCALE;
           }
           f32x16 agg = {0};
-          float xacc[DIM];
+          float xacc[DIM], pown[DIM], p0own[DIM];
 #pragma unroll
-          for (int k = 0; k < DIM; ++k) xacc[k] = 0.f;
+          for (int k = 0; k < DIM; ++k) {
+            xacc[k] = 0.f;
+            pown[k] = poscur[col[T] * DIM + k];
+            p0own[k] = pos0[col[T] * DIM + k];
+          }
           const int cbase = col[T] - nodei[T];
 
           for (int dd = 1; dd < N; ++dd) {
@@ -280,9 +322,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
             float df[DIM], radial = 0.f, ea = 0.f;
 #pragma unroll
             for (int k = 0; k < DIM; ++k) {
-              df[k] = posi[T][k] - poscur[cj * DIM + k];
+              df[k] = pown[k] - poscur[cj * DIM + k];
               radial = fmaf(df[k], df[k], radial);
-              const float e0 = p0i[T][k] - pos0[cj * DIM + k];
+              const float e0 = p0own[k] - pos0[cj * DIM + k];
               ea = fmaf(e0, e0, ea);
             }
             // edge MLP layer 1 (:232-237,:270-271): Wa h_i + Wb h_j + b1, then one k-step [w_r|w_e]·[radial;ea]
@@ -311,16 +353,15 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
           // coordinate update (:306,:318): other tiles still read the old coordinates
 #pragma unroll
           for (int k = 0; k < DIM; ++k) {
-            posi[T][k] += xacc[k];
-            if (hh == 0) posnext[col[T] * DIM + k] = posi[T][k];
+            if (hh == 0) posnext[col[T] * DIM + k] = pown[k] + xacc[k];
           }
           if (!last) {  // node model (:239-243,:284-291), recurrent
             WFrag<NPREC> wn;
-            wn.load(mats, mats16, M_WN1A, lane);
+            wn.load(mats, matsn, M_WN1A, lane);
             f32x16 n1 = wn.mul(hfeat[T], lds_vec16(vl + V_BN1 * EH));
-            wn.load(mats, mats16, M_WN1B, lane);
+            wn.load(mats, matsn, M_WN1B, lane);
             n1 = wn.mul(agg, n1);
-            if (PREC == 2) silu16_out(n1); else silu16(n1);
+            if (NODE16) silu16_acc(n1); else if (PREC == 2) silu16_out(n1); else silu16(n1);
             WFrag<PREC> wo;
             wo.load(mats, PREC == 2 ? mats16h : mats16, M_WN2, lane);
             f32x16 o = wo.mul(n1, lds_vec16(vl + V_BN2 * EH));
@@ -339,7 +380,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
       for (int T = 0; T < NT; ++T)
 #pragma unroll
         for (int k = 0; k < DIM; ++k) {
-          F[T][k] = posi[T][k] - p0i[T][k];
+          F[T][k] = poscur[col[T] * DIM + k] - pos0[col[T] * DIM + k];
           if (hh == 0) scr[col[T] * DIM + k] = F[T][k];
         }
       wave_lds_fence();
@@ -362,10 +403,11 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
           for (int k = 0; k < DIM; ++k) {
             float o = F[T][k];
             if (mode >= 1) {
-              o = c_s[T] * xcur[T][k] + c_out[T] * F[T][k];           // denoiser (score_net.py:31-33)
-              if (mode == 2) o = (o - xcur[T][k]) / hval[T];        // score (:19)
+              const float xc = xbuf[col[T] * DIM + k];
+              o = c_s[T] * xc + c_out[T] * F[T][k];           // denoiser (score_net.py:31-33)
+              if (mode == 2) o = (o - xc) / hval[T];        // score (:19)
             }
-            if (valid[T] && hh == 0) p.out[(walker0 * N + col[T]) * DIM + k] = o;
+            if (mine[T] && hh == 0) p.out[(walker0 * N + col[T]) * DIM + k] = o;
           }
       } else {
         // ---- reverse-SDE Euler-Maruyama update (sdes.py:119-122,250; sde_integration.py:347-348)
@@ -383,10 +425,11 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
           }
 #pragma unroll
           for (int k = 0; k < DIM; ++k) {
-            const float Dth = c_s[T] * xcur[T][k] + c_out[T] * F[T][k];
-            const float sc = (Dth - xcur[T][k]) / hval[T];
+            const float xc = xbuf[col[T] * DIM + k];
+            const float Dth = c_s[T] * xc + c_out[T] * F[T][k];
+            const float sc = (Dth - xc) / hval[T];
             const float drift = gamma * (sc * g2);
-            if (p.drift_out && step == nsteps - 1 && valid[T] && hh == 0)
+            if (p.drift_out && step == nsteps - 1 && mine[T] && hh == 0)
               p.drift_out[(walker0 * N + col[T]) * DIM + k] = drift;
             const float dif = noise_scale * xi[k];  // sdes.py:250
             if (p.stats_out && valid[T] && hh == 0) {
@@ -402,7 +445,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
                 st_n += dif; st_n2 = fmaf(dif, dif, st_n2);
               }
             }
-            xn[T][k] = xcur[T][k] + (drift * dt + (dif * sqrt_dt));
+            xn[T][k] = xc + (drift * dt + (dif * sqrt_dt));
             if (hh == 0) scr[col[T] * DIM + k] = xn[T][k];
           }
         }
@@ -431,7 +474,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
 #pragma unroll
         for (int T = 0; T < NT; ++T)
 #pragma unroll
-          for (int k = 0; k < DIM; ++k) xcur[T][k] = xn[T][k];
+          for (int k = 0; k < DIM; ++k)
+            if (hh == 0) xbuf[col[T] * DIM + k] = xn[T][k];
+        wave_lds_fence();
       }
     }  // steps
 
@@ -440,7 +485,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
       for (int T = 0; T < NT; ++T) {
 #pragma unroll
         for (int k = 0; k < DIM; ++k)
-          if (valid[T] && hh == 0) p.x[(walker0 * N + col[T]) * DIM + k] = xcur[T][k];
+          if (mine[T] && hh == 0) p.x[(walker0 * N + col[T]) * DIM + k] = xbuf[col[T] * DIM + k];
         if (PREC == 2 && p.stats_out && p.bad_from && valid[T] && hh == 0) p.bad_from[walker0 * N + col[T]] = bad_from[T];
       }
     }
@@ -451,7 +496,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) egnn_kernel(EgnnParams p) {
 // ------------------------------------------------------------------------------------ host side
 
 struct EgnnShape {
-  int n, dim, G, waves;
+  int n, dim, G, waves, occ;  // occ: resident workgroups per CU the kernels were compiled for
   void (*kernel[3][2])(EgnnParams);  // [PREC][SAMPLER]
   size_t (*lds_bytes)(int);
 };
@@ -459,18 +504,19 @@ struct EgnnShape {
 template <int N, int DIM, int G, int WAVES>
 static size_t lds_bytes_of(int L) { return EgnnCfg<N, DIM, G, WAVES>::lds_bytes(L); }
 
-#define PITA_EGNN_SHAPE(N, DIM, G, WAVES) \
-  EgnnShape { N, DIM, G, WAVES, {{egnn_kernel<N, DIM, G, WAVES, 0, false>, egnn_kernel<N, DIM, G, WAVES, 0, true>}, \
-                                 {egnn_kernel<N, DIM, G, WAVES, 1, false>, egnn_kernel<N, DIM, G, WAVES, 1, true>}, \
-                                 {egnn_kernel<N, DIM, G, WAVES, 2, false>, egnn_kernel<N, DIM, G, WAVES, 2, true>}}, \
+#define PITA_EGNN_SHAPE(N, DIM, G, WAVES, OCC) \
+  EgnnShape { N, DIM, G, WAVES, OCC, \
+              {{egnn_kernel<N, DIM, G, WAVES, 0, false, OCC>, egnn_kernel<N, DIM, G, WAVES, 0, true, OCC>}, \
+               {egnn_kernel<N, DIM, G, WAVES, 1, false, OCC>, egnn_kernel<N, DIM, G, WAVES, 1, true, OCC>}, \
+               {egnn_kernel<N, DIM, G, WAVES, 2, false, OCC>, egnn_kernel<N, DIM, G, WAVES, 2, true, OCC>}}, \
               lds_bytes_of<N, DIM, G, WAVES> }
 
 // Instantiated (n_particles, n_dim) shapes: DW4, LJ13, alanine dipeptide (22 atoms), LJ55.
 static const EgnnShape kShapes[] = {
-    PITA_EGNN_SHAPE(4, 2, 8, 4),
-    PITA_EGNN_SHAPE(13, 3, 7, 4),
-    PITA_EGNN_SHAPE(22, 3, 4, 4),
-    PITA_EGNN_SHAPE(55, 3, 1, 4),
+    PITA_EGNN_SHAPE(4, 2, 8, 4, 2),
+    PITA_EGNN_SHAPE(13, 3, 7, 4, 2),
+    PITA_EGNN_SHAPE(22, 3, 4, 4, 2),
+    PITA_EGNN_SHAPE(55, 3, 1, 4, 2),
 };
 
 }  // namespace pita
@@ -501,9 +547,6 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
   const EgnnShape* shape = nullptr;
   for (const auto& s : kShapes)
     if (s.n == cfg->n_particles && s.dim == cfg->n_dim) shape = &s;
-  if (!shape)
-    return fail(PITA_EUNSUPPORTED, "pita_egnn_create: no kernel instantiated for n_particles=%d n_dim=%d",
-                cfg->n_particles, cfg->n_dim);
   const int H = EH, L = cfg->n_layers, nf = cfg->in_node_nf;
   const size_t n_mats = (size_t)L * M_COUNT * MAT_F, n_vecs = VEC_EMB_F + (size_t)L * VEC_LAYER_F;
   float* h_mats = new float[n_mats];
@@ -652,6 +695,7 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
       const float up = F16_SX * F16_SW, dn = 1.0f / F16_SX;
       for (int o = 0; o < H; ++o) {
         vh[V_B2 * EH + o] *= up; vh[V_BC1 * EH + o] *= up; vh[V_BN2 * EH + o] *= up;
+        if (F16_NODE_LAYERS) { vh[V_B1 * EH + o] *= up; vh[V_BN1 * EH + o] *= up; }
         vh[V_WATT * EH + o] *= dn; vh[V_WC2 * EH + o] *= dn;
       }
     }
@@ -738,7 +782,7 @@ static int egnn_launch(pita_egnn_t* net, EgnnParams& p, void* stream) {
   const size_t lds = s->lds_bytes(p.n_layers);
   // resident blocks per CU: limited by LDS and by the 256-VGPR budget (2 waves per SIMD = two 4-wave blocks)
   int blocks_per_cu = (int)((160 * 1024) / lds);
-  blocks_per_cu = blocks_per_cu < 1 ? 1 : (blocks_per_cu > 2 ? 2 : blocks_per_cu);
+  blocks_per_cu = blocks_per_cu < 1 ? 1 : (blocks_per_cu > s->occ ? s->occ : blocks_per_cu);
   long long want = (ngroups + s->waves - 1) / s->waves;
   long long cap = (long long)net->n_cu * blocks_per_cu;
   // forward modes: one group per wave (plain grid); sampler mode: persistent grid-stride
@@ -784,7 +828,7 @@ extern "C" int pita_egnn_sampler_work(const pita_egnn_t* net, int64_t B, double*
   const int L = net->cfg.n_layers, N = s->n, G = s->G;
   const size_t lds = s->lds_bytes(L);
   int blocks_per_cu = (int)((160 * 1024) / lds);
-  blocks_per_cu = blocks_per_cu < 1 ? 1 : (blocks_per_cu > 2 ? 2 : blocks_per_cu);
+  blocks_per_cu = blocks_per_cu < 1 ? 1 : (blocks_per_cu > s->occ ? s->occ : blocks_per_cu);
   const long long ngroups = (B + G - 1) / G;
   long long want = (ngroups + s->waves - 1) / s->waves, cap = (long long)net->n_cu * blocks_per_cu;
   const long long total_waves = (want < cap ? want : cap) * s->waves;
@@ -804,7 +848,8 @@ extern "C" int pita_egnn_sampler_work(const pita_egnn_t* net, int64_t B, double*
     *mfma16_per_walker_step = 0.0;
     *mfma32_per_walker_step = (16.0 * (node_dense + edge_dense) + kstep) / (double)B;
   } else {
-    *mfma16_per_walker_step = (12.0 * node_dense + (net->cfg.precision == 2 ? 6.0 : 12.0) * edge_dense) / (double)B;
+    const double f16d = net->cfg.precision == 2 ? 6.0 : 12.0;
+    *mfma16_per_walker_step = ((F16_NODE_LAYERS ? f16d : 12.0) * node_dense + f16d * edge_dense) / (double)B;
     *mfma32_per_walker_step = kstep / (double)B;
   }
   return PITA_OK;

@@ -16,7 +16,7 @@ import torch.nn as nn
 from . import _lib
 
 
-DEFAULT_PRECISION = "bf16x3"  # dense-layer arithmetic of the HIP EGNN when the caller does not choose (see EGNN_dynamics)
+DEFAULT_PRECISION = "f16x2"  # dense-layer arithmetic of the HIP EGNN when the caller does not choose (see EGNN_dynamics)
 
 
 class _GCLParams(nn.Module):
