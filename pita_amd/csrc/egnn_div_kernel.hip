@@ -19,8 +19,14 @@
 namespace pita {
 
 struct DivParams {
-  const unsigned* mats16;
+  const unsigned* mats16;   // bf16 three-piece fragments (this kernel; the transposed matrices of the fast kernel)
+  const unsigned* mats16h;  // f16 two-piece fragments (fast kernel)
   const float* vecs;
+  const float* vecs_h;      // vectors with the f16-path scale factors folded in (fast kernel)
+  const float* vecs_div;    // [L][3][32] k-step weights in fragment order (fast kernel)
+  int* mark;                // [B] fast kernel: 1 = this launch's contribution of the walker was non-finite and NOT added;
+                            // this kernel with repair != 0: recompute and add exactly the marked walkers
+  int repair;
   int n_layers, in_nf, attention, tanh_on, feature_layout;
   float coord_scale;
   long long B;
@@ -43,7 +49,7 @@ struct DivCfg {
   static constexpr int WAVE_F = (1 + 2 * K) * PB_F + 3 * POS_F + 3 * K * POS_F;
   static __host__ __device__ constexpr int vec_f(int L) { return ((VEC_EMB_F + L * VEC_LAYER_F) + 3) & ~3; }
   static __host__ __device__ constexpr size_t lds_bytes(int L) {
-    return sizeof(float) * (size_t)(vec_f(L) + WAVES * WAVE_F);
+    return sizeof(float) * (size_t)(vec_f(L) + WAVES * WAVE_F + L * VEC_DIV_F);
   }
 };
 
@@ -83,16 +89,22 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_kernel(DivParams p) {
     const int ncol = nwalk * N;
     const int ntile = (ncol + 31) >> 5;
     int col[NT], nodei[NT];
-    bool valid[NT];
+    bool valid[NT], mine[NT];
     float c_s[NT], c_in[NT], c_out[NT];
     float posi[NT][DIM], p0i[NT][DIM], dposi[NT][K][DIM], dp0i[NT][K][DIM];
     f32x16 hf[NT], dhf[NT][K];
+    if (p.repair) {  // second launch behind the f16 kernel: only groups with a marked walker are recomputed
+      bool any = false;
+      for (int w = 0; w < nwalk; ++w) any = any || p.mark[walker0 + w] != 0;
+      if (!any) continue;
+    }
 #pragma unroll
     for (int T = 0; T < NT; ++T) {
       col[T] = T * 32 + cl;
       const int w = col[T] / N;
       nodei[T] = col[T] - w * N;
       valid[T] = col[T] < ncol;
+      mine[T] = valid[T] && (!p.repair || p.mark[walker0 + w] != 0);
       const long long wid = valid[T] ? walker0 + w : p.B - 1;
       const float hv = p.h[wid];
       const float bet = p.beta ? p.beta[wid] : 0.f;
@@ -339,7 +351,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_kernel(DivParams p) {
       for (int d = 0; d < K; ++d)
 #pragma unroll
         for (int k = 0; k < DIM; ++k) {
-          if (!(valid[T] && hh == 0 && d < p.ndir && nodei[T] * DIM + k == p.dir0 + d)) continue;
+          if (!(mine[T] && hh == 0 && d < p.ndir && nodei[T] * DIM + k == p.dir0 + d)) continue;
           float ds = 0.f;
           for (int q = 0; q < N; ++q) ds += dscr[d * C::POS_F + (cb + q) * DIM + k];
           const float dF = dposi[T][d][k] - ds / (float)N;
@@ -359,7 +371,443 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_kernel(DivParams p) {
       wave_lds_fence();
 #pragma unroll
       for (int T = 0; T < NT; ++T) {
-        if (!(valid[T] && hh == 0)) continue;
+        if (!(mine[T] && hh == 0)) continue;
+        const int cb = col[T] - nodei[T];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          float sum = 0.f;
+          for (int q = 0; q < N; ++q) sum += scr[(cb + q) * DIM + k];
+          const float F = (posi[T][k] - p0i[T][k]) - sum / (float)N;
+          const long long gi = (walker0 * N + col[T]) * DIM + k;
+          p.out[gi] = fmaf(c_s[T], p.x[gi], c_out[T] * F);
+        }
+      }
+      wave_lds_fence();
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fast variant (handles built with precision 2).  Same mapping and LDS tables; two changes in the arithmetic:
+//
+// (1) dense layers on the f16 two-piece path (egnn_common.h, PREC 2).  Feature tangents (dh, dz, dm, dagg and the LDS
+//     tables dPB / dA) travel scaled by DIV_ST = 32 so that their low f16 pieces stay normal; position tangents keep
+//     their true scale and start from 1 (the factor c_in of d(c_in x)/dx is applied to the final sum instead).
+//     Out-of-range operands end as NaN in the walker's trace term: the term is then NOT added, the walker is marked, and
+//     the launch wrapper re-runs the bf16x3 kernel above for the marked walkers (same protocol as egnn_kernel.hip).
+// (2) adjoints inside the edge, computed once per edge and shared by the K directions, remove tangent GEMMs:
+//     * coordinate head: w_c2 . (gc o Wc1 dm) = vc . dm with vc = Wc1^T (gc o w_c2): ONE transposed GEMM per edge
+//       instead of one Wc1 GEMM per direction;
+//     * last layer (aggregate dead, only the scalar head is consumed):  vc . dm = qv . dz1  with
+//       qv = g1 o W2^T (g2 o (att vc + att (1 - att) (vc . m2) w_att)): no tangent GEMM at all, dz1 = dA_i + dPB_j + k-step
+//       is only dotted with qv;
+//     * first layer (dh = 0, pos = pos0, so radial = edge_attr): every direction's dz1 is the SAME vector
+//       g1 o (w_r + w_e) times the scalar dradial_d: one W2 GEMM per edge for all directions.
+//     Per edge over three layers: 6 primal + 4 adjoint + 1 + K tangent GEMMs instead of 6 + 6 K.
+__device__ __forceinline__ void silu_dsilu16(const f32x16& vin, float pre, f32x16& y, f32x16& g) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float v = vin[r] * pre;
+    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v));
+    const float yy = v * sg;
+    y[r] = yy;
+    g[r] = fmaf(yy * (1.0f / SILU_PRESCALE), 1.0f - sg, sg);  // s (1 + z (1 - s)), z = v / kS
+  }
+}
+
+template <int N, int DIM, int G, int WAVES, int K>
+__global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_fast_kernel(DivParams p) {
+  using C = DivCfg<N, DIM, G, WAVES, K>;
+  constexpr int NT = C::NT;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int L = p.n_layers;
+  const int vec_f = C::vec_f(L);
+  for (int i = threadIdx.x; i < VEC_EMB_F + L * VEC_LAYER_F; i += WAVES * 64) lds[i] = p.vecs_h[i];
+  float* vdiv = lds + vec_f + WAVES * C::WAVE_F;   // [L][3][32] behind the per-wave tables
+  for (int i = threadIdx.x; i < L * VEC_DIV_F; i += WAVES * 64) vdiv[i] = p.vecs_div[i];
+  __syncthreads();
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cl = lane & 31, hh = lane >> 5;
+  float* PB = lds + vec_f + wave * C::WAVE_F;
+  float* dPB = PB + C::PB_F;                       // [K][PB_F]  DIV_ST x Wb dh_j
+  float* dA = dPB + K * C::PB_F;                   // [K][PB_F]  DIV_ST x Wa dh_i
+  float* posb = dA + K * C::PB_F;                  // [2][POS_F]
+  float* pos0 = posb + 2 * C::POS_F;
+  float* dposb = pos0 + C::POS_F;                  // [K][2][POS_F]
+  float* dpos0 = dposb + 2 * K * C::POS_F;         // [K][POS_F]
+  const float* vemb = lds;
+  const f32x16 zero16 = {0};
+
+  const long long total_waves = (long long)gridDim.x * WAVES;
+  const long long quota = (p.B + total_waves - 1) / total_waves;
+  const long long wbeg = ((long long)blockIdx.x * WAVES + wave) * quota;
+  const long long wend = (wbeg + quota < p.B) ? wbeg + quota : p.B;
+  for (long long walker0 = wbeg; walker0 < wend; walker0 += G) {
+    const int nwalk = (int)((wend - walker0) < G ? (wend - walker0) : G);
+    const int ncol = nwalk * N;
+    const int ntile = (ncol + 31) >> 5;
+    int col[NT], nodei[NT];
+    bool valid[NT];
+    float c_s[NT], c_in[NT], c_out[NT];
+    float posi[NT][DIM], p0i[NT][DIM], dposi[NT][K][DIM], dp0i[NT][K][DIM];
+    f32x16 hf[NT], dhf[NT][K];
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+      col[T] = T * 32 + cl;
+      const int w = col[T] / N;
+      nodei[T] = col[T] - w * N;
+      valid[T] = col[T] < ncol;
+      const long long wid = valid[T] ? walker0 + w : p.B - 1;
+      const float hv = p.h[wid];
+      const float bet = p.beta ? p.beta[wid] : 0.f;
+      const float op = 1.0f + hv, rs = 1.0f / sqrtf(op);
+      c_s[T] = 1.0f / op;
+      c_in[T] = rs;
+      c_out[T] = sqrtf(hv) * rs;
+      const float tfeat = 0.125f * logf(hv);
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) {
+        const long long gi = (walker0 * N + col[T]) * DIM + k;
+        const float xv = valid[T] ? p.x[gi] : 0.f;
+        posi[T][k] = c_in[T] * xv;
+        p0i[T][k] = posi[T][k];
+        if (hh == 0) {
+          pos0[col[T] * DIM + k] = posi[T][k];
+          posb[col[T] * DIM + k] = posi[T][k];
+        }
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+          const float v = (valid[T] && q < p.ndir && nodei[T] * DIM + k == p.dir0 + q) ? 1.0f : 0.f;  // unit direction
+          dposi[T][q][k] = v;
+          dp0i[T][q][k] = v;
+          if (hh == 0) {
+            dpos0[q * C::POS_F + col[T] * DIM + k] = v;
+            dposb[(2 * q) * C::POS_F + col[T] * DIM + k] = v;
+          }
+        }
+      }
+      float a0, a1;
+      if (p.in_nf == 1) { a0 = tfeat; a1 = 0.f; }
+      else if (p.feature_layout == 0) {
+        a0 = (2 * nodei[T] < N) ? tfeat : bet;
+        a1 = (2 * nodei[T] + 1 < N) ? tfeat : bet;
+      } else { a0 = tfeat; a1 = bet; }
+      const f32x16 w0 = lds_vec16(vemb + hh * 16), w1 = lds_vec16(vemb + 32 + hh * 16), eb = lds_vec16(vemb + 64 + hh * 16);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hf[T][r] = fmaf(w0[r], a0, fmaf(w1[r], a1, eb[r]));
+#pragma unroll
+      for (int q = 0; q < K; ++q) dhf[T][q] = zero16;
+    }
+    wave_lds_fence();
+
+    int cur = 0;
+    for (int l = 0; l < L; ++l) {
+      const unsigned* mats16 = p.mats16 + (size_t)l * M_COUNT * MAT_W;     // bf16x3: the transposed matrices
+      const unsigned* mats16h = p.mats16h + (size_t)l * M_COUNT * MAT_WH;  // f16x2: the forward matrices
+      const float* vl = lds + VEC_EMB_F + l * VEC_LAYER_F + hh * 16;
+      const bool first = (l == 0), last = (l == L - 1) && !first;
+      const float* poscur = posb + cur * C::POS_F;
+      {
+        WFrag<2> wb;
+        wb.load(nullptr, mats16h, M_WB, lane);
+#pragma unroll
+        for (int T = 0; T < NT; ++T) {
+          if (T >= ntile) continue;
+          f32x16 pb = wb.mul(hf[T], zero16);
+          pb *= F16_UNSCALE;
+          f32x4* dst = reinterpret_cast<f32x4*>(PB + col[T] * PBS + hh * 16);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dst[q] = f32x4{pb[4 * q], pb[4 * q + 1], pb[4 * q + 2], pb[4 * q + 3]};
+          if (!first) {
+#pragma unroll
+            for (int d = 0; d < K; ++d) {
+              f32x16 dpb = wb.mul(dhf[T][d], zero16);
+              dpb *= F16_UNSCALE;
+              f32x4* ddst = reinterpret_cast<f32x4*>(dPB + d * C::PB_F + col[T] * PBS + hh * 16);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) ddst[q] = f32x4{dpb[4 * q], dpb[4 * q + 1], dpb[4 * q + 2], dpb[4 * q + 3]};
+            }
+          }
+        }
+      }
+      wave_lds_fence();
+      WFrag<2> w2f, wc1f;
+      w2f.load(nullptr, mats16h, M_W2, lane);
+      wc1f.load(nullptr, mats16h, M_WC1, lane);
+      WFrag<1> wc1t, w2t;
+      wc1t.load(nullptr, mats16, M_WC1T, lane);
+      if (last) w2t.load(nullptr, mats16, M_W2T, lane);
+      const float a_re = lds[VEC_EMB_F + l * VEC_LAYER_F + V_WRE * EH + lane];
+      const float b_att = lds[VEC_EMB_F + l * VEC_LAYER_F + V_COUNT * EH];
+      // k-step weights in fragment order, pre-scaled like the k-step's A operand: [0] DIV_ST (w_r + w_e), [1] w_r, [2] w_e
+      const float* vd = vdiv + l * VEC_DIV_F + hh * 16;
+#pragma unroll
+      for (int T = 0; T < NT; ++T) {
+        if (T >= ntile) continue;
+        f32x16 Ai;
+        {
+          WFrag<2> wa;
+          wa.load(nullptr, mats16h, M_WA, lane);
+          Ai = wa.mul(hf[T], lds_vec16(vl + V_B1 * EH));
+          Ai *= F16_UNSCALE;
+          if (!first) {
+#pragma unroll
+            for (int d = 0; d < K; ++d) {
+              f32x16 da = wa.mul(dhf[T][d], zero16);
+              da *= F16_UNSCALE;
+              f32x4* dst = reinterpret_cast<f32x4*>(dA + d * C::PB_F + col[T] * PBS + hh * 16);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) dst[q] = f32x4{da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]};
+            }
+          }
+        }
+        wave_lds_fence();
+        f32x16 agg = {0}, dagg[K];
+        float xacc[DIM], dxacc[K][DIM];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) xacc[k] = 0.f;
+#pragma unroll
+        for (int d = 0; d < K; ++d) {
+          dagg[d] = zero16;
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) dxacc[d][k] = 0.f;
+        }
+        const int cbase = col[T] - nodei[T];
+        const float aggw = (l == L - 1) ? 0.0f : 1.0f;
+        for (int dd = 1; dd < N; ++dd) {
+          asm volatile("" ::: "memory");
+          int j = nodei[T] + dd;
+          j = (j >= N) ? j - N : j;
+          const int cj = (col[T] < ncol) ? cbase + j : col[T];
+          float df[DIM], e0[DIM], radial = 0.f, ea = 0.f;
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) {
+            df[k] = posi[T][k] - poscur[cj * DIM + k];
+            radial = fmaf(df[k], df[k], radial);
+            e0[k] = p0i[T][k] - pos0[cj * DIM + k];
+            ea = fmaf(e0[k], e0[k], ea);
+          }
+          // ---- primal edge MLP with derivative factors (once for all K directions)
+          f32x16 z = Ai + lds_vec16(PB + cj * PBS + hh * 16);
+          z = __builtin_amdgcn_mfma_f32_32x32x2f32(a_re, hh ? ea : radial, z, 0, 0, 0);
+          f32x16 y1, g1, m2, g2, yc, gc;
+          silu_dsilu16(z, 1.0f, y1, g1);
+          z = w2f.mul(y1, lds_vec16(vl + V_B2 * EH));
+          silu_dsilu16(z, F16_UNSCALE, m2, g2);
+          float att = 1.0f, datt_f = 0.0f;
+          const f32x16 v_watt = lds_vec16(vl + V_WATT * EH);
+          if (p.attention) {
+            att = fast_sigmoid(xhalf_sum(dot16(v_watt, m2)) + b_att);
+            datt_f = att * (1.0f - att);
+          }
+          const f32x16 m = m2 * att;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) agg[r] = fmaf(m[r], aggw, agg[r]);
+          z = wc1f.mul(m, lds_vec16(vl + V_BC1 * EH));
+          silu_dsilu16(z, F16_UNSCALE, yc, gc);
+          const f32x16 v_wc2 = lds_vec16(vl + V_WC2 * EH);
+          float cs = xhalf_sum(dot16(v_wc2, yc)), dcs_f = 1.0f;
+          if (p.tanh_on) {
+            const float th = accurate_tanh(cs);
+            dcs_f = p.coord_scale * fmaf(-th, th, 1.0f);
+            cs = th * p.coord_scale;
+          }
+          dcs_f *= (1.0f / DIV_ST);  // the feature tangents carry DIV_ST
+          // adjoint of the coordinate head: d(w_c2 . silu(Wc1 m + b)) = vc . dm
+          const f32x16 vc = wc1t.mul(gc * v_wc2, zero16);
+          const float sq = __builtin_amdgcn_sqrtf(radial + 1e-8f), inv = __builtin_amdgcn_rcpf(sq + 1.0f);
+          const float hsq = 0.5f * __builtin_amdgcn_rcpf(sq);
+          float u[DIM];
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) {
+            u[k] = df[k] * inv;
+            xacc[k] = fmaf(u[k], cs, xacc[k]);
+          }
+          // per-direction geometry
+          float ddf[K][DIM], dradial[K], dea[K];
+#pragma unroll
+          for (int d = 0; d < K; ++d) {
+            const float* dposcur = dposb + (2 * d + cur) * C::POS_F;
+            dradial[d] = 0.f;
+            dea[d] = 0.f;
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+              ddf[d][k] = dposi[T][d][k] - dposcur[cj * DIM + k];
+              dradial[d] = fmaf(df[k], ddf[d][k], dradial[d]);
+              dea[d] = fmaf(e0[k], dp0i[T][d][k] - dpos0[d * C::POS_F + cj * DIM + k], dea[d]);
+            }
+            dradial[d] *= 2.0f;
+            dea[d] *= 2.0f;
+          }
+          float dcs[K];
+          if (first) {
+            // every direction: dz1 = dradial_d (w_r + w_e) (radial == edge_attr, dh == 0): one shared tangent chain
+            f32x16 du_ = w2f.mul(g1 * lds_vec16(vd), zero16);
+            du_ *= g2 * F16_UNSCALE;  // dm2 per unit dradial, DIV_ST-scaled
+            f32x16 dmu = du_ * att;
+            if (p.attention) {
+              const float dattu = datt_f * xhalf_sum(dot16(v_watt, du_));
+#pragma unroll
+              for (int r = 0; r < 16; ++r) dmu[r] = fmaf(dattu, m2[r], dmu[r]);
+            }
+            const float vcdmu = xhalf_sum(dot16(vc, dmu));
+#pragma unroll
+            for (int d = 0; d < K; ++d) {
+              const float w_ = dradial[d] * aggw;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) dagg[d][r] = fmaf(dmu[r], w_, dagg[d][r]);
+              dcs[d] = dcs_f * (dradial[d] * vcdmu);
+            }
+          } else if (last) {
+            // only the scalar head consumes this layer's tangents: vc . dm = qv . dz1
+            const float svm = p.attention ? xhalf_sum(dot16(vc, m2)) : 0.0f;
+            f32x16 uvec = vc * att;
+            if (p.attention) {
+              const float c1_ = datt_f * svm;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) uvec[r] = fmaf(c1_, v_watt[r], uvec[r]);
+            }
+            f32x16 qv = w2t.mul(g2 * uvec, zero16);
+            qv *= g1;
+            const float qr = DIV_ST * xhalf_sum(dot16(qv, lds_vec16(vd + EH)));
+            const float qe = DIV_ST * xhalf_sum(dot16(qv, lds_vec16(vd + 2 * EH)));
+#pragma unroll
+            for (int d = 0; d < K; ++d) {
+              const f32x16 dz1 = lds_vec16(dA + d * C::PB_F + col[T] * PBS + hh * 16) +
+                                 lds_vec16(dPB + d * C::PB_F + cj * PBS + hh * 16);
+              const float sdot = xhalf_sum(dot16(qv, dz1));
+              dcs[d] = dcs_f * fmaf(qr, dradial[d], fmaf(qe, dea[d], sdot));
+            }
+          } else {
+            const f32x16 g2s = g2 * F16_UNSCALE;
+#pragma unroll
+            for (int d = 0; d < K; ++d) {
+              f32x16 dz = lds_vec16(dA + d * C::PB_F + col[T] * PBS + hh * 16) +
+                          lds_vec16(dPB + d * C::PB_F + cj * PBS + hh * 16);
+              dz = __builtin_amdgcn_mfma_f32_32x32x2f32(a_re, DIV_ST * (hh ? dea[d] : dradial[d]), dz, 0, 0, 0);
+              dz *= g1;
+              dz = w2f.mul(dz, zero16);
+              dz *= g2s;  // dm2
+              f32x16 dm = dz * att;
+              if (p.attention) {
+                const float datt = datt_f * xhalf_sum(dot16(v_watt, dz));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dm[r] = fmaf(datt, m2[r], dm[r]);
+              }
+#pragma unroll
+              for (int r = 0; r < 16; ++r) dagg[d][r] = fmaf(dm[r], aggw, dagg[d][r]);
+              dcs[d] = dcs_f * xhalf_sum(dot16(vc, dm));
+            }
+          }
+#pragma unroll
+          for (int d = 0; d < K; ++d) {
+            const float dnrm = dradial[d] * hsq;
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+              const float du = (ddf[d][k] - u[k] * dnrm) * inv;
+              dxacc[d][k] = fmaf(du, cs, fmaf(u[k], dcs[d], dxacc[d][k]));
+            }
+          }
+        }
+        float* posnext = posb + (cur ^ 1) * C::POS_F;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          posi[T][k] += xacc[k];
+          if (hh == 0) posnext[col[T] * DIM + k] = posi[T][k];
+#pragma unroll
+          for (int d = 0; d < K; ++d) {
+            dposi[T][d][k] += dxacc[d][k];
+            if (hh == 0) dposb[(2 * d + (cur ^ 1)) * C::POS_F + col[T] * DIM + k] = dposi[T][d][k];
+          }
+        }
+        if (l != L - 1) {
+          WFrag<2> wn;
+          wn.load(nullptr, mats16h, M_WN1A, lane);
+          f32x16 zn = wn.mul(hf[T], lds_vec16(vl + V_BN1 * EH));
+          f32x16 dzn[K];
+#pragma unroll
+          for (int d = 0; d < K; ++d) dzn[d] = first ? zero16 : wn.mul(dhf[T][d], zero16);
+          wn.load(nullptr, mats16h, M_WN1B, lane);
+          zn = wn.mul(agg, zn);
+#pragma unroll
+          for (int d = 0; d < K; ++d) dzn[d] = wn.mul(dagg[d], dzn[d]);
+          f32x16 yn, gn;
+          silu_dsilu16(zn, F16_UNSCALE, yn, gn);
+          gn *= F16_UNSCALE;
+          wn.load(nullptr, mats16h, M_WN2, lane);
+          f32x16 o = wn.mul(yn, lds_vec16(vl + V_BN2 * EH));
+          o *= F16_UNSCALE;
+          hf[T] += o;
+#pragma unroll
+          for (int d = 0; d < K; ++d) {
+            dzn[d] *= gn;
+            f32x16 dho = wn.mul(dzn[d], zero16);
+            dho *= F16_UNSCALE;
+            dhf[T][d] += dho;
+          }
+        }
+      }
+      wave_lds_fence();
+      cur ^= 1;
+    }
+
+    // dD_d = c_s + c_out c_in (dF - mean dF)_d  (unit position tangents); the K terms of a walker are summed by ONE lane,
+    // added only when finite, otherwise the walker is marked for the bf16x3 kernel
+    float* dscr = dPB;          // [K][NCOLP*DIM]
+    float* tsl = dA;            // [G][K] terms
+#pragma unroll
+    for (int T = 0; T < NT; ++T)
+#pragma unroll
+      for (int d = 0; d < K; ++d)
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          dposi[T][d][k] -= dp0i[T][d][k];  // dF
+          if (hh == 0) dscr[d * C::POS_F + col[T] * DIM + k] = dposi[T][d][k];
+        }
+    if (lane < G * K) tsl[lane] = 0.f;
+    wave_lds_fence();
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+      const int cb = (col[T] < ncol) ? col[T] - nodei[T] : 0;
+#pragma unroll
+      for (int d = 0; d < K; ++d)
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          if (!(valid[T] && hh == 0 && d < p.ndir && nodei[T] * DIM + k == p.dir0 + d)) continue;
+          float ds = 0.f;
+          for (int q = 0; q < N; ++q) ds += dscr[d * C::POS_F + (cb + q) * DIM + k];
+          const float dF = dposi[T][d][k] - ds / (float)N;
+          tsl[(col[T] / N) * K + d] = fmaf(c_out[T] * c_in[T], dF, c_s[T]);
+        }
+    }
+    wave_lds_fence();
+    bool bad[NT];
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+      const int w = col[T] / N;
+      float sum = 0.f;
+#pragma unroll
+      for (int d = 0; d < K; ++d) sum += tsl[(valid[T] ? w : 0) * K + d];
+      bad[T] = valid[T] && !__builtin_isfinite(sum);
+      if (valid[T] && hh == 0 && nodei[T] == 0) {
+        if (!bad[T]) p.diag_acc[walker0 + w] += sum;
+        p.mark[walker0 + w] = bad[T] ? 1 : 0;
+      }
+    }
+    wave_lds_fence();
+    if (p.out) {  // primal denoiser D = c_s x + c_out (F - mean F), F = pos^L - pos^0 (x = pos^0 / c_in)
+      float* scr = PB;
+#pragma unroll
+      for (int T = 0; T < NT; ++T)
+        if (hh == 0) {
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) scr[col[T] * DIM + k] = posi[T][k] - p0i[T][k];
+        }
+      wave_lds_fence();
+#pragma unroll
+      for (int T = 0; T < NT; ++T) {
+        if (!(valid[T] && hh == 0) || bad[T]) continue;
         const int cb = col[T] - nodei[T];
 #pragma unroll
         for (int k = 0; k < DIM; ++k) {
@@ -378,12 +826,14 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_kernel(DivParams p) {
 struct DivShape {
   int n, dim, G, waves, K;
   void (*kernel)(DivParams);
+  void (*fast)(DivParams);
   size_t (*lds_bytes)(int);
 };
 template <int N, int DIM, int G, int WAVES, int K>
 static size_t div_lds_bytes_of(int L) { return DivCfg<N, DIM, G, WAVES, K>::lds_bytes(L); }
 #define PITA_DIV_SHAPE(N, DIM, G, WAVES, K) \
-  DivShape { N, DIM, G, WAVES, K, egnn_div_kernel<N, DIM, G, WAVES, K>, div_lds_bytes_of<N, DIM, G, WAVES, K> }
+  DivShape { N, DIM, G, WAVES, K, egnn_div_kernel<N, DIM, G, WAVES, K>, egnn_div_fast_kernel<N, DIM, G, WAVES, K>, \
+             div_lds_bytes_of<N, DIM, G, WAVES, K> }
 static const DivShape kDivShapes[] = {
     PITA_DIV_SHAPE(4, 2, 8, 4, 3),
     PITA_DIV_SHAPE(13, 3, 2, 4, 3),
@@ -425,7 +875,9 @@ extern "C" int pita_egnn_div_accumulate(pita_egnn_t* net, const float* h, const 
   if (!s) return fail(PITA_EUNSUPPORTED, "pita_egnn_div_accumulate: no kernel for this particle system");
   PITA_REQUIRE(dir0 >= 0 && ndir >= 1 && ndir <= s->K && dir0 + ndir <= D, "pita_egnn_div_accumulate: directions out of range");
   DivParams p{};
-  p.mats16 = net->d_mats16; p.vecs = net->d_vecs; p.n_layers = net->cfg.n_layers; p.in_nf = net->cfg.in_node_nf;
+  p.mats16 = net->d_mats16; p.mats16h = net->d_mats16h; p.vecs = net->d_vecs; p.vecs_h = net->d_vecs_h;
+  p.vecs_div = net->d_vecs_div;
+  p.n_layers = net->cfg.n_layers; p.in_nf = net->cfg.in_node_nf;
   p.attention = net->cfg.attention; p.tanh_on = net->cfg.tanh; p.feature_layout = net->cfg.feature_layout;
   p.coord_scale = net->cfg.coords_range / (float)net->cfg.n_layers;
   p.B = B; p.h = h; p.x = x; p.beta = beta; p.dir0 = dir0; p.ndir = ndir; p.diag_acc = diag_acc; p.out = out;
@@ -434,12 +886,31 @@ extern "C" int pita_egnn_div_accumulate(pita_egnn_t* net, const float* h, const 
   if (configured != (const void*)s->kernel) {
     PITA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(s->kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PITA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(s->fast),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = (const void*)s->kernel;
   }
   const long long ngroups = (B + s->G - 1) / s->G;
   long long want = (ngroups + s->waves - 1) / s->waves;
   const long long cap = net->n_cu;  // one 4-wave block per CU (one wave per SIMD)
   const unsigned grid = (unsigned)(want < cap ? want : cap);
+  static const bool force_slow = getenv("PITA_DIV_SLOW") != nullptr;  // development aid: A/B against the bf16x3 kernel
+  if (net->cfg.precision == 2 && !force_slow) {
+    // f16 kernel first; it adds the finite terms and marks the walkers whose term was not; then the bf16x3 kernel
+    // recomputes exactly the marked ones
+    if (sizeof(int) * (size_t)B > net->mark_bytes) {
+      PITA_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+      (void)hipFree(net->d_mark);
+      net->d_mark = nullptr;
+      net->mark_bytes = 0;
+      PITA_HIP_CHECK(hipMalloc(&net->d_mark, sizeof(int) * (size_t)B));
+      net->mark_bytes = sizeof(int) * (size_t)B;
+    }
+    p.mark = net->d_mark;
+    hipLaunchKernelGGL(s->fast, dim3(grid), dim3(s->waves * 64), lds, (hipStream_t)stream, p);
+    PITA_LAUNCH_CHECK();
+    p.repair = 1;
+  }
   hipLaunchKernelGGL(s->kernel, dim3(grid), dim3(s->waves * 64), lds, (hipStream_t)stream, p);
   PITA_LAUNCH_CHECK();
   return PITA_OK;

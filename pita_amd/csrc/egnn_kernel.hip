@@ -556,6 +556,7 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
   const size_t n_mats16h = (size_t)L * M_COUNT * MAT_WH;
   unsigned* h_mats16h = new unsigned[n_mats16h]();
   float* h_vecs_h = new float[n_vecs]();
+  float* h_vecs_div = new float[(size_t)L * VEC_DIV_F]();
   // walk the state_dict order
   const float* q = w;
   const float* emb_w = q; q += H * nf;
@@ -687,6 +688,12 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
     pack_vec(vecs + V_BN2 * EH, n2b, 1, 1.0f);
     pack_vec(vecs + V_WRF * EH, e0w + 2 * H, 2 * H + 2, 1.0f);
     pack_vec(vecs + V_WEF * EH, e0w + 2 * H + 1, 2 * H + 2, 1.0f);
+    {
+      float* vd = h_vecs_div + (size_t)l * VEC_DIV_F;
+      pack_vec(vd + EH, e0w + 2 * H, 2 * H + 2, kS);
+      pack_vec(vd + 2 * EH, e0w + 2 * H + 1, 2 * H + 2, kS);
+      for (int o = 0; o < H; ++o) vd[o] = DIV_ST * (vd[EH + o] + vd[2 * EH + o]);
+    }
     vecs[V_COUNT * EH] = ab ? ab[0] : 0.f;
     {  // PREC 2 copy: biases that initialise an f16-path accumulator (W2, Wc1, Wn2) x F16_SX F16_SW, vectors that
        // consume F16_SX-scaled SiLU outputs (attention gate, coordinate head) / F16_SX
@@ -709,6 +716,9 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
   hipError_t e0 = hipMalloc(&net->d_mats16, n_mats16 * sizeof(unsigned));
   if (e0 == hipSuccess) e0 = hipMalloc(&net->d_mats16h, n_mats16h * sizeof(unsigned));
   if (e0 == hipSuccess) e0 = hipMalloc(&net->d_vecs_h, n_vecs * sizeof(float));
+  if (e0 == hipSuccess) e0 = hipMalloc(&net->d_vecs_div, (size_t)L * VEC_DIV_F * sizeof(float));
+  if (e0 == hipSuccess)
+    e0 = hipMemcpy(net->d_vecs_div, h_vecs_div, (size_t)L * VEC_DIV_F * sizeof(float), hipMemcpyHostToDevice);
   if (e0 == hipSuccess) e0 = hipMemcpy(net->d_mats16h, h_mats16h, n_mats16h * sizeof(unsigned), hipMemcpyHostToDevice);
   if (e0 == hipSuccess) e0 = hipMemcpy(net->d_vecs_h, h_vecs_h, n_vecs * sizeof(float), hipMemcpyHostToDevice);
   if (e1 == hipSuccess && e2 == hipSuccess && e0 == hipSuccess) {
@@ -722,12 +732,14 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
   delete[] h_mats16;
   delete[] h_mats16h;
   delete[] h_vecs_h;
+  delete[] h_vecs_div;
   if (e1 != hipSuccess || e2 != hipSuccess) {
     (void)hipFree(net->d_mats);
     (void)hipFree(net->d_vecs);
     (void)hipFree(net->d_mats16);
     (void)hipFree(net->d_mats16h);
     (void)hipFree(net->d_vecs_h);
+    (void)hipFree(net->d_vecs_div);
     delete net;
     return fail(PITA_EHIP, "pita_egnn_create: device upload failed: %s",
                 hipGetErrorString(e1 != hipSuccess ? e1 : e2));
@@ -758,8 +770,10 @@ extern "C" int pita_egnn_destroy(pita_egnn_t* net) {
   (void)hipFree(net->d_mats16);
   (void)hipFree(net->d_mats16h);
   (void)hipFree(net->d_vecs_h);
+  (void)hipFree(net->d_vecs_div);
   (void)hipFree(net->d_ws);
   (void)hipFree(net->d_bk);
+  (void)hipFree(net->d_mark);
   delete net;
   return PITA_OK;
 }

@@ -721,6 +721,27 @@ def test_jacobian_trace_multi_direction(pa, golden):
             np.testing.assert_allclose(tr.cpu().numpy(), want.numpy(), rtol=5e-5, atol=5e-5 * scale)
 
 
+def test_jacobian_trace_out_of_range_walkers_fall_back_to_bf16(pa, golden):
+    """The f16 divergence kernel marks walkers whose trace term is non-finite (operands beyond the f16 range) and the
+    bf16x3 kernel recomputes exactly those: far-out walkers must equal the pure bf16x3 result, ordinary walkers keep
+    the f16 kernel's, the denoiser by-product follows the same rule, and nothing is counted twice."""
+    w = golden("egnn_weights_trainedlike.npz")
+    nf, nb = make_net(pa, 13, 3, w, precision="f16x2"), make_net(pa, 13, 3, w, precision="bf16x3")
+    gen = torch.Generator().manual_seed(5)
+    B = 40
+    x = torch.randn(B, 39, generator=gen)
+    x[20:] *= 2000.0
+    x = O.remove_mean(x, 13, 3).cuda()
+    h, b = torch.full((B,), 0.02).cuda(), torch.ones(B).cuda()
+    tf, df = nf.jacobian_trace(h, x, b, want_denoiser=True)
+    tb, db = nb.jacobian_trace(h, x, b, want_denoiser=True)
+    assert torch.isfinite(tf).all() and torch.isfinite(df).all()
+    assert torch.equal(tf[20:], tb[20:]) and torch.equal(df[20:], db[20:])
+    assert not torch.equal(tf[:20], tb[:20])
+    np.testing.assert_allclose(tf[:20].cpu().numpy(), tb[:20].cpu().numpy(), rtol=2e-5, atol=2e-5)
+    assert rel(df[:20], db[:20]) < 1e-6
+
+
 @pytest.mark.parametrize("n,B", [(22, 9), (55, 3)])
 def test_derivative_kernels_other_shapes(pa, golden, n, B):
     """The 22-atom (alanine dipeptide, config C4) and LJ55 (C5) instantiations of the forward-mode, reverse-mode and
