@@ -149,7 +149,8 @@ constexpr float F16_SX = 1.0f, F16_SW = 16.0f;
 constexpr bool F16_NODE_LAYERS = true;  // false: Wa, Wb, Wn1a, Wn1b (inputs: node features, message aggregate) stay on PREC 1
 constexpr float F16_UNSCALE = 1.0f / (F16_SX * F16_SW);
 constexpr float DIV_ST = 32.0f;  // scale carried by the feature tangents of the fast divergence kernel (egnn_div_kernel.hip)
-constexpr int VEC_DIV_F = 3 * EH;
+constexpr float DIV_SV = 2048.0f;  // scale of the coordinate-head adjoint vc (its inputs gc o w_c2 are ~1e-4 for a fresh net)
+constexpr int VEC_DIV_F = 4 * EH;
 constexpr int MAT_WH = 1024;  // 32-bit words per f16-split packed matrix: [piece 2][kstep 2][lane 64][4]
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -285,7 +286,7 @@ struct pita_egnn {
   float* d_mats = nullptr;       // [L][M_COUNT][4][64][4]     f32 fragments
   float* d_vecs = nullptr;       // [VEC_EMB_F + L*VEC_LAYER_F]
   float* d_vecs_h = nullptr;     // the same vectors with the PREC 2 scale factors folded in
-  float* d_vecs_div = nullptr;   // [L][3][32] fragment order: DIV_ST kS (w_r + w_e), kS w_r, kS w_e (egnn_div_kernel.hip)
+  float* d_vecs_div = nullptr;   // [L][4][32] fragment order: DIV_ST kS (w_r + w_e), kS w_r, kS w_e, DIV_SV w_c2 / kS
   const void* shape = nullptr;   // pita::EgnnShape of egnn_kernel.hip
   int n_cu = 256;
   float* d_ws = nullptr;         // reverse-mode checkpoint scratch (egnn_vjp_kernel.hip), grown on demand

@@ -38,7 +38,7 @@ struct DivParams {
   float* out;         // [B, D] denoiser D of the primal (nullable: the caller asks for it with the first launch only)
 };
 
-template <int N, int DIM, int G, int WAVES, int K>
+template <int N, int DIM, int G, int WAVES, int K, int DAL = 1>  // DAL: Wa dh_i tables in LDS (1) or in registers (0)
 struct DivCfg {
   static constexpr int NCOL = G * N;
   static constexpr int NT = (NCOL + 31) / 32;
@@ -46,7 +46,7 @@ struct DivCfg {
   static constexpr int PB_F = NCOLP * PBS;
   static constexpr int POS_F = NCOLP * DIM;
   // PB, dPB[K], dA[K]; pos[2], pos0; dpos[K][2], dpos0[K]
-  static constexpr int WAVE_F = (1 + 2 * K) * PB_F + 3 * POS_F + 3 * K * POS_F;
+  static constexpr int WAVE_F = (1 + K + DAL * K) * PB_F + 3 * POS_F + 3 * K * POS_F;
   static __host__ __device__ constexpr int vec_f(int L) { return ((VEC_EMB_F + L * VEC_LAYER_F) + 3) & ~3; }
   static __host__ __device__ constexpr size_t lds_bytes(int L) {
     return sizeof(float) * (size_t)(vec_f(L) + WAVES * WAVE_F + L * VEC_DIV_F);
@@ -409,16 +409,17 @@ __device__ __forceinline__ void silu_dsilu16(const f32x16& vin, float pre, f32x1
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const float v = vin[r] * pre;
-    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v));
+    const float e = __builtin_amdgcn_exp2f(v);
+    const float sg = __builtin_amdgcn_rcpf(1.0f + e);
     const float yy = v * sg;
     y[r] = yy;
-    g[r] = fmaf(yy * (1.0f / SILU_PRESCALE), 1.0f - sg, sg);  // s (1 + z (1 - s)), z = v / kS
+    g[r] = fmaf(yy * (1.0f / SILU_PRESCALE), e * sg, sg);  // s (1 + z (1 - s)), z = v / kS, 1 - s = e s
   }
 }
 
-template <int N, int DIM, int G, int WAVES, int K>
+template <int N, int DIM, int G, int WAVES, int K, int DAL>
 __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_fast_kernel(DivParams p) {
-  using C = DivCfg<N, DIM, G, WAVES, K>;
+  using C = DivCfg<N, DIM, G, WAVES, K, DAL>;
   constexpr int NT = C::NT;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int L = p.n_layers;
@@ -431,8 +432,8 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_fast_kernel(DivParams 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cl = lane & 31, hh = lane >> 5;
   float* PB = lds + vec_f + wave * C::WAVE_F;
   float* dPB = PB + C::PB_F;                       // [K][PB_F]  DIV_ST x Wb dh_j
-  float* dA = dPB + K * C::PB_F;                   // [K][PB_F]  DIV_ST x Wa dh_i
-  float* posb = dA + K * C::PB_F;                  // [2][POS_F]
+  float* dA = dPB + K * C::PB_F;                   // [K][PB_F]  DIV_ST x Wa dh_i (DAL = 1; else registers)
+  float* posb = dA + DAL * K * C::PB_F;            // [2][POS_F]
   float* pos0 = posb + 2 * C::POS_F;
   float* dposb = pos0 + C::POS_F;                  // [K][2][POS_F]
   float* dpos0 = dposb + 2 * K * C::POS_F;         // [K][POS_F]
@@ -503,7 +504,6 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_fast_kernel(DivParams 
 
     int cur = 0;
     for (int l = 0; l < L; ++l) {
-      const unsigned* mats16 = p.mats16 + (size_t)l * M_COUNT * MAT_W;     // bf16x3: the transposed matrices
       const unsigned* mats16h = p.mats16h + (size_t)l * M_COUNT * MAT_WH;  // f16x2: the forward matrices
       const float* vl = lds + VEC_EMB_F + l * VEC_LAYER_F + hh * 16;
       const bool first = (l == 0), last = (l == L - 1) && !first;
@@ -535,9 +535,9 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_fast_kernel(DivParams 
       WFrag<2> w2f, wc1f;
       w2f.load(nullptr, mats16h, M_W2, lane);
       wc1f.load(nullptr, mats16h, M_WC1, lane);
-      WFrag<1> wc1t, w2t;
-      wc1t.load(nullptr, mats16, M_WC1T, lane);
-      if (last) w2t.load(nullptr, mats16, M_W2T, lane);
+      WFrag<2> wc1t, w2t;  // adjoints: transposed matrices
+      wc1t.load(nullptr, mats16h, M_WC1T, lane);
+      if (last) w2t.load(nullptr, mats16h, M_W2T, lane);
       const float a_re = lds[VEC_EMB_F + l * VEC_LAYER_F + V_WRE * EH + lane];
       const float b_att = lds[VEC_EMB_F + l * VEC_LAYER_F + V_COUNT * EH];
       // k-step weights in fragment order, pre-scaled like the k-step's A operand: [0] DIV_ST (w_r + w_e), [1] w_r, [2] w_e
@@ -545,7 +545,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_fast_kernel(DivParams 
 #pragma unroll
       for (int T = 0; T < NT; ++T) {
         if (T >= ntile) continue;
-        f32x16 Ai;
+        f32x16 Ai, dAr[DAL ? 1 : K];
         {
           WFrag<2> wa;
           wa.load(nullptr, mats16h, M_WA, lane);
@@ -556,9 +556,13 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_fast_kernel(DivParams 
             for (int d = 0; d < K; ++d) {
               f32x16 da = wa.mul(dhf[T][d], zero16);
               da *= F16_UNSCALE;
-              f32x4* dst = reinterpret_cast<f32x4*>(dA + d * C::PB_F + col[T] * PBS + hh * 16);
+              if (DAL) {
+                f32x4* dst = reinterpret_cast<f32x4*>(dA + d * C::PB_F + col[T] * PBS + hh * 16);
 #pragma unroll
-              for (int q = 0; q < 4; ++q) dst[q] = f32x4{da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]};
+                for (int q = 0; q < 4; ++q) dst[q] = f32x4{da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]};
+              } else {
+                dAr[d] = da;
+              }
             }
           }
         }
@@ -606,16 +610,16 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_fast_kernel(DivParams 
           for (int r = 0; r < 16; ++r) agg[r] = fmaf(m[r], aggw, agg[r]);
           z = wc1f.mul(m, lds_vec16(vl + V_BC1 * EH));
           silu_dsilu16(z, F16_UNSCALE, yc, gc);
-          const f32x16 v_wc2 = lds_vec16(vl + V_WC2 * EH);
-          float cs = xhalf_sum(dot16(v_wc2, yc)), dcs_f = 1.0f;
+          float cs = xhalf_sum(dot16(lds_vec16(vl + V_WC2 * EH), yc)), dcs_f = 1.0f;
           if (p.tanh_on) {
             const float th = accurate_tanh(cs);
             dcs_f = p.coord_scale * fmaf(-th, th, 1.0f);
             cs = th * p.coord_scale;
           }
-          dcs_f *= (1.0f / DIV_ST);  // the feature tangents carry DIV_ST
-          // adjoint of the coordinate head: d(w_c2 . silu(Wc1 m + b)) = vc . dm
-          const f32x16 vc = wc1t.mul(gc * v_wc2, zero16);
+          dcs_f *= 1.0f / (DIV_ST * DIV_SV);  // the feature tangents carry DIV_ST, the head adjoint DIV_SV
+          // adjoint of the coordinate head: d(w_c2 . silu(Wc1 m + b)) = vc . dm;  vc carries DIV_SV
+          f32x16 vc = wc1t.mul(gc * lds_vec16(vd + 3 * EH), zero16);
+          vc *= F16_UNSCALE;
           const float sq = __builtin_amdgcn_sqrtf(radial + 1e-8f), inv = __builtin_amdgcn_rcpf(sq + 1.0f);
           const float hsq = 0.5f * __builtin_amdgcn_rcpf(sq);
           float u[DIM];
@@ -669,12 +673,12 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_fast_kernel(DivParams 
               for (int r = 0; r < 16; ++r) uvec[r] = fmaf(c1_, v_watt[r], uvec[r]);
             }
             f32x16 qv = w2t.mul(g2 * uvec, zero16);
-            qv *= g1;
+            qv *= g1 * F16_UNSCALE;
             const float qr = DIV_ST * xhalf_sum(dot16(qv, lds_vec16(vd + EH)));
             const float qe = DIV_ST * xhalf_sum(dot16(qv, lds_vec16(vd + 2 * EH)));
 #pragma unroll
             for (int d = 0; d < K; ++d) {
-              const f32x16 dz1 = lds_vec16(dA + d * C::PB_F + col[T] * PBS + hh * 16) +
+              const f32x16 dz1 = (DAL ? lds_vec16(dA + d * C::PB_F + col[T] * PBS + hh * 16) : dAr[DAL ? 0 : d]) +
                                  lds_vec16(dPB + d * C::PB_F + cj * PBS + hh * 16);
               const float sdot = xhalf_sum(dot16(qv, dz1));
               dcs[d] = dcs_f * fmaf(qr, dradial[d], fmaf(qe, dea[d], sdot));
@@ -683,7 +687,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_fast_kernel(DivParams 
             const f32x16 g2s = g2 * F16_UNSCALE;
 #pragma unroll
             for (int d = 0; d < K; ++d) {
-              f32x16 dz = lds_vec16(dA + d * C::PB_F + col[T] * PBS + hh * 16) +
+              f32x16 dz = (DAL ? lds_vec16(dA + d * C::PB_F + col[T] * PBS + hh * 16) : dAr[DAL ? 0 : d]) +
                           lds_vec16(dPB + d * C::PB_F + cj * PBS + hh * 16);
               dz = __builtin_amdgcn_mfma_f32_32x32x2f32(a_re, DIV_ST * (hh ? dea[d] : dradial[d]), dz, 0, 0, 0);
               dz *= g1;
@@ -755,7 +759,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_fast_kernel(DivParams 
     // dD_d = c_s + c_out c_in (dF - mean dF)_d  (unit position tangents); the K terms of a walker are summed by ONE lane,
     // added only when finite, otherwise the walker is marked for the bf16x3 kernel
     float* dscr = dPB;          // [K][NCOLP*DIM]
-    float* tsl = dA;            // [G][K] terms
+    float* tsl = PB;            // [G][K] terms (the partner table is free now)
 #pragma unroll
     for (int T = 0; T < NT; ++T)
 #pragma unroll
@@ -829,11 +833,16 @@ struct DivShape {
   void (*fast)(DivParams);
   size_t (*lds_bytes)(int);
 };
-template <int N, int DIM, int G, int WAVES, int K>
-static size_t div_lds_bytes_of(int L) { return DivCfg<N, DIM, G, WAVES, K>::lds_bytes(L); }
+template <int N, int DIM, int G, int WAVES, int K, int DAL>
+static size_t div_lds_bytes_of(int L) { return DivCfg<N, DIM, G, WAVES, K, DAL>::lds_bytes(L); }
 #define PITA_DIV_SHAPE(N, DIM, G, WAVES, K) \
-  DivShape { N, DIM, G, WAVES, K, egnn_div_kernel<N, DIM, G, WAVES, K>, egnn_div_fast_kernel<N, DIM, G, WAVES, K>, \
-             div_lds_bytes_of<N, DIM, G, WAVES, K> }
+  DivShape { N, DIM, G, WAVES, K, egnn_div_kernel<N, DIM, G, WAVES, K>, egnn_div_fast_kernel<N, DIM, G, WAVES, K, 1>, \
+             div_lds_bytes_of<N, DIM, G, WAVES, K, 1> }
+// fast kernel only, Wa dh_i in registers (frees LDS for a fourth direction); the repair kernel is the K-direction
+// kernel of kDivShapes, which accepts any ndir <= its own K -- so these are used for the fast launch only
+#define PITA_DIV_FAST_SHAPE(N, DIM, G, WAVES, K) \
+  DivShape { N, DIM, G, WAVES, K, nullptr, egnn_div_fast_kernel<N, DIM, G, WAVES, K, 0>, \
+             div_lds_bytes_of<N, DIM, G, WAVES, K, 0> }
 static const DivShape kDivShapes[] = {
     PITA_DIV_SHAPE(4, 2, 8, 4, 3),
     PITA_DIV_SHAPE(13, 3, 2, 4, 3),
@@ -853,6 +862,15 @@ static const DivShape* find_div_shape(int n, int dim) {
     if (c.n == n && c.dim == dim) return &c;
   return nullptr;
 }
+// f16 kernel with more directions per launch than the bf16x3 kernel's LDS budget allows (Wa dh_i in registers);
+// PITA_DIV_FAST_K=0 falls back to the bf16x3 kernel's K (development aid)
+// measured: K = 4 for LJ13 (PITA_DIV_FAST_SHAPE(13, 3, 2, 4, 4)): 65.3 ms for the 39 directions against 61.9 ms with K = 3
+// (800 B/lane of scratch: the fourth direction's state no longer fits the 512 registers) -- not instantiated
+static const DivShape* find_div_fast_shape(int n, int dim) { return find_div_shape(n, dim); }
+static bool div_fast_enabled(const pita_egnn* net) {
+  static const bool force_slow = getenv("PITA_DIV_SLOW") != nullptr;  // development aid: A/B against the bf16x3 kernel
+  return net->cfg.precision == 2 && !force_slow;
+}
 
 }  // namespace pita
 
@@ -860,8 +878,22 @@ using namespace pita;
 
 extern "C" int pita_egnn_div_directions(const pita_egnn_t* net) {
   if (!net) return PITA_EINVAL;
-  const DivShape* s = find_div_shape(net->cfg.n_particles, net->cfg.n_dim);
+  const DivShape* s = div_fast_enabled(net) ? find_div_fast_shape(net->cfg.n_particles, net->cfg.n_dim)
+                                            : find_div_shape(net->cfg.n_particles, net->cfg.n_dim);
   return s ? s->K : PITA_EUNSUPPORTED;
+}
+
+static int div_launch(const DivShape* s, void (*kernel)(DivParams), pita_egnn_t* net, const DivParams& p, void* stream) {
+  const size_t lds = s->lds_bytes(p.n_layers);
+  PITA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds));
+  const long long ngroups = (p.B + s->G - 1) / s->G;
+  long long want = (ngroups + s->waves - 1) / s->waves;
+  const long long cap = net->n_cu;  // one 4-wave block per CU (one wave per SIMD)
+  const unsigned grid = (unsigned)(want < cap ? want : cap);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(s->waves * 64), lds, (hipStream_t)stream, p);
+  PITA_LAUNCH_CHECK();
+  return PITA_OK;
 }
 
 extern "C" int pita_egnn_div_accumulate(pita_egnn_t* net, const float* h, const float* x, const float* beta, int dir0,
@@ -873,7 +905,9 @@ extern "C" int pita_egnn_div_accumulate(pita_egnn_t* net, const float* h, const 
   const int D = net->cfg.n_particles * net->cfg.n_dim;
   const DivShape* s = find_div_shape(net->cfg.n_particles, net->cfg.n_dim);
   if (!s) return fail(PITA_EUNSUPPORTED, "pita_egnn_div_accumulate: no kernel for this particle system");
-  PITA_REQUIRE(dir0 >= 0 && ndir >= 1 && ndir <= s->K && dir0 + ndir <= D, "pita_egnn_div_accumulate: directions out of range");
+  const bool fast = div_fast_enabled(net);
+  const DivShape* sf = fast ? find_div_fast_shape(net->cfg.n_particles, net->cfg.n_dim) : s;
+  PITA_REQUIRE(dir0 >= 0 && ndir >= 1 && ndir <= sf->K && dir0 + ndir <= D, "pita_egnn_div_accumulate: directions out of range");
   DivParams p{};
   p.mats16 = net->d_mats16; p.mats16h = net->d_mats16h; p.vecs = net->d_vecs; p.vecs_h = net->d_vecs_h;
   p.vecs_div = net->d_vecs_div;
@@ -881,37 +915,27 @@ extern "C" int pita_egnn_div_accumulate(pita_egnn_t* net, const float* h, const 
   p.attention = net->cfg.attention; p.tanh_on = net->cfg.tanh; p.feature_layout = net->cfg.feature_layout;
   p.coord_scale = net->cfg.coords_range / (float)net->cfg.n_layers;
   p.B = B; p.h = h; p.x = x; p.beta = beta; p.dir0 = dir0; p.ndir = ndir; p.diag_acc = diag_acc; p.out = out;
-  const size_t lds = s->lds_bytes(p.n_layers);
-  static thread_local const void* configured = nullptr;
-  if (configured != (const void*)s->kernel) {
-    PITA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(s->kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    PITA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(s->fast),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = (const void*)s->kernel;
+  if (!fast) return div_launch(s, s->kernel, net, p, stream);
+  // f16 kernel first: it adds the finite terms and marks the walkers whose term was not; then the bf16x3 kernel
+  // recomputes exactly the marked ones (in chunks of its own K directions)
+  if (sizeof(int) * (size_t)B > net->mark_bytes) {
+    PITA_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    (void)hipFree(net->d_mark);
+    net->d_mark = nullptr;
+    net->mark_bytes = 0;
+    PITA_HIP_CHECK(hipMalloc(&net->d_mark, sizeof(int) * (size_t)B));
+    net->mark_bytes = sizeof(int) * (size_t)B;
   }
-  const long long ngroups = (B + s->G - 1) / s->G;
-  long long want = (ngroups + s->waves - 1) / s->waves;
-  const long long cap = net->n_cu;  // one 4-wave block per CU (one wave per SIMD)
-  const unsigned grid = (unsigned)(want < cap ? want : cap);
-  static const bool force_slow = getenv("PITA_DIV_SLOW") != nullptr;  // development aid: A/B against the bf16x3 kernel
-  if (net->cfg.precision == 2 && !force_slow) {
-    // f16 kernel first; it adds the finite terms and marks the walkers whose term was not; then the bf16x3 kernel
-    // recomputes exactly the marked ones
-    if (sizeof(int) * (size_t)B > net->mark_bytes) {
-      PITA_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-      (void)hipFree(net->d_mark);
-      net->d_mark = nullptr;
-      net->mark_bytes = 0;
-      PITA_HIP_CHECK(hipMalloc(&net->d_mark, sizeof(int) * (size_t)B));
-      net->mark_bytes = sizeof(int) * (size_t)B;
-    }
-    p.mark = net->d_mark;
-    hipLaunchKernelGGL(s->fast, dim3(grid), dim3(s->waves * 64), lds, (hipStream_t)stream, p);
-    PITA_LAUNCH_CHECK();
-    p.repair = 1;
+  p.mark = net->d_mark;
+  int rc = div_launch(sf, sf->fast, net, p, stream);
+  if (rc != PITA_OK) return rc;
+  p.repair = 1;
+  for (int d0 = 0; d0 < ndir; d0 += s->K) {
+    p.dir0 = dir0 + d0;
+    p.ndir = (ndir - d0) < s->K ? (ndir - d0) : s->K;
+    p.out = (d0 == 0) ? out : nullptr;
+    rc = div_launch(s, s->kernel, net, p, stream);
+    if (rc != PITA_OK) return rc;
   }
-  hipLaunchKernelGGL(s->kernel, dim3(grid), dim3(s->waves * 64), lds, (hipStream_t)stream, p);
-  PITA_LAUNCH_CHECK();
   return PITA_OK;
 }

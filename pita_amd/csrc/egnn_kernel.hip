@@ -667,6 +667,13 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
         pack_mat16(m16 + slot * MAT_W, T, H, 0, 1.0f);
         pack_mat(mats + slot * MAT_F, T, H, 0, 1.0f);
       };
+      auto pack_th = [&](int slot, const float* M, int ld, int col0) {  // f16 fragments (fast divergence kernel)
+        for (int k = 0; k < H; ++k)
+          for (int o = 0; o < H; ++o) T[k * H + o] = M[o * ld + col0 + k];
+        pack_mat16h(m16h + slot * MAT_WH, T, H, 0, 1.0f);
+      };
+      pack_th(M_W2T, e2w, H, 0);
+      pack_th(M_WC1T, c0w, H, 0);
       pack_t(M_WAT, e0w, 2 * H + 2, 0);
       pack_t(M_WBT, e0w, 2 * H + 2, H);
       pack_t(M_W2T, e2w, H, 0);
@@ -693,6 +700,7 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
       pack_vec(vd + EH, e0w + 2 * H, 2 * H + 2, kS);
       pack_vec(vd + 2 * EH, e0w + 2 * H + 1, 2 * H + 2, kS);
       for (int o = 0; o < H; ++o) vd[o] = DIV_ST * (vd[EH + o] + vd[2 * EH + o]);
+      pack_vec(vd + 3 * EH, c2w, 1, DIV_SV * kSi);
     }
     vecs[V_COUNT * EH] = ab ? ab[0] : 0.f;
     {  // PREC 2 copy: biases that initialise an f16-path accumulator (W2, Wc1, Wn2) x F16_SX F16_SW, vectors that

@@ -1,11 +1,12 @@
 """Timing of the debiased (Feynman-Kac) regime: walker-steps/s of sde.f + EM update at a given batch."""
-import copy, sys, time
+import copy, os, sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import pita_amd
 from pita_amd.energy_net import EnergyNet
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
-w = dict(np.load("tests/golden/egnn_weights_trainedlike.npz"))
+w = dict(np.load(os.path.join(ROOT, "tests/golden/egnn_weights_trainedlike.npz")))
 net = pita_amd.EGNN_dynamics(13, 3, hidden_nf=32, n_layers=3, recurrent=True, tanh=True, attention=True,
                              condition_time=True, condition_temperature=True, agg="sum")
 net.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
