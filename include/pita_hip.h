@@ -189,14 +189,21 @@ int pita_egnn_div_accumulate(pita_egnn_t* net, const float* h, const float* x, c
                              void* stream);
 
 /* Feynman-Kac drift assembly per walker from those reductions (replaces the torch/autograd expressions of
- * sdes.py:157-227): with E = (1+c_s)|x|^2/(2h) - <D_E,x>/h,
- *   grad E = ((1+c_s) x - D_E - jtx_E)/h,  b = (D_S - x)/h * g2/2,  drift_X = gamma (-grad E) g2/2 + gamma b,
- *   drift_A = gamma^2 <-grad E, b> + gamma (trace_S - D)/h g2/2 + gamma dE/dt + dgamma E   (NOT yet clamped).
- * All arrays are device pointers: x, D_E, jtx_E, D_S, drift_X [B,D]; the rest [B]. */
-int pita_fk_assemble(const float* x, const float* h, const float* g2, const float* D_E, const float* jtx_E,
-                     const float* dot_h, const float* D_S, const float* trace_S, float gamma, float dgamma,
-                     float* drift_X, float* drift_A, float* div_bt, float* cross, float* dUdt, float* Ut,
-                     int64_t B, int D, void* stream);
+ * sdes.py:157-227): with E = be [(1+c_s)|x|^2/(2h) - <D_E,x>/h],
+ *   grad E = be ((1+c_s) x - D_E - jtx_E)/h,  s = bs (D_S - x)/h,  b = s g2/2,
+ *   U = E, or with pin_energy (energy_net.py:43-48)  U = w U0 + (1-w) E,  U0 = clamp(-logp_target, +-1e3),
+ *   grad U = (1-w) grad E  (the reference's energy classes return log p detached: no target force enters),
+ *   dU/dt = dw/dt (U0 - E) + (1-w) dE/dh dh/dt   (dh/dt from the schedule, not assumed equal to g^2),
+ *   drift_X = gamma (-grad U) g2/2 + gamma b,
+ *   drift_A = gamma^2 <-grad U, b> + gamma bs (trace_S - D)/h g2/2 + gamma dU/dt + dgamma U   (NOT yet clamped).
+ * be / bs: per-walker inverse temperatures when the energy / score net was built with precondition_beta
+ * (score_net.py:36-38, energy_net.py:40-41), NULL = 1.  pin_w = (1-t)^3 and pin_dw = -3 (1-t)^2 with logp_target [B];
+ * logp_target NULL = no pinning.  All arrays are device pointers: x, D_E, jtx_E, D_S, drift_X [B,D]; the rest [B]. */
+int pita_fk_assemble(const float* x, const float* h, const float* g2, const float* dhdt, const float* D_E,
+                     const float* jtx_E, const float* dot_h, const float* D_S, const float* trace_S, float gamma,
+                     float dgamma, const float* beta_e /*nullable*/, const float* beta_s /*nullable*/, float pin_w,
+                     float pin_dw, const float* logp_target /*nullable*/, float* drift_X, float* drift_A, float* div_bt,
+                     float* cross, float* dUdt, float* Ut, int64_t B, int D, void* stream);
 /* K11: in place a[c] = min(a[c], quantile_q(a over its chunk)), chunks of `chunk` consecutive walkers, linear
  * interpolation like torch.quantile (sdes.py:230; sde_integration.py:179). */
 int pita_quantile_clamp(float* a, int64_t B, int64_t chunk, float q, void* stream);

@@ -517,27 +517,39 @@ def f_not_debiased(backbone: Backbone, sched, gamma_sched, t: Tensor, x: Tensor,
 
 
 def f_debiased(score_backbone: Backbone, energy_backbone: Backbone, sched, gamma_sched, t: Tensor, x: Tensor,
-               beta, clamp_quantile: Optional[float] = 0.9) -> Terms:
+               beta, clamp_quantile: Optional[float] = 0.9, pin_energy: bool = False, target_logp=None,
+               precondition_beta: bool = False) -> Terms:
     """Feynman-Kac corrected drift (sdes.py:151-239): needs grad_x E_theta, exact div s_theta
-    (vmap(jacrev), utils.py:43-51), dE_theta/dt through h(t)."""
+    (vmap(jacrev), utils.py:43-51), dE_theta/dt through h(t).  ``pin_energy`` (energy_net.py:43-48) blends the model
+    energy with the clamped target energy U0 = clamp(-log p_target(x), +-1e3); ``target_logp`` is called like the
+    reference's energy classes, whose result is DETACHED (lennardjones_energy.py:227), so no target force enters
+    grad_x U.  ``precondition_beta`` applies to both nets (score_net.py:36-38, energy_net.py:40-41)."""
     from torch.func import jacrev, vmap
 
     gamma = gamma_sched.gamma(t)
+
+    def energy(ht, xg, tb):
+        E = energy_theta(energy_backbone, ht, xg, beta, precondition_beta)
+        if not pin_energy:
+            return E
+        U0 = torch.clamp(-target_logp(xg.detach()).detach().to(E.dtype), max=1e3, min=-1e3)
+        return (1 - tb) ** 3 * U0 + (1 - (1 - tb) ** 3) * E
+
     with torch.enable_grad():
         xg = x.detach().clone().requires_grad_(True)
         tb = (t * torch.ones(x.shape[0], dtype=x.dtype)).detach().requires_grad_(True)
         ht = sched.h(tb)
         g2 = sched.g(tb).pow(2)
-        Ut = energy_theta(energy_backbone, ht, xg, beta)
+        Ut = energy(ht, xg, tb)
         nabla_U = torch.autograd.grad(Ut.sum(), xg, create_graph=True)[0]
-        s_t = score(score_backbone, ht, xg, beta)
+        s_t = score(score_backbone, ht, xg, beta, precondition_beta)
         bt = s_t * g2.unsqueeze(-1) / 2
         drift_X = (gamma * -nabla_U * g2.unsqueeze(-1) / 2 + gamma * bt).detach()
-        Ut2 = energy_theta(energy_backbone, ht, xg, beta)
+        Ut2 = energy(ht, xg, tb)
         dUt_dt = torch.autograd.grad(Ut2.sum(), tb)[0].detach()
 
         def one(h1, x1):
-            return score(score_backbone, h1.unsqueeze(0), x1.unsqueeze(0), beta).squeeze(0)
+            return score(score_backbone, h1.unsqueeze(0), x1.unsqueeze(0), beta, precondition_beta).squeeze(0)
 
         jac = vmap(jacrev(one, argnums=1))(ht.detach(), x.detach())
         div_bt = jac.diagonal(dim1=-2, dim2=-1).sum(-1).detach() * g2.detach() / 2

@@ -73,7 +73,8 @@ _PROTOS = {
     "pita_egnn_div_directions": (c_int, [c_void_p]),
     "pita_egnn_div_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                          c_int64, c_void_p]),
-    "pita_fk_assemble": (c_int, [c_void_p] * 8 + [c_float, c_float] + [c_void_p] * 6 + [c_int64, c_int, c_void_p]),
+    "pita_fk_assemble": (c_int, [c_void_p] * 9 + [c_float, c_float, c_void_p, c_void_p, c_float, c_float, c_void_p] +
+                         [c_void_p] * 6 + [c_int64, c_int, c_void_p]),
     "pita_quantile_clamp": (c_int, [c_void_p, c_int64, c_int64, c_float, c_void_p]),
     "pita_egnn_sampler_run": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_uint64, c_uint64,
                                       c_int64, c_int, c_void_p, c_void_p, c_void_p]),

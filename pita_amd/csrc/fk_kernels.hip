@@ -9,7 +9,10 @@
 namespace pita {
 
 struct FkParams {
-  const float *x, *h, *g2;           // [B,D], [B], [B]
+  const float *x, *h, *g2, *dhdt;    // [B,D], [B], [B], [B]
+  const float *beta_e, *beta_s;      // nullable [B]: precondition_beta of the energy net / of the score net
+  float pin_w, pin_dw;               // pin_energy: w = (1 - t)^3 and dw/dt (0, 0 = off)
+  const float* logp_target;          // pin_energy: log p_target(x) [B]
   const float *D_E, *jtx_E, *dot_h;  // energy net: denoiser, J^T x, <x, dD/dh>
   const float *D_S, *trace_S;        // score net: denoiser, trace of J_x D
   float gamma, dgamma;
@@ -27,6 +30,11 @@ __global__ void __launch_bounds__(256) fk_assemble_kernel(FkParams p) {
   for (long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); b < p.B; b += nwaves) {
     const float h = p.h[b], g2 = p.g2[b];
     const float c_s = 1.0f / (1.0f + h);
+    // precondition_beta (score_net.py:36-38, energy_net.py:40-41): E, grad E, dE/dt scale with beta_e; s and div s with
+    // beta_s.  pin_energy (energy_net.py:43-48): U = w U0 + (1 - w) E with U0 = clamp(-log p_target, +-1e3); the
+    // reference's energy classes return log p DETACHED, so grad_x U = (1 - w) grad_x E (no target force)
+    const float be = p.beta_e ? p.beta_e[b] : 1.0f, bs = p.beta_s ? p.beta_s[b] : 1.0f;
+    const float keep = (1.0f - p.pin_w) * be;
     const float* x = p.x + b * p.D;
     const float* DE = p.D_E + b * p.D;
     const float* JE = p.jtx_E + b * p.D;
@@ -37,8 +45,8 @@ __global__ void __launch_bounds__(256) fk_assemble_kernel(FkParams p) {
       const float xv = x[k];
       x2 = fmaf(xv, xv, x2);
       DEx = fmaf(DE[k], xv, DEx);
-      const float nab = (fmaf(1.0f + c_s, xv, -DE[k]) - JE[k]) / h;   // grad_x E_theta
-      const float bt = ((DS[k] - xv) / h) * g2 * 0.5f;                 // b_t = s_theta g^2 / 2
+      const float nab = keep * ((fmaf(1.0f + c_s, xv, -DE[k]) - JE[k]) / h);   // grad_x U_t
+      const float bt = (bs * ((DS[k] - xv) / h)) * g2 * 0.5f;                   // b_t = s_theta g^2 / 2
       dX[k] = p.gamma * (-nab) * g2 * 0.5f + p.gamma * bt;             // sdes.py:172-174 (gamma_score = gamma_energy)
       inner = fmaf(-nab, bt, inner);
     }
@@ -49,11 +57,19 @@ __global__ void __launch_bounds__(256) fk_assemble_kernel(FkParams p) {
       inner += __shfl_xor(inner, o, 64);
     }
     if (lane == 0) {
-      const float Ut = (1.0f + c_s) / (2.0f * h) * x2 - DEx / h;
+      const float Et = be * ((1.0f + c_s) / (2.0f * h) * x2 - DEx / h);
       const float den = 2.0f * h + 2.0f * h * h;
       const float dq = (-2.0f * h * h - 8.0f * h - 4.0f) / (den * den);  // d/dh [(1 + c_s)/(2h)]
-      const float dUdt = (dq * x2 + DEx / (h * h) - p.dot_h[b] / h) * g2;  // dh/dt = g^2
-      const float div_bt = ((p.trace_S[b] - (float)p.D) / h) * g2 * 0.5f;
+      // dE/dt = dE/dh dh/dt, dh/dt supplied by the schedule (== g^2 for the variance-exploding schedules, but a
+      // plug-in schedule need not satisfy that identity exactly: sdes.py:218 differentiates through h(t))
+      const float dEdt = be * (dq * x2 + DEx / (h * h) - p.dot_h[b] / h) * p.dhdt[b];
+      float Ut = Et, dUdt = dEdt;
+      if (p.logp_target) {
+        const float U0 = fminf(fmaxf(-p.logp_target[b], -1e3f), 1e3f);
+        Ut = p.pin_w * U0 + (1.0f - p.pin_w) * Et;
+        dUdt = p.pin_dw * (U0 - Et) + (1.0f - p.pin_w) * dEdt;
+      }
+      const float div_bt = (bs * ((p.trace_S[b] - (float)p.D) / h)) * g2 * 0.5f;
       p.drift_A[b] = p.gamma * p.gamma * inner + p.gamma * div_bt + p.gamma * dUdt + p.dgamma * Ut;  // :222-227
       p.div_bt[b] = div_bt;
       p.cross[b] = inner;
@@ -155,15 +171,21 @@ __global__ void __launch_bounds__(QT) quantile_clamp_kernel(float* __restrict__ 
 
 using namespace pita;
 
-extern "C" int pita_fk_assemble(const float* x, const float* h, const float* g2, const float* D_E, const float* jtx_E,
-                                const float* dot_h, const float* D_S, const float* trace_S, float gamma, float dgamma,
-                                float* drift_X, float* drift_A, float* div_bt, float* cross, float* dUdt, float* Ut,
-                                int64_t B, int D, void* stream) {
+extern "C" int pita_fk_assemble(const float* x, const float* h, const float* g2, const float* dhdt, const float* D_E,
+                                const float* jtx_E, const float* dot_h, const float* D_S, const float* trace_S,
+                                float gamma, float dgamma, const float* beta_e, const float* beta_s, float pin_w,
+                                float pin_dw, const float* logp_target, float* drift_X, float* drift_A, float* div_bt,
+                                float* cross, float* dUdt, float* Ut, int64_t B, int D, void* stream) {
   PITA_REQUIRE(B >= 0 && D >= 1, "pita_fk_assemble: bad shape");
   if (B == 0) return PITA_OK;
-  PITA_REQUIRE(x && h && g2 && D_E && jtx_E && dot_h && D_S && trace_S && drift_X && drift_A && div_bt && cross && dUdt && Ut,
-               "pita_fk_assemble: null argument");
-  FkParams p{x, h, g2, D_E, jtx_E, dot_h, D_S, trace_S, gamma, dgamma, drift_X, drift_A, div_bt, cross, dUdt, Ut, B, D};
+  PITA_REQUIRE(x && h && g2 && dhdt && D_E && jtx_E && dot_h && D_S && trace_S && drift_X && drift_A && div_bt && cross &&
+               dUdt && Ut, "pita_fk_assemble: null argument");
+  PITA_REQUIRE(logp_target || (pin_w == 0.f && pin_dw == 0.f), "pita_fk_assemble: pin weights without logp_target");
+  FkParams p{};
+  p.x = x; p.h = h; p.g2 = g2; p.dhdt = dhdt; p.beta_e = beta_e; p.beta_s = beta_s;
+  p.pin_w = logp_target ? pin_w : 0.f; p.pin_dw = logp_target ? pin_dw : 0.f; p.logp_target = logp_target;
+  p.D_E = D_E; p.jtx_E = jtx_E; p.dot_h = dot_h; p.D_S = D_S; p.trace_S = trace_S; p.gamma = gamma; p.dgamma = dgamma;
+  p.drift_X = drift_X; p.drift_A = drift_A; p.div_bt = div_bt; p.cross = cross; p.dUdt = dUdt; p.Ut = Ut; p.B = B; p.D = D;
   const long long nb = (B + 3) / 4;  // one wave per walker, four waves per block
   hipLaunchKernelGGL(fk_assemble_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, (hipStream_t)stream, p);
   PITA_LAUNCH_CHECK();

@@ -357,7 +357,9 @@ class WeightedSDEIntegrator:
         t_end = times[min(self.end_resampling_step, self.num_integration_steps - 1)]
         xg = comm.all_gather(x)
         tb = torch.full((xg.shape[0],), float(t_end), device=xg.device)
-        model_energy = self.sde.energy_net.forward_energy(self.sde.noise_schedule.h(tb), xg, beta)
+        model_energy = self.sde.energy_net.forward_energy(self.sde.noise_schedule.h(tb), xg, beta,
+                                                          pin=bool(getattr(self.sde, "pin_energy", False)),
+                                                          energy_function=energy_function, t=tb)  # :166-173
         a_next = energy_function(xg) + model_energy * _scalar(gamma_schedule.gamma(t_end))
         if a is not None:
             a_next = a_next + comm.all_gather(a)

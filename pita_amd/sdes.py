@@ -86,7 +86,9 @@ class VEReverseSDE:
         self.energy_net, self.score_net = energy_net, score_net
         self.pin_energy = pin_energy
         self.debias_inference = debias_inference
-        self.compiled_divergence_fn = cdf  # accepted for interface compatibility (unused: next tier)
+        # accepted for interface compatibility and ignored: the exact divergence comes from the backbone's own
+        # multi-direction kernel (EGNN_dynamics.jacobian_trace), not from a torch.compile'd vmap(jacrev) closure
+        self.compiled_divergence_fn = cdf
         self.trainer = None  # set from outside by the reference (energytemp_module.py:1295)
 
     def g(self, t):
@@ -110,7 +112,7 @@ class VEReverseSDE:
             gamma_energy = gamma_energy.to(x.device)
         if not self.debias_inference:
             return self.f_not_debiased(t, x, beta, gamma_energy)
-        return self.f_debiased(t, x, beta, gamma_energy, gamma_energy_schedule, clamp_chunk)
+        return self.f_debiased(t, x, beta, gamma_energy, gamma_energy_schedule, clamp_chunk, energy_function)
 
     # ------------------------------------------------------------------ debiased regime (sdes.py:151-239)
     def _denoiser_jacobian_terms(self, model, ht, x, beta, want_h_direction):
@@ -155,12 +157,22 @@ class VEReverseSDE:
         trace, D_S = model.jacobian_trace(ht, x, beta, want_denoiser=True)
         return D_S, trace
 
-    def f_debiased(self, t, x, beta, gamma_energy, gamma_energy_schedule, clamp_chunk=None):
+    def _dh_dt(self, t):
+        """dh/dt per walker: the schedule's own ``dh_dt`` when it has one, else autograd through ``h`` like the
+        reference (sdes.py:218 differentiates U_t through h(t)); never assumed equal to g(t)^2."""
+        sched = self.noise_schedule
+        if hasattr(sched, "dh_dt"):
+            return sched.dh_dt(t)
+        with torch.enable_grad():
+            tt = t.detach().clone().requires_grad_(True)
+            return torch.autograd.grad(sched.h(tt).sum(), tt)[0]
+
+    def f_debiased(self, t, x, beta, gamma_energy, gamma_energy_schedule, clamp_chunk=None, energy_function=None):
         assert self.energy_net is not None
-        if self.pin_energy or getattr(self.energy_net, "precondition_beta", False) or (
-                self.score_net is not None and getattr(self.score_net, "precondition_beta", False)):
-            raise NotImplementedError("debiased HIP path: pin_energy / precondition_beta are not built")
         if self.score_net is None:
+            # sdes.py:204-216 (Laplacian of E_theta by vmap(hessian)).  Unreachable in the reference as shipped: its
+            # constructor dereferences score_net.forward when cdf is None (:111-112) and energyTempModule always passes
+            # a score net (energytemp_module.py:124-131); needs second-order derivatives of the backbone.
             raise NotImplementedError("debiased HIP path without a score net (Laplacian of E_theta) is not built")
         from . import _lib
 
@@ -168,6 +180,25 @@ class VEReverseSDE:
         B, D = x.shape
         ht = _lib.dev_tensor(self.noise_schedule.h(t), "h(t)").contiguous()
         g2 = _lib.dev_tensor(self.g(t).pow(2), "g(t)^2").contiguous()
+        dhdt = _lib.dev_tensor(self._dh_dt(t), "dh/dt").contiguous()
+        pb_e = bool(getattr(self.energy_net, "precondition_beta", False))
+        pb_s = bool(getattr(self.score_net, "precondition_beta", False))
+        beta_b = None
+        if pb_e or pb_s:
+            from .score_net import _Preconditioned
+
+            beta_b = _Preconditioned._batch(beta, B, x.device)
+        pin_w = pin_dw = 0.0
+        logp_t = None
+        if self.pin_energy:  # energy_net.py:43-48; t is the integrator's scalar step time repeated per walker
+            if energy_function is None:
+                raise ValueError("pin_energy=True needs the target energy_function")
+            tv = t.reshape(-1)
+            if bool((tv != tv[0]).any()):
+                raise NotImplementedError("pin_energy with per-walker times")
+            one_minus = 1 - tv[0].to(torch.float32).cpu()
+            pin_w, pin_dw = float(one_minus**3), float(-3 * one_minus**2)
+            logp_t = _lib.dev_tensor(energy_function(x), "energy_function(x)").contiguous()
         gamma = float(gamma_energy.reshape(-1)[0]) if isinstance(gamma_energy, torch.Tensor) else float(gamma_energy)
         dg = gamma_energy_schedule.dgamma_dt(t)
         dgamma = float(dg.reshape(-1)[0]) if isinstance(dg, torch.Tensor) else float(dg)
@@ -176,10 +207,11 @@ class VEReverseSDE:
         drift_X = torch.empty_like(x)
         drift_A, div_bt, cross, dUdt, Ut = (torch.empty(B, device=x.device) for _ in range(5))
         _lib.check(_lib.lib().pita_fk_assemble(
-            x.data_ptr(), ht.data_ptr(), g2.data_ptr(), D_E.data_ptr(), jtx_E.data_ptr(), dot_h.data_ptr(),
-            D_S.data_ptr(), trace_S.data_ptr(), gamma, dgamma, drift_X.data_ptr(), drift_A.data_ptr(),
-            div_bt.data_ptr(), cross.data_ptr(), dUdt.data_ptr(), Ut.data_ptr(), B, D, _lib.stream_ptr(x.device)),
-            "pita_fk_assemble")
+            x.data_ptr(), ht.data_ptr(), g2.data_ptr(), dhdt.data_ptr(), D_E.data_ptr(), jtx_E.data_ptr(),
+            dot_h.data_ptr(), D_S.data_ptr(), trace_S.data_ptr(), gamma, dgamma,
+            _lib.ptr(beta_b if pb_e else None), _lib.ptr(beta_b if pb_s else None), pin_w, pin_dw, _lib.ptr(logp_t),
+            drift_X.data_ptr(), drift_A.data_ptr(), div_bt.data_ptr(), cross.data_ptr(), dUdt.data_ptr(), Ut.data_ptr(),
+            B, D, _lib.stream_ptr(x.device)), "pita_fk_assemble")
         # 0.9-quantile clamp of the weight drift over this inference chunk (sdes.py:230), K11
         _lib.check(_lib.lib().pita_quantile_clamp(drift_A.data_ptr(), B, int(clamp_chunk or B), 0.9,
                                                   _lib.stream_ptr(x.device)), "pita_quantile_clamp")

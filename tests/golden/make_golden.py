@@ -426,6 +426,47 @@ def gen_traj_debias_end():
          drift_A=np.stack([t.drift_A.reshape(B).detach().numpy() for t in terms]))
 
 
+def gen_debias_variants():
+    """Debiased drift terms of VEReverseSDE.f (sdes.py:151-239) in the configurations the experiment files do not
+    exercise: pin_energy=True (energy_net.py:43-48: the energy is blended with the clamped target energy, which the
+    reference's energy classes return DETACHED, so only log p(x) -- not its force -- enters) and precondition_beta=True on
+    both nets (score_net.py:36-38, energy_net.py:40-41), with a Linear annealing schedule (d gamma/dt != 0) and a
+    Geometric noise schedule for one case (g^2 = dh/dt holds for it too; checks that dh/dt is not hard-wired to the
+    Elucidating form)."""
+    import copy
+
+    wt = dict(np.load(os.path.join(HERE, "egnn_weights_trainedlike.npz")))
+    e = LJ(39, 13, 3, data_path="", temperature=1.0)
+    gen = torch.Generator().manual_seed(4242)
+    B = 10
+    # near-physical clusters so that log p_target is inside the +-1e3 clamp for most walkers and outside for some
+    x = lattice_cluster(13, 3, B, gen, spacing=1.12, jitter=0.05)
+    x[7:] = x[7:] * 0.55  # compressed: LJ energy > 1e3 -> clamp active
+    x = data_utils.remove_mean(x, 13, 3)
+    out = dict(x=x.numpy())
+    gam = annealing_factor_schedules.LinearAnnealingFactorSchedule(annealing_factor=1.5, annealing_factor_start=1.0)
+    for name, pin, pb, sched in (
+            ("pin", True, False, noise_schedules.ElucidatingNoiseSchedule(sigma_min=0.05, sigma_max=80.0, rho=7)),
+            ("pb", False, True, noise_schedules.ElucidatingNoiseSchedule(sigma_min=0.05, sigma_max=80.0, rho=7)),
+            ("pinpb_geo", True, True, noise_schedules.GeometricNoiseSchedule(sigma_min=0.05, sigma_max=20.0))):
+        net = make_egnn(13, 3)
+        net.load_state_dict({k: torch.tensor(v) for k, v in wt.items()})
+        sn = score_net.ScoreNet(net, precondition_beta=pb)
+        en = energy_net.EnergyNet(copy.deepcopy(net), precondition_beta=pb)
+        sde = sdes.VEReverseSDE(noise_schedule=sched, energy_net=en, score_net=sn,
+                                cdf=partial(utils.compute_divergence_exact, sn.forward), pin_energy=pin,
+                                debias_inference=True)
+        sde.trainer = FakeTrainer()
+        for ti, tv in enumerate((0.2, 0.7)):
+            terms = sde.f(torch.tensor(tv), x.clone(), 1.25, gam, None, e, resampling_interval=1)
+            for nm in ("drift_X", "drift_A", "divergence_score", "cross_term", "dUt_dt"):
+                out[f"{name}_t{ti}_{nm}"] = getattr(terms, nm).detach().numpy()
+        out[f"{name}_logp"] = e(x.clone()).numpy()
+    out["t"] = np.asarray([0.2, 0.7], dtype=F32)
+    out["beta"] = np.float32(1.25)
+    save("debias_variants_lj13.npz", **out)
+
+
 def gen_post():
     """negative-time descent + MALA on the LJ13 target (sde_integration.py:353-470)."""
     e_raw = LJ(39, 13, 3, data_path="", temperature=1.0)
@@ -507,6 +548,6 @@ def gen_traj_gmm():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["schedules", "lj", "gmm", "egnn", "mlp", "prior", "resample", "traj_nodebias",
-                             "traj_debias", "traj_debias_end", "post", "traj_gmm"]
+                             "traj_debias", "traj_debias_end", "debias_variants", "post", "traj_gmm"]
     for w in which:
         globals()["gen_" + w]()

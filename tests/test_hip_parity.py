@@ -947,6 +947,41 @@ class _Foreign(torch.nn.Module):
         return self.net.forward(t, x, beta)
 
 
+@pytest.mark.parametrize("name,pin,pb,sch", [("pin", True, False, "elucidating"), ("pb", False, True, "elucidating"),
+                                             ("pinpb_geo", True, True, "geometric")])
+def test_debiased_variants_golden(pa, golden, name, pin, pb, sch):
+    """pin_energy (the target log-density enters the drift terms every step, energy_net.py:43-48), precondition_beta on
+    both nets, dh/dt from the schedule (Geometric), d gamma/dt != 0 (Linear annealing): VEReverseSDE.f on the HIP path
+    against the reference's own output (debias_variants_lj13.npz)."""
+    import copy
+
+    from pita_amd.energy_net import EnergyNet
+
+    g = golden("debias_variants_lj13.npz")
+    w = golden("egnn_weights_trainedlike.npz")
+    net = make_net(pa, 13, 3, w)
+    sched = (pa.ElucidatingNoiseSchedule(sigma_min=0.05, sigma_max=80.0, rho=7) if sch == "elucidating"
+             else pa.GeometricNoiseSchedule(sigma_min=0.05, sigma_max=20.0))
+    sde = pa.VEReverseSDE(noise_schedule=sched, score_net=pa.ScoreNet(net, precondition_beta=pb),
+                          energy_net=EnergyNet(copy.deepcopy(net), precondition_beta=pb), pin_energy=pin,
+                          debias_inference=True)
+    gam = pa.LinearAnnealingFactorSchedule(annealing_factor=1.5, annealing_factor_start=1.0)
+    e = pa.LennardJonesEnergy(39, 13, 3)
+    x, beta = cu(g["x"]), float(g["beta"])
+    np.testing.assert_allclose(e(x).cpu().numpy(), g["pin_logp"], rtol=2e-5)
+    for ti, tv in enumerate(g["t"]):
+        terms = sde.f(torch.tensor(float(tv)).cuda(), x, beta, gam, None, e, resampling_interval=1)
+        key = f"{name}_t{ti}_"
+        assert rel(terms.drift_X, g[key + "drift_X"]) < 3e-4, key
+        for nm in ("drift_A", "divergence_score", "cross_term", "dUt_dt"):
+            ref = g[key + nm]
+            np.testing.assert_allclose(getattr(terms, nm).cpu().numpy(), ref, rtol=3e-3, atol=3e-3 * np.abs(ref).max(),
+                                       err_msg=key + nm)
+    if pin:
+        with pytest.raises(ValueError):
+            sde.f(torch.tensor(0.5).cuda(), x, beta, gam, None, None)  # pinning needs the target
+
+
 def test_debiased_resample_at_end_golden(pa, golden):
     """experiment/lj13.yaml settings: inference chunks of 6 (per-chunk quantile clamp inside one set of launches) and
     resample_at_end=True (sde_integration.py:158-183), against the reference run em_traj_lj13_debias_end.npz."""

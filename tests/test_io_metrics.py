@@ -34,6 +34,37 @@ def test_checkpoint_mapping_raw_and_ema():
     assert torch.equal(next(sn.model.parameters()), next(src_s.parameters())) and rep2["ema"] == []
 
 
+def test_checkpoint_layouts_without_ema_and_empty_checkpoint():
+    """ema_decay = 0 checkpoints (energytemp_module.py:107-109: nets not wrapped) and the module-level h_theta copy are
+    recognised; a checkpoint without a single backbone tensor raises instead of leaving random weights in place."""
+    import pytest
+
+    import pita_amd
+    from pita_amd import io
+    from pita_amd.energy_net import EnergyNet
+
+    mk = lambda: pita_amd.EGNN_dynamics(13, 3, hidden_nf=32, n_layers=3, tanh=True, attention=True,
+                                        condition_temperature=True)
+    torch.manual_seed(3)
+    src_s, src_e = mk(), mk()
+    plain = {"score_net.model." + k: v.clone() for k, v in src_s.state_dict().items()}
+    plain.update({"energy_net.net." + k: v.clone() for k, v in src_e.state_dict().items()})
+    plain.update({"h_theta." + k: v.clone() for k, v in src_s.state_dict().items()})
+    torch.manual_seed(4)
+    sn, en = pita_amd.ScoreNet(mk()), EnergyNet(mk())
+    rep = io.load_reference_checkpoint({"state_dict": plain}, sn, en, use_ema=True)
+    assert rep["layout"] == ["score_net.model", "energy_net.net"] and rep["ema"] == []
+    for (k, p), q in zip(sn.model.state_dict().items(), src_s.state_dict().values()):
+        assert torch.equal(p, q), k
+    for (k, p), q in zip(en.net.state_dict().items(), src_e.state_dict().values()):
+        assert torch.equal(p, q), k
+    only_h = {"h_theta." + k: v.clone() for k, v in src_e.state_dict().items()}
+    rep = io.load_reference_checkpoint(only_h, sn, None, use_ema=False)
+    assert rep["layout"] == ["h_theta"] and torch.equal(next(sn.model.parameters()), next(src_e.parameters()))
+    with pytest.raises(KeyError):
+        io.load_reference_checkpoint({"state_dict": {"optimizer.foo": torch.zeros(1)}}, sn, en)
+
+
 def test_w2_matches_oracle():
     from pita_amd import metrics
 

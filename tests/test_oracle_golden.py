@@ -200,6 +200,30 @@ def test_traj_debias(golden):
     np.testing.assert_allclose(terms.divergence_score.numpy(), g["divergence_score"][0], rtol=2e-3, atol=1e-2)
 
 
+VARIANTS = (("pin", True, False, "elucidating"), ("pb", False, True, "elucidating"), ("pinpb_geo", True, True, "geometric"))
+
+
+def test_debias_variants(golden):
+    """pin_energy / precondition_beta / a Geometric schedule / a Linear annealing schedule in the debiased drift
+    (debias_variants_lj13.npz: VEReverseSDE.f of the reference itself)."""
+    g = golden("debias_variants_lj13.npz")
+    bb = _lj13_backbone(golden)
+    x, beta = T(g["x"]), float(g["beta"])
+    gam = O.GammaLinear(annealing_factor=1.5, annealing_factor_start=1.0)
+    np.testing.assert_allclose(O.lj_logp(x, 13, 3).numpy(), g["pin_logp"], rtol=2e-5)
+    for name, pin, pb, sch in VARIANTS:
+        sched = O.Elucidating(0.05, 80.0, 7) if sch == "elucidating" else O.Geometric(0.05, 20.0)
+        for ti, tv in enumerate(g["t"]):
+            terms = O.f_debiased(bb, bb, sched, gam, torch.tensor(float(tv)), x, beta, pin_energy=pin,
+                                 target_logp=lambda xx: O.lj_logp(xx, 13, 3), precondition_beta=pb)
+            key = f"{name}_t{ti}_"
+            assert rel(terms.drift_X.numpy(), g[key + "drift_X"]) < 2e-4, key
+            for nm in ("drift_A", "divergence_score", "cross_term", "dUt_dt"):
+                ref = g[key + nm]
+                np.testing.assert_allclose(getattr(terms, nm).numpy(), ref, rtol=3e-3, atol=3e-3 * np.abs(ref).max(),
+                                           err_msg=key + nm)
+
+
 def test_traj_debias_resample_at_end(golden):
     """The LJ13 experiment's settings: two inference chunks per step (per-chunk clamp) and resample_at_end."""
     g = golden("em_traj_lj13_debias_end.npz")
