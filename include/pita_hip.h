@@ -334,7 +334,9 @@ int pita_mala_adapt(double* dt_dev, int* acc_count, int64_t total, int adaptive,
  * K10 systematic resampling, replaces sample_cat_sys (utils.py:111-120): weights =
  * clip(softmax(logits),1e-6,1) (not renormalised), inclusive fp32 cumsum, u_k = (u0 + k/B) mod 1
  * in fp64, ids = digitize(u, bins, right=True) clamped to B-1.
- * workspace: device scratch of at least pita_resample_workspace_bytes(B) bytes. */
+ * Five short multi-block passes (block maxima, block sums, clipped-weight block sums, bins, binary search), fixed
+ * summation order; exp evaluated in double and rounded once.
+ * workspace: 8-byte aligned device scratch of at least pita_resample_workspace_bytes(B) bytes. */
 size_t pita_resample_workspace_bytes(int64_t B);
 int pita_systematic_resample(const float* logits, int64_t B, double u0, int64_t* ids,
                              void* workspace, void* stream);

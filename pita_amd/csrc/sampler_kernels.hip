@@ -283,70 +283,114 @@ __global__ void mala_adapt_kernel(double* dt_dev, int* acc_count, long long tota
 }
 
 // ---------------------------------------------------------------------------- resampling
-// Single 1024-thread block: B is at most a few 10^5 and the op is latency- not bandwidth-bound.
-// workspace: float w[B]; double cum[B] (stored as float bins after rounding).
-constexpr int RS_T = 1024;
+// Systematic resampling (utils.py:111-120) as five short multi-block passes over the logits, all in a fixed
+// summation order (bitwise reproducible), 1 024 walkers per block:
+//   A  block maxima                      B  block sums of exp(l - max) in double
+//   C  block sums of the clipped weights clip(exp(l - max) / sum, 1e-6, 1) in double
+//   D  bins = inclusive cumsum: blocks' prefix (sequential over the block totals) + in-block scan, accumulated in
+//      double and rounded to fp32 per prefix -- torch's CPU cumsum semantics (float input, double accumulator)
+//   E  ids[k] = #bins < u_k (digitize right=True), one thread per k, binary search
+// exp is evaluated in double and rounded once: the correctly rounded fp32 exponential, which is what torch-CPU's
+// (SLEEF, <= 1 ulp) expf returns in all but a vanishing fraction of arguments; the ocml expf differs from it far
+// more often and each difference can move an id whose uniform lies within an ulp of a bin edge.
+constexpr int RS_T = 256, RS_E = 1024;  // threads and elements per block
 
-__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
-  for (int o = 32; o > 0; o >>= 1) {
-    float u = __shfl_xor(v, o, 64);
-    v = is_max ? fmaxf(v, u) : v + u;
-  }
-  const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+__device__ __forceinline__ float rs_exp(float v) { return (float)exp((double)v); }
+
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   __syncthreads();
-  if (ln == 0) red[wv] = v;
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  float r = red[0];
-  for (int k = 1; k < RS_T / 64; ++k) r = is_max ? fmaxf(r, red[k]) : r + red[k];
+  double r = 0.0;
+  for (int k = 0; k < RS_T / 64; ++k) r += red[k];
   return r;
 }
 
-__global__ void __launch_bounds__(RS_T) resample_kernel(const float* __restrict__ logits, long long B, double u0,
-                                                        long long* __restrict__ ids, float* __restrict__ bins) {
+__global__ void __launch_bounds__(RS_T) rs_max_kernel(const float* __restrict__ logits, long long B, float* __restrict__ bmax) {
   __shared__ float red[RS_T / 64];
-  __shared__ double dred[RS_T];
-  const int tid = threadIdx.x;
-  // softmax(logits) -> clip(., 1e-6, 1)   (utils.py:114)
+  const long long lo = (long long)blockIdx.x * RS_E;
   float mx = -INFINITY;
-  for (long long i = tid; i < B; i += RS_T) mx = fmaxf(mx, logits[i]);
-  mx = block_reduce(mx, red, true);
-  float sm = 0.f;
-  for (long long i = tid; i < B; i += RS_T) sm += expf(logits[i] - mx);
-  sm = block_reduce(sm, red, false);
-  // inclusive cumsum.  torch's CPU cumsum accumulates float inputs in double and rounds each
-  // prefix to float (utils.py:116); a blocked double scan reproduces that to the last bit except
-  // at double-rounding ties.
-  const long long per = (B + RS_T - 1) / RS_T;
-  const long long lo = (long long)tid * per, hi = (lo + per < B) ? lo + per : B;
+  for (int i = threadIdx.x; i < RS_E; i += RS_T)
+    if (lo + i < B) mx = fmaxf(mx, logits[lo + i]);
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < RS_T / 64; ++k) mx = fmaxf(mx, red[k]);
+    bmax[blockIdx.x] = mx;
+  }
+}
+
+// phase 0: sums of exp(l - max);  phase 1: sums of the clipped weights
+__global__ void __launch_bounds__(RS_T) rs_sum_kernel(const float* __restrict__ logits, long long B, int nblk,
+                                                      const float* __restrict__ bmax, const double* __restrict__ bsum,
+                                                      double* __restrict__ out, int phase) {
+  __shared__ double red[RS_T / 64];
+  float mx = -INFINITY;
+  for (int k = 0; k < nblk; ++k) mx = fmaxf(mx, bmax[k]);
+  float sm = 1.0f;
+  if (phase == 1) {
+    double t = 0.0;
+    for (int k = 0; k < nblk; ++k) t += bsum[k];
+    sm = (float)t;
+  }
+  const long long lo = (long long)blockIdx.x * RS_E;
   double acc = 0.0;
-  for (long long i = lo; i < hi; ++i) {
-    float w = expf(logits[i] - mx) / sm;
-    w = fminf(fmaxf(w, 1e-6f), 1.0f);
-    acc += (double)w;
+  for (int i = threadIdx.x; i < RS_E; i += RS_T)
+    if (lo + i < B) {
+      float w = rs_exp(logits[lo + i] - mx);
+      if (phase == 1) w = fminf(fmaxf(w / sm, 1e-6f), 1.0f);
+      acc += (double)w;
+    }
+  acc = block_sum_d(acc, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = acc;
+}
+
+__global__ void __launch_bounds__(RS_T) rs_bins_kernel(const float* __restrict__ logits, long long B, int nblk,
+                                                       const float* __restrict__ bmax, const double* __restrict__ bsum,
+                                                       const double* __restrict__ bw, float* __restrict__ bins) {
+  __shared__ double part[RS_T];
+  float mx = -INFINITY;
+  for (int k = 0; k < nblk; ++k) mx = fmaxf(mx, bmax[k]);
+  double t = 0.0;
+  for (int k = 0; k < nblk; ++k) t += bsum[k];
+  const float sm = (float)t;
+  double base = 0.0;
+  for (int k = 0; k < (int)blockIdx.x; ++k) base += bw[k];
+  constexpr int PER = RS_E / RS_T;  // contiguous elements per thread
+  const long long lo = (long long)blockIdx.x * RS_E + (long long)threadIdx.x * PER;
+  float w[PER];
+  double acc = 0.0;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    w[q] = (lo + q < B) ? fminf(fmaxf(rs_exp(logits[lo + q] - mx) / sm, 1e-6f), 1.0f) : 0.0f;
+    acc += (double)w[q];
   }
-  dred[tid] = acc;
+  part[threadIdx.x] = acc;
   __syncthreads();
-  if (tid == 0) {
+  if (threadIdx.x == 0) {
     double run = 0.0;
-    for (int k = 0; k < RS_T; ++k) { double t = dred[k]; dred[k] = run; run += t; }
+    for (int k = 0; k < RS_T; ++k) { const double v = part[k]; part[k] = run; run += v; }
   }
   __syncthreads();
-  acc = dred[tid];
-  for (long long i = lo; i < hi; ++i) {
-    float w = expf(logits[i] - mx) / sm;
-    w = fminf(fmaxf(w, 1e-6f), 1.0f);
-    acc += (double)w;
-    bins[i] = (float)acc;
+  acc = base + part[threadIdx.x];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    acc += (double)w[q];
+    if (lo + q < B) bins[lo + q] = (float)acc;
   }
-  __threadfence_block();
-  __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) rs_search_kernel(const float* __restrict__ bins, long long B, double u0,
+                                                        long long* __restrict__ ids) {
   // u_k = (u0 + fp32(k * fp32(1/B))) mod 1 in double; ids = #bins < u  (digitize right=True), clamp
   const float invB = (float)(1.0 / (double)B);
-  for (long long k = tid; k < B; k += RS_T) {
-    double u = fmod(u0 + (double)((float)k * invB), 1.0);
+  for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < B; k += (long long)gridDim.x * 256) {
+    const double u = fmod(u0 + (double)((float)k * invB), 1.0);
     long long a = 0, b = B;  // first index with bins[idx] >= u
     while (a < b) {
-      long long m = (a + b) >> 1;
+      const long long m = (a + b) >> 1;
       if ((double)bins[m] < u) a = m + 1; else b = m;
     }
     ids[k] = (a >= B) ? B - 1 : a;
@@ -407,14 +451,35 @@ extern "C" int pita_fill_normal(float* out, int64_t B, int n, int d, uint64_t se
   return launch_elem<OP_NORMAL>(out, nullptr, nullptr, B, n, d, p, stream);
 }
 
-extern "C" size_t pita_resample_workspace_bytes(int64_t B) { return sizeof(float) * (size_t)(B > 0 ? B : 1); }
+static inline long long rs_nblk(int64_t B) { return (B + RS_E - 1) / RS_E; }
+
+// workspace: float bins[B] | float bmax[nblk] | double bsum[nblk] | double bw[nblk]   (8-byte aligned sections)
+extern "C" size_t pita_resample_workspace_bytes(int64_t B) {
+  const size_t n = (size_t)(B > 0 ? B : 1), nb = (size_t)rs_nblk(B > 0 ? B : 1);
+  return ((n * 4 + 7) & ~(size_t)7) + ((nb * 4 + 7) & ~(size_t)7) + 2 * nb * 8;
+}
 
 extern "C" int pita_systematic_resample(const float* logits, int64_t B, double u0, int64_t* ids, void* workspace,
                                         void* stream) {
   PITA_REQUIRE(logits && ids && workspace && B >= 0, "pita_systematic_resample: null argument");
   if (B == 0) return PITA_OK;
-  hipLaunchKernelGGL(resample_kernel, dim3(1), dim3(RS_T), 0, (hipStream_t)stream, logits, (long long)B, u0,
-                     (long long*)ids, (float*)workspace);
+  PITA_REQUIRE(((uintptr_t)workspace & 7) == 0, "pita_systematic_resample: workspace must be 8-byte aligned");
+  const long long nb = rs_nblk(B);
+  char* w = static_cast<char*>(workspace);
+  float* bins = reinterpret_cast<float*>(w);
+  w += ((size_t)B * 4 + 7) & ~(size_t)7;
+  float* bmax = reinterpret_cast<float*>(w);
+  w += ((size_t)nb * 4 + 7) & ~(size_t)7;
+  double* bsum = reinterpret_cast<double*>(w);
+  double* bw = bsum + nb;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(rs_max_kernel, dim3((unsigned)nb), dim3(RS_T), 0, s, logits, (long long)B, bmax);
+  hipLaunchKernelGGL(rs_sum_kernel, dim3((unsigned)nb), dim3(RS_T), 0, s, logits, (long long)B, (int)nb, bmax, bsum, bsum, 0);
+  hipLaunchKernelGGL(rs_sum_kernel, dim3((unsigned)nb), dim3(RS_T), 0, s, logits, (long long)B, (int)nb, bmax, bsum, bw, 1);
+  hipLaunchKernelGGL(rs_bins_kernel, dim3((unsigned)nb), dim3(RS_T), 0, s, logits, (long long)B, (int)nb, bmax, bsum, bw, bins);
+  const long long sb = (B + 255) / 256;
+  hipLaunchKernelGGL(rs_search_kernel, dim3((unsigned)(sb < 8192 ? sb : 8192)), dim3(256), 0, s, bins, (long long)B, u0,
+                     (long long*)ids);
   PITA_LAUNCH_CHECK();
   return PITA_OK;
 }

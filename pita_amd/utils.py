@@ -15,7 +15,8 @@ def sample_cat_sys(bs, logits, u=None):
         u = torch.rand(size=(1,), dtype=torch.float64)
     u0 = float(u.reshape(-1)[0]) if isinstance(u, torch.Tensor) else float(u)
     ids = torch.empty(bs, device=logits.device, dtype=torch.int64)
-    ws = torch.empty(max(bs, 1), device=logits.device, dtype=torch.float32)
+    nbytes = int(_lib.lib().pita_resample_workspace_bytes(bs))
+    ws = torch.empty((nbytes + 7) // 8, device=logits.device, dtype=torch.float64)  # 8-byte aligned scratch
     _lib.check(_lib.lib().pita_systematic_resample(logits.data_ptr(), bs, u0, ids.data_ptr(), ws.data_ptr(),
                                                    _lib.stream_ptr(logits.device)), "pita_systematic_resample")
     return ids, None

@@ -433,11 +433,53 @@ def test_resample_golden(pa, golden, case):
     ids = ids.cpu().numpy()
     want = g[f"ids_{case}"]
     bad = ids != want
-    assert bad.mean() < 5e-3 and (np.abs(ids[bad] - want[bad]) <= 1).all(), (bad.sum(), len(ids))
+    print(f"[resample/{case}] {int(bad.sum())} of {len(ids)} ids differ from the reference's")
+    # index work is exact except where a uniform lies within fp32 rounding of a bin edge: the reference's softmax sums
+    # its exponentials in the vector-lane order of the host CPU, which no other summation reproduces bit for bit
+    assert bad.sum() <= max(2, len(ids) // 2000) and (np.abs(ids[bad] - want[bad]) <= 1).all(), (bad.sum(), len(ids))
     assert (np.diff(ids) >= 0).sum() >= len(ids) - 2  # sorted up to the single wrap of (u0 + k/B) mod 1
     x = torch.arange(logits.shape[0] * 3, dtype=torch.float32, device="cuda").reshape(-1, 3)
     got = pa.utils.gather_rows(x, torch.as_tensor(want).cuda())
     assert torch.equal(got, x[torch.as_tensor(want).cuda()])
+
+
+def test_resample_global_batch_of_config_c5(pa):
+    """262 144 walkers (config C5's global batch): ids against the oracle, sortedness, every id a valid walker; the
+    multi-block passes are timed (printed) so the cost of a global resampling event is on record."""
+    B = 262144
+    gen = torch.Generator().manual_seed(9)
+    logits = torch.randn(B, generator=gen)
+    u0 = 0.7312345678901234
+    want = O.sample_cat_sys(logits, u0)
+    lg = logits.cuda()
+    ids, _ = pa.utils.sample_cat_sys(B, lg, u=u0)
+    got = ids.cpu().numpy()
+    bad = got != want
+    print(f"[resample/C5] {int(bad.sum())} of {B} ids differ from the fp32 oracle's (all by one)")
+    # At this size the reference's own fp32 softmax denominator (a vector-lane sum of 262 144 terms) is off by ~1e-7
+    # relative, a few percent of one walker's weight by the end of the cumulative sum: ids shift by one for ~10 % of
+    # the walkers, depending on the host CPU's lane count.  Exactness is therefore checked against the same arithmetic
+    # carried out with exact (double) sums -- which the kernel must reproduce bit for bit -- and the fp32 oracle
+    # bounds the deviation: never more than one position.
+    assert (np.abs(got - want) <= 1).all()
+    l64 = logits.numpy().astype(np.float32)
+    e = np.exp((l64 - l64.max()).astype(np.float64)).astype(np.float32)
+    sm = np.float32(e.astype(np.float64).sum())
+    w = np.clip(e / sm, np.float32(1e-6), np.float32(1.0)).astype(np.float32)
+    bins = np.cumsum(w.astype(np.float64)).astype(np.float32)
+    u = (u0 + (np.arange(B, dtype=np.float32) * np.float32(1.0 / B)).astype(np.float64)) % 1.0
+    exact = np.minimum(np.searchsorted(bins.astype(np.float64), u, side="left"), B - 1)
+    nbad = int((got != exact).sum())
+    print(f"[resample/C5] {nbad} of {B} ids differ from the double-sum restatement")
+    assert nbad <= 2
+    assert got.min() >= 0 and got.max() < B and (np.diff(got) >= 0).sum() >= B - 2
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        pa.utils.sample_cat_sys(B, lg, u=u0)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"[resample/C5] {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per global resampling event at {B} walkers")
 
 
 def test_post_processing_golden(pa, golden):
@@ -1096,10 +1138,88 @@ def test_final_histograms_match_oracle_sampler(pa, golden):
     x, _, _, _, _ = integ.integrate_sde(x1, pa.LennardJonesEnergy(39, 13, 3), pa.ConstantAnnealingFactorSchedule(4 / 3),
                                         inverse_temperature=1.0)
     got = stats(x)
+    from pita_amd import metrics
+
     for k, name in enumerate(("interatomic distance", "log10 energy")):
         seed_to_seed = O.w2_1d(ref[0][k], ref[1][k])
-        hip_to_ref = max(O.w2_1d(got[k], ref[0][k]), O.w2_1d(got[k], ref[1][k]))
+        # the product's own metric (pita_amd.metrics, device sort) measures the HIP run; the oracle's W2 checks it
+        w2 = lambda a, b: np.sqrt(metrics._w_1d(torch.as_tensor(a).cuda(), torch.as_tensor(b).cuda(), 2))
+        assert abs(w2(got[k], ref[0][k]) - O.w2_1d(got[k], ref[0][k])) < 1e-6 * (1 + seed_to_seed)
+        hip_to_ref = max(w2(got[k], ref[0][k]), w2(got[k], ref[1][k]))
         assert hip_to_ref < 4 * seed_to_seed + 1e-3 * float(np.abs(ref[0][k]).mean()), (name, hip_to_ref, seed_to_seed)
+
+
+def test_checkpoint_to_samples_to_metrics_round_trip(pa, golden, tmp_path):
+    """Edges of the path on real artefact layouts: a Lightning-layout checkpoint with raw and EMA
+    shadow parameters (energytemp_module.py:94-111, ema.py:6-80) -> io.load_reference_checkpoint -> HIP sampler ->
+    samples_temperature_*.pt (:1040-1041) -> reload -> energy W1/W2 and interatomic-distance W2 (:1157-1191,
+    distribution_distances.py:13-33) on HIP energies, checked against the oracle's sorted-sample W2."""
+    import copy
+
+    from pita_amd import io, metrics
+    from pita_amd.energy_net import EnergyNet
+
+    w_raw = golden("egnn_weights_seed12345.npz")       # "raw" training weights
+    w_ema = golden("egnn_weights_trainedlike.npz")     # what the EMA shadow holds
+    src = make_net(pa, 13, 3, w_raw)
+    names = [n for n, p_ in src.named_parameters() if p_.requires_grad]
+    state = {"score_net.model.model." + k: T(v) for k, v in w_raw.items()}
+    state.update({"energy_net.model.net." + k: T(v) for k, v in w_raw.items()})
+    for pre in ("score_net", "energy_net"):
+        state.update({f"{pre}.shadow_params.{i}": T(w_ema[n]) for i, n in enumerate(names)})
+        state[f"{pre}.num_updates"] = torch.tensor(1234)
+    state["h_theta." + next(iter(w_raw))] = T(next(iter(w_raw.values())))
+    ckpt = tmp_path / "last.ckpt"
+    torch.save({"state_dict": state, "epoch": 3, "hyper_parameters": {"ema_decay": 0.999}}, ckpt)
+
+    torch.manual_seed(99)  # the nets start from unrelated weights: everything must come from the file
+    mk = lambda: pa.EGNN_dynamics(13, 3, hidden_nf=32, n_layers=3, recurrent=True, tanh=True, attention=True,
+                                  condition_time=True, condition_temperature=True, agg="sum")
+    sn, en = pa.ScoreNet(mk()), EnergyNet(mk())
+    rep = io.load_reference_checkpoint(str(ckpt), sn, en, use_ema=True)
+    assert rep["ema"] == ["score_net.shadow_params", "energy_net.shadow_params"] and not rep["missing"]
+    assert rep["layout"] == ["score_net.model.model", "energy_net.model.net"]
+    for k, v in sn.model.state_dict().items():
+        want = w_ema[k] if k in names else w_raw[k]
+        assert np.array_equal(v.cpu().numpy(), want), k
+
+    # sample with the loaded nets; the same run from nets built directly from the EMA weights must agree bitwise
+    sched = pa.ElucidatingNoiseSchedule(sigma_min=0.05, sigma_max=80.0, rho=7)
+    gam = pa.ConstantAnnealingFactorSchedule(4 / 3)
+    e = pa.LennardJonesEnergy(39, 13, 3)
+    N, B = 30, 2048
+    x1 = pa.Prior(scale=80.0 / np.sqrt(4 / 3), n_particles=13, spatial_dim=3, seed=11).sample(B)
+
+    def sample(score_net):
+        sde = pa.VEReverseSDE(noise_schedule=sched, score_net=score_net, energy_net=en, debias_inference=False)
+        integ = pa.WeightedSDEIntegrator(sde=sde, num_integration_steps=N, start_resampling_step=0, end_resampling_step=N,
+                                         resampling_interval=-1, num_negative_time_steps=0, post_mcmc_steps=0, seed=5)
+        return integ.integrate_sde(x1, e, gam, inverse_temperature=1.0)[0]
+
+    xa = sample(sn)
+    direct = make_net(pa, 13, 3, {k: (w_ema[k] if k in names else w_raw[k]) for k in w_raw})
+    assert torch.equal(xa, sample(pa.ScoreNet(direct)))
+    path = tmp_path / "samples_temperature_3.0.pt"
+    io.save_samples(xa, str(path))
+    xb = io.load_samples(str(path))
+    assert xb.is_cuda and torch.equal(xa, xb)
+
+    # metrics against a second sample set (different Philox seed) through the product's functions, oracle W2 as checker
+    x2 = pa.Prior(scale=80.0 / np.sqrt(4 / 3), n_particles=13, spatial_dim=3, seed=12).sample(B)
+    sde = pa.VEReverseSDE(noise_schedule=sched, score_net=sn, energy_net=en, debias_inference=False)
+    xc = pa.WeightedSDEIntegrator(sde=sde, num_integration_steps=N, start_resampling_step=0, end_resampling_step=N,
+                                  resampling_interval=-1, num_negative_time_steps=0, post_mcmc_steps=0,
+                                  seed=6).integrate_sde(x2, e, gam, inverse_temperature=1.0)[0]
+    ea, ec = -e(xb), -e(xc)   # energies (the reference logs -log p)
+    # these untrained-net samples have enormous energies; compare on a monotone transform so W2 is well conditioned
+    la, lc = torch.log10(ea.clamp_min(1.0)), torch.log10(ec.clamp_min(1.0))
+    d = metrics.energy_distances(la, lc, prefix="test")
+    assert abs(d["test/energy_w2"] - O.w2_1d(lc.cpu().numpy(), la.cpu().numpy())) < 1e-9
+    assert d["test/energy_w1"] <= d["test/energy_w2"] + 1e-12 and d["test/num_cropped"] == 0
+    dw2 = metrics.interatomic_w2(e, xb, xc)
+    iu = np.triu_indices(13, 1)
+    dist = lambda x: (x.reshape(-1, 13, 1, 3) - x.reshape(-1, 1, 13, 3)).norm(dim=-1)[:, iu[0], iu[1]].reshape(-1)
+    assert abs(dw2 - O.w2_1d(dist(xc.cpu()).numpy(), dist(xb.cpu()).numpy())) < 1e-5 * (1 + dw2)
 
 
 def test_not_debiased_resample_at_end(pa, golden):
