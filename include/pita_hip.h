@@ -175,9 +175,12 @@ int pita_egnn_jvp(pita_egnn_t* net, const float* h, const float* x, const float*
 /* Reverse-mode derivative of the denoiser:  vjp = J_x D(h, x)^T cot  (and out = D when out != NULL), one launch for
  * all walkers.  cot: device [B, D] or NULL (= x).  With cot = x this is the only derivative grad_x E_theta needs
  * (energy_net.py:33-62: E = (1+c_s)|x|^2/(2h) - <D, x>/h, so grad E = ((1+c_s) x - D - J^T x)/h), replacing the
- * reference's torch.autograd.grad through the network.  Checkpoint scratch is owned by the handle. */
+ * reference's torch.autograd.grad through the network.  Checkpoint scratch is owned by the handle.
+ * dot_h (nullable, device [B]): <cot, dD/dh> from the same reverse sweep (it also reaches the h-dependent inputs of the
+ * backbone -- time feature ln(h)/8, the scaling c_in(h) -- and the explicit c_s(h), c_out(h)): with cot = x this is the
+ * term of dE_theta/dt (sdes.py:218) that otherwise takes a forward-mode launch in the h direction. */
 int pita_egnn_vjp(pita_egnn_t* net, const float* h, const float* x, const float* beta, const float* cot /*nullable*/,
-                  float* out /*nullable*/, float* vjp, int64_t B, void* stream);
+                  float* out /*nullable*/, float* vjp, float* dot_h /*nullable*/, int64_t B, void* stream);
 
 /* Exact trace of the denoiser Jacobian, K unit directions per launch sharing one primal evaluation:
  *   diag_acc[b] += sum_{k < ndir} (J_x D(h, x) e_{dir0+k})_{dir0+k},   1 <= ndir <= pita_egnn_div_directions(net).

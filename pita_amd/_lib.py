@@ -69,7 +69,7 @@ _PROTOS = {
     "pita_egnn_edm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "pita_egnn_jvp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
-    "pita_egnn_vjp": (c_int, [c_void_p] * 7 + [c_int64, c_void_p]),
+    "pita_egnn_vjp": (c_int, [c_void_p] * 8 + [c_int64, c_void_p]),
     "pita_egnn_div_directions": (c_int, [c_void_p]),
     "pita_egnn_div_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                          c_int64, c_void_p]),

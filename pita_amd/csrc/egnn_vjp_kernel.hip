@@ -38,6 +38,8 @@ struct VjpParams {
   const float* cot;   // [B, D] cotangent (null: cot = x)
   float* out;         // [B, D] denoiser D (nullable)
   float* vjp;         // [B, D] J_x D^T cot
+  float* dot_h;       // nullable [B]: <cot, dD/dh> -- the reverse sweep also reaches the inputs that depend on h (time
+                      // feature, c_in scaling) and the explicit c_s(h), c_out(h): no forward-mode launch needed
   float* ws;          // checkpoint scratch: total_waves * ws_f floats
 };
 
@@ -122,7 +124,8 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
     const int ntile = (ncol + 31) >> 5;
     int col[NT], nodei[NT];
     bool valid[NT];
-    float xin[NT][DIM], cot[NT][DIM], c_s[NT], c_in[NT], c_out[NT];
+    float xin[NT][DIM], cot[NT][DIM], c_s[NT], c_in[NT], c_out[NT], hvv[NT], dhacc[NT];
+    bool a0t[NT], a1t[NT];  // which embedding inputs of this node are the time feature (quirk Q1 layout)
     float posi[NT][DIM], p0i[NT][DIM];
     f32x16 hf[NT];
 #pragma unroll
@@ -138,6 +141,8 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
       c_s[T] = 1.0f / op;
       c_in[T] = rs;
       c_out[T] = sqrtf(hv) * rs;
+      hvv[T] = hv;
+      dhacc[T] = 0.f;
       const float tfeat = 0.125f * logf(hv);
 #pragma unroll
       for (int k = 0; k < DIM; ++k) {
@@ -153,11 +158,13 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
         }
       }
       float a0, a1;
-      if (p.in_nf == 1) { a0 = tfeat; a1 = 0.f; }
+      if (p.in_nf == 1) { a0 = tfeat; a1 = 0.f; a0t[T] = true; a1t[T] = false; }
       else if (p.feature_layout == 0) {
-        a0 = (2 * nodei[T] < N) ? tfeat : bet;
-        a1 = (2 * nodei[T] + 1 < N) ? tfeat : bet;
-      } else { a0 = tfeat; a1 = bet; }
+        a0t[T] = 2 * nodei[T] < N;
+        a1t[T] = 2 * nodei[T] + 1 < N;
+        a0 = a0t[T] ? tfeat : bet;
+        a1 = a1t[T] ? tfeat : bet;
+      } else { a0 = tfeat; a1 = bet; a0t[T] = true; a1t[T] = false; }
       const f32x16 w0 = lds_vec16(vemb + hh * 16), w1 = lds_vec16(vemb + 32 + hh * 16), eb = lds_vec16(vemb + 64 + hh * 16);
 #pragma unroll
       for (int r = 0; r < 16; ++r) hf[T][r] = fmaf(w0[r], a0, fmaf(w1[r], a1, eb[r]));
@@ -282,6 +289,13 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
         for (int q = 0; q < N; ++q) { s += scr[(cb + q) * DIM + k]; sc += scr[C::POS_F + (cb + q) * DIM + k]; }
         const float F = (posi[T][k] - p0i[T][k]) - s / (float)N;
         if (p.out && valid[T] && hh == 0) p.out[(walker0 * N + col[T]) * DIM + k] = fmaf(c_s[T], xin[T][k], c_out[T] * F);
+        if (p.dot_h && valid[T] && hh == 0) {  // explicit h-dependence of D = c_s(h) x + c_out(h) F
+          const float op = 1.0f + hvv[T];
+          const float dcs = -c_s[T] * c_s[T];                               // d/dh 1/(1+h)
+          const float dcin = -0.5f * c_in[T] / op;                          // d/dh (1+h)^-1/2
+          const float dcout = 0.5f * c_in[T] / sqrtf(hvv[T]) + sqrtf(hvv[T]) * dcin;
+          dhacc[T] = fmaf(cot[T][k], fmaf(dcs, xin[T][k], dcout * F), dhacc[T]);
+        }
         pb[T][k] = valid[T] ? c_out[T] * (cot[T][k] - sc / (float)N) : 0.f;  // remove_mean is self-adjoint
       }
     }
@@ -358,7 +372,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
           for (int r = 0; r < 16; ++r) { float y, g; silu_grad(zn[r], y, g); znb[r] *= g; }
           wt.load(nullptr, mats16, M_WN1BT, lane);
           aggb = wt.mul(znb, zero16);
-          if (l > 0) {
+          if (l > 0 || p.dot_h) {
             wt.load(nullptr, mats16, M_WN1AT, lane);
             hb[T] = wt.mul(znb, hb[T]);
           }
@@ -432,7 +446,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
           f32x16 z1b = w2t.mul(mb, zero16);
 #pragma unroll
           for (int r = 0; r < 16; ++r) z1b[r] *= g1[r];
-          if (l > 0) {  // h^0 does not depend on x
+          if (l > 0 || p.dot_h) {  // h^0 does not depend on x (but on h, through the time feature)
             S += z1b;
             lds_add16(TB + cj * PBS + hh * 16, z1b);
           }
@@ -451,7 +465,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
             }
           }
         }
-        if (l > 0) {
+        if (l > 0 || p.dot_h) {
           WFrag<1> wt;
           wt.load(nullptr, mats16, M_WAT, lane);
           hb[T] = wt.mul(S, hb[T]);
@@ -462,13 +476,13 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
       wave_lds_fence();  // all scatter contributions of this layer are in LDS
       {
         WFrag<1> wt;
-        if (l > 0) wt.load(nullptr, mats16, M_WBT, lane);
+        if (l > 0 || p.dot_h) wt.load(nullptr, mats16, M_WBT, lane);
 #pragma unroll
         for (int T = 0; T < NT; ++T) {
           if (T >= ntile) continue;
 #pragma unroll
           for (int k = 0; k < DIM; ++k) pb[T][k] += pbsc[col[T] * DIM + k];
-          if (l > 0) hb[T] = wt.mul(lds_vec16(TB + col[T] * PBS + hh * 16), hb[T]);
+          if (l > 0 || p.dot_h) hb[T] = wt.mul(lds_vec16(TB + col[T] * PBS + hh * 16), hb[T]);
         }
       }
       wave_lds_fence();
@@ -482,9 +496,33 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
       for (int k = 0; k < DIM; ++k) {
         const float yb = pb[T][k] + p0acc[T][k] + p0sc[col[T] * DIM + k] - vfin[T][k];
         p.vjp[(walker0 * N + col[T]) * DIM + k] = fmaf(c_s[T], cot[T][k], c_in[T] * yb);
+        if (p.dot_h) dhacc[T] = fmaf((-0.5f * c_in[T] / (1.0f + hvv[T])) * yb, xin[T][k], dhacc[T]);  // through c_in(h) x
       }
     }
     wave_lds_fence();
+    if (p.dot_h) {
+      // through the time feature c_noise = ln(h)/8: t_bar = sum_nodes <h_bar^0, d h^0 / dt>; then one lane per walker
+      // adds up its particles' partial sums (both feature halves) in a fixed order
+      float* red = TB;  // [2][NCOLP]
+      const f32x16 w0 = lds_vec16(vemb + hh * 16), w1 = lds_vec16(vemb + 32 + hh * 16);
+#pragma unroll
+      for (int T = 0; T < NT; ++T) {
+        float tb = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tb = fmaf(hb[T][r], (a0t[T] ? w0[r] : 0.f) + (a1t[T] ? w1[r] : 0.f), tb);
+        const float part = valid[T] ? fmaf(tb, 0.125f / hvv[T], hh == 0 ? dhacc[T] : 0.f) : 0.f;
+        red[hh * C::NCOLP + col[T]] = part;
+      }
+      wave_lds_fence();
+#pragma unroll
+      for (int T = 0; T < NT; ++T) {
+        if (!(valid[T] && hh == 0 && nodei[T] == 0)) continue;
+        float sum = 0.f;
+        for (int q = 0; q < N; ++q) sum += red[col[T] + q] + red[C::NCOLP + col[T] + q];
+        p.dot_h[walker0 + col[T] / N] = sum;
+      }
+      wave_lds_fence();
+    }
   }
 }
 
@@ -513,7 +551,7 @@ static const VjpShape kVjpShapes[] = {
 using namespace pita;
 
 extern "C" int pita_egnn_vjp(pita_egnn_t* net, const float* h, const float* x, const float* beta, const float* cot,
-                             float* out, float* vjp, int64_t B, void* stream) {
+                             float* out, float* vjp, float* dot_h, int64_t B, void* stream) {
   PITA_REQUIRE(net && B >= 0, "pita_egnn_vjp: bad argument");
   if (B == 0) return PITA_OK;
   PITA_REQUIRE(h && x && vjp, "pita_egnn_vjp: null argument");
@@ -526,7 +564,7 @@ extern "C" int pita_egnn_vjp(pita_egnn_t* net, const float* h, const float* x, c
   p.mats16 = net->d_mats16; p.vecs = net->d_vecs; p.n_layers = net->cfg.n_layers; p.in_nf = net->cfg.in_node_nf;
   p.attention = net->cfg.attention; p.tanh_on = net->cfg.tanh; p.feature_layout = net->cfg.feature_layout;
   p.coord_scale = net->cfg.coords_range / (float)net->cfg.n_layers;
-  p.B = B; p.h = h; p.x = x; p.beta = beta; p.cot = cot; p.out = out; p.vjp = vjp;
+  p.B = B; p.h = h; p.x = x; p.beta = beta; p.cot = cot; p.out = out; p.vjp = vjp; p.dot_h = dot_h;
   const size_t lds = s->lds_bytes(p.n_layers);
   static thread_local const void* configured = nullptr;
   if (configured != (const void*)s->kernel) {

@@ -205,9 +205,10 @@ class EGNN_dynamics(nn.Module):
                        "pita_egnn_div_accumulate")
         return (trace, den) if want_denoiser else trace
 
-    def vjp(self, h_t, x_t, beta, cot=None, want_primal=True):
+    def vjp(self, h_t, x_t, beta, cot=None, want_primal=True, want_dot_h=False):
         """(D, J_x D^T cot): the denoiser and its reverse-mode derivative for a per-walker cotangent (default: x_t
-        itself, which is what grad_x E_theta needs).  One launch (pita_egnn_vjp) instead of dim JVP launches."""
+        itself, which is what grad_x E_theta needs).  One launch (pita_egnn_vjp) instead of dim JVP launches.
+        ``want_dot_h``: also return <cot, dD/dh> [B] from the same sweep -> (D, vjp, dot_h)."""
         x_t = _lib.dev_tensor(x_t, "x_t")
         B = x_t.shape[0]
         h_t = _lib.dev_tensor(h_t, "h_t").reshape(-1).expand(B).contiguous()
@@ -216,10 +217,11 @@ class EGNN_dynamics(nn.Module):
             cot = _lib.dev_tensor(cot, "cot")
         out = torch.empty_like(x_t) if want_primal else None
         vjp = torch.empty_like(x_t)
+        dot_h = torch.empty(B, device=x_t.device) if want_dot_h else None
         _lib.check(_lib.lib().pita_egnn_vjp(self._native(x_t.device), h_t.data_ptr(), x_t.data_ptr(), _lib.ptr(b),
-                                            _lib.ptr(cot), _lib.ptr(out), vjp.data_ptr(), B,
+                                            _lib.ptr(cot), _lib.ptr(out), vjp.data_ptr(), _lib.ptr(dot_h), B,
                                             _lib.stream_ptr(x_t.device)), "pita_egnn_vjp")
-        return out, vjp
+        return (out, vjp, dot_h) if want_dot_h else (out, vjp)
 
     def sampler_run(self, x, step_tab, n_steps, noise=None, seed=0, walker_offset=0, step0=0, remove_mean=True,
                     drift_out=None, n_particles=None, n_dim=None, stats_out=None):

@@ -137,15 +137,12 @@ class VEReverseSDE:
         return Dx, trace, jtx, dot_h
 
     def _energy_gradient_terms(self, model, ht, x, beta):
-        """D, J_x D^T x (one reverse-mode launch, pita_egnn_vjp) and <x, dD/dh> (one forward-mode launch): all that
-        grad_x E_theta and dE_theta/dt need.  Backbones without ``vjp`` fall back to dim forward-mode launches."""
+        """D, J_x D^T x and <x, dD/dh> from ONE reverse-mode launch (pita_egnn_vjp): all that grad_x E_theta and
+        dE_theta/dt need.  Backbones without ``vjp`` fall back to dim + 1 forward-mode launches."""
         if not hasattr(model, "vjp"):
             D_E, _, jtx, dot_h = self._denoiser_jacobian_terms(model, ht, x, beta, True)
             return D_E, jtx, dot_h
-        D_E, jtx = model.vjp(ht, x, beta)
-        dot_h = torch.empty(x.shape[0], device=x.device)
-        model.jvp(ht, x, beta, direction=-1, vh=torch.ones(x.shape[0], device=x.device), want_primal=False,
-                  want_tangent=False, dot_out=dot_h)
+        D_E, jtx, dot_h = model.vjp(ht, x, beta, want_dot_h=True)  # <x, dD/dh> rides on the reverse sweep
         return D_E, jtx, dot_h
 
     def _score_divergence_terms(self, model, ht, x, beta):

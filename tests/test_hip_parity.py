@@ -849,6 +849,21 @@ def test_vjp_vs_oracle(pa, golden):
         assert torch.equal(JTc, net.vjp(h.cuda(), x.cuda(), beta.cuda(), cot=cot.cuda(), want_primal=False)[1])  # reproducible
         lhs, rhs = (cot.cuda() * Jv).sum(1), (JTc * v.cuda()).sum(1)
         np.testing.assert_allclose(lhs.cpu().numpy(), rhs.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(lhs.abs().mean()))
+        # <cot, dD/dh> from the reverse sweep (time feature, c_in scaling, explicit c_s / c_out) against autograd of the
+        # fp64 oracle through h and against the forward-mode kernel's h direction
+        for tag, c in (("x", None), ("random", cot)):
+            hd = h.double().requires_grad_(True)
+            cc = (x if c is None else c).double()
+            (gh,) = torch.autograd.grad((O.denoiser(bb, hd, x.double(), beta.double()) * cc).sum(), hd)
+            _, vj2, dh = net.vjp(h.cuda(), x.cuda(), beta.cuda(), cot=None if c is None else c.cuda(), want_dot_h=True)
+            np.testing.assert_allclose(dh.cpu().numpy(), gh.numpy(), rtol=5e-5, atol=5e-5 * float(gh.abs().mean()),
+                                       err_msg=f"{n} {B} {tag}")
+            if c is None:
+                dj = torch.empty(B, device="cuda")
+                net.jvp(h.cuda(), x.cuda(), beta.cuda(), direction=-1, vh=torch.ones(B).cuda(), want_primal=False,
+                        want_tangent=False, dot_out=dj)
+                np.testing.assert_allclose(dh.cpu().numpy(), dj.cpu().numpy(), rtol=1e-4,
+                                           atol=1e-4 * float(dj.abs().mean()))
 
 
 def test_debiased_terms_and_trajectory_golden(pa, golden):
