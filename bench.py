@@ -245,9 +245,16 @@ def force_roofline(pita_amd, cfg, energy, x, dev, reps):
            "launches": reps, "same_bytes_device_copy_us": us_copy,
            "same_bytes_device_copy_GBs": 2 * B * n * d * 4 / (us_copy * 1e-6) / 1e9,
            "note": "stand-alone launches through the plug-in class (output tensors allocated per call)"}
+    # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x 2 streaming correction + WRITE_SIZE): the force
+    # kernel of this config is the one launched most often under that name in the profiled bench run
     pm = pmc_summary()
-    key = f"force_{cfg['name']}"
-    out["traffic"] = pm[key]["traffic_bytes_per_launch"] if pm and key in pm and pm[key].get("walkers") == B else None
+    ks = (pm or {}).get(f"force_{cfg['name']}_kernels", {})
+    pat = {"lj": "lj13_kernel<2" if n == 13 else "pair", "dw": "pair", "ff": "ff_"}[cfg["target"]]
+    ks = {k: v for k, v in ks.items() if pat in k}
+    out["traffic"] = None
+    if ks and B == cfg["walkers"]:
+        v = max(ks.values(), key=lambda e: e["launches"])
+        out["traffic"] = v["fetch_bytes_x2_streaming_correction"] + v["write_bytes"]
     if cfg["target"] == "lj" and n == 55:  # VALU-bound: SURVEY 8(d) 1 485 pairs x 28 + 55 x 9 flop per walker-eval
         flop = 1485 * 28 + 55 * 9
         tf = B * flop / (us * 1e-6) / 1e12

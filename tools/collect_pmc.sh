@@ -21,7 +21,7 @@ for P in "$P1" "$P2" "FETCH_SIZE" "WRITE_SIZE"; do
 done
 python3 tools/pmc_summarise.py $CFG $WALK 100 $OUT/pmc_sampler_$CFG.json $OUT/pmc1_$CFG $OUT/pmc2_$CFG $OUT/pmc3_$CFG $OUT/pmc4_$CFG > /dev/null
 # keep what is judged small: the stats CSV and the summary; drop the raw per-dispatch counter dumps
-find $OUT -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_$CFG.csv \;
+find $OUT/stats_$CFG -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_$CFG.csv \;
 find $OUT -name "*counter_collection.csv" -size +2M -delete
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*agent_info.csv" -delete

@@ -72,7 +72,7 @@ def main():
             e["write_bytes_per_launch"] = wr * 1024
             e["traffic_bytes_per_walker_step"] = (fe + wr) * 1024 / ws
         res[f"sampler_{config}"] = e
-    force = [k for k in acc if any(t in k for t in ("lj13_kernel", "pair_energy_kernel", "ff_kernel"))]
+    force = [k for k in acc if any(t in k for t in ("lj13_kernel", "pair_energy_kernel", "pair_energy_n3l_kernel", "ff_kernel"))]
     for k in force:
         fe, wr = mean(k, "FETCH_SIZE"), mean(k, "WRITE_SIZE")
         if fe is None or wr is None:
