@@ -194,8 +194,34 @@ def debiased_leg(pita_amd, net, cfg, dev, B, with_cpu):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     K = max(1, L.pita_egnn_div_directions(net._native(dev)))
+    # the divergence launches dominate the step: time them alone and price them against the 16-bit matrix peak
+    ht = torch.full((B,), float(sched.h(torch.tensor(0.5))), device=dev)
+    bt = torch.ones(B, device=dev)
+    net.jacobian_trace(ht, x, bt)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    net.jacobian_trace(ht, x, bt)
+    e1.record()
+    torch.cuda.synchronize()
+    tr_ms = e0.elapsed_time(e1)
+    import ctypes
+
+    a, b = ctypes.c_double(), ctypes.c_double()
+    pita_amd._lib.check(L.pita_egnn_div_work(net._native(dev), ctypes.byref(a), ctypes.byref(b)), "pita_egnn_div_work")
+    tf = B * a.value * MFMA16_FLOP / (tr_ms * 1e-3) / 1e12
+    pm = pmc_summary() or {}
+    pk = pm.get(f"divergence_{cfg['name']}")
     out = {"metric": f"walker-steps/s, debiased (Feynman-Kac) regime, {n}x{d}D", "value": B / dt, "walkers": B,
-           "ms_per_step": dt * 1e3, "launches_per_step": -(-n * d // K) + 2 + 3}
+           "ms_per_step": dt * 1e3,
+           "launches_per_step": f"{-(-n * d // K)} x (divergence + its repair pass), 1 reverse-mode, assembly, clamp, update",
+           "roofline": {"kernel": f"egnn_div_fast_kernel, {-(-n * d // K)} launches of {K} directions (exact trace of J_x D)",
+                        "bound": "mfma", "achieved": tf, "peak": PEAK_MFMA16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": tf / PEAK_MFMA16_TFLOPS, "ms_per_trace": tr_ms,
+                        "executed_mfma_flop_per_walker": a.value * MFMA16_FLOP,
+                        "executed_f32_mfma_flop_per_walker": b.value * MFMA32_FLOP,
+                        "valu_issue_frac": pk.get("valu_issue_frac") if pk and pk.get("walkers") == B else None,
+                        "note": "one wavefront per SIMD (512 registers): VALU-issue- and latency-bound, DESIGN.md 4.5"}}
+    assert 0.0 < out["roofline"]["frac"] <= 1.0
     if with_cpu:
         from oracle import pita_oracle as O
 

@@ -77,6 +77,22 @@ int pita_dw_descent(float* x, const float* noise, int64_t B, int n_particles, in
                     float b, float c, float d0, int nsteps, float dt, float noise_scale, float sqrt_dt, uint64_t seed,
                     uint64_t walker_offset, int64_t step0, int remove_mean, void* stream);
 
+/* Fused MALA chain on the LJ13 target: all nsteps of metropolis_hastings_mala / _adaptive
+ * (pita/src/models/components/sde_integration.py:28-45,362-470) in one launch, walkers resident in LDS; bit-identical to
+ * pita_lj_logp_force + pita_mala_propose + pita_lj_logp_force + pita_mala_accept + pita_mala_adapt step after step.
+ * x [B, 39] and logp [B] (log-density of x on entry) are updated in place; dt_dev holds the step size (adapted in place when
+ * adaptive != 0, against the acceptance rate over `total` walkers -- this rank's B: with several ranks the global rate
+ * needs the launch-per-kernel path); rates_out [nsteps] receives the acceptance rates.  noise [nsteps, B, 39] / uniforms
+ * [nsteps, B] nullable -> Philox keyed (seed, walker key, step0 + s, particle / 0xFFFFF), walker key = walker_ids[w] or
+ * walker_offset + w.  workspace: 8-byte aligned device scratch of pita_lj_mala_workspace_bytes(nsteps) bytes.  Returns PITA_EUNSUPPORTED
+ * for other particle systems, and for an adaptive chain whose blocks cannot all be resident (its per-step grid barrier). */
+size_t pita_lj_mala_workspace_bytes(int nsteps);
+int pita_lj_mala(float* x, float* logp, const float* noise /*nullable*/, const float* uniforms /*nullable*/, int64_t B,
+                 int n_particles, int n_dim, float temperature, float energy_factor, float dist_eps, float eps, float rm,
+                 float osc_scale, int nsteps, double* dt_dev, int adaptive, int64_t total, uint64_t seed,
+                 uint64_t walker_offset, const int64_t* walker_ids /*nullable*/, int64_t step0, int remove_mean,
+                 float* rates_out /*nullable*/, void* workspace, void* stream);
+
 /* Diagonal Gaussian mixture with equal weights.
  * replaces GMM.__call__ (pita/src/energies/gmm_energy.py:87-90) ->
  * fab GMM.log_prob (fab/fab/target_distributions/gmm.py:71-79,104).
@@ -190,6 +206,10 @@ int pita_egnn_div_directions(const pita_egnn_t* net);
 int pita_egnn_div_accumulate(pita_egnn_t* net, const float* h, const float* x, const float* beta, int dir0, int ndir,
                              float* diag_acc, float* denoiser_out /*nullable: D(h, x) of the shared primal*/, int64_t B,
                              void* stream);
+
+/* Work accounting for the roofline of the debiased leg (bench.py): matrix-core wave-instructions per walker for one full
+ * trace (all n_particles * n_dim directions) on the path this handle takes; units as pita_egnn_sampler_work. */
+int pita_egnn_div_work(const pita_egnn_t* net, double* mfma16_per_walker, double* mfma32_per_walker);
 
 /* Feynman-Kac drift assembly per walker from those reductions (replaces the torch/autograd expressions of
  * sdes.py:157-227): with E = be [(1+c_s)|x|^2/(2h) - <D_E,x>/h],

@@ -57,6 +57,10 @@ _PROTOS = {
                                 c_float, c_uint64, c_uint64, c_int64, c_int, c_void_p]),
     "pita_dw_descent": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int] + [c_float] * 5 + [c_int, c_float, c_float,
                                 c_float, c_uint64, c_uint64, c_int64, c_int, c_void_p]),
+    "pita_lj_mala_workspace_bytes": (c_size_t, [c_int]),
+    "pita_lj_mala": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int] + [c_float] * 6 +
+                     [c_int, c_void_p, c_int, c_int64, c_uint64, c_uint64, c_void_p, c_int64, c_int, c_void_p, c_void_p,
+                      c_void_p]),
     "pita_gmm_logp_force": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_float,
                                     c_void_p]),
     "pita_ff_create": (c_int, [POINTER(c_void_p), POINTER(FfConfig)]),
@@ -73,6 +77,7 @@ _PROTOS = {
     "pita_egnn_div_directions": (c_int, [c_void_p]),
     "pita_egnn_div_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                          c_int64, c_void_p]),
+    "pita_egnn_div_work": (c_int, [c_void_p, POINTER(c_double), POINTER(c_double)]),
     "pita_fk_assemble": (c_int, [c_void_p] * 9 + [c_float, c_float, c_void_p, c_void_p, c_float, c_float, c_void_p] +
                          [c_void_p] * 6 + [c_int64, c_int, c_void_p]),
     "pita_quantile_clamp": (c_int, [c_void_p, c_int64, c_int64, c_float, c_void_p]),

@@ -883,6 +883,44 @@ extern "C" int pita_egnn_div_directions(const pita_egnn_t* net) {
   return s ? s->K : PITA_EUNSUPPORTED;
 }
 
+// Matrix-core wave-instructions per walker for one FULL trace (all D directions) on the path the handle takes, counted on
+// the kernels' loop structure (bench.py: roofline of the debiased leg).  Fast kernel per column tile and launch: primal
+// 6 (Wb) + 6 (Wa) + (N-1)(18 f16 + 1 f32 k-step) per layer, + 6 x 3 node-model GEMMs except in the last layer; tangents:
+// first layer one shared W2 chain per edge (6), middle layers K (6 f16 + 1 f32) per edge, last layer one W2^T chain (6)
+// per edge; per direction 6 x (Wb, Wa, Wn1a) from the second layer on and 6 x (Wn1b, Wn2) in every layer but the last.
+extern "C" int pita_egnn_div_work(const pita_egnn_t* net, double* mfma16_per_walker, double* mfma32_per_walker) {
+  PITA_REQUIRE(net && mfma16_per_walker && mfma32_per_walker, "pita_egnn_div_work: null argument");
+  const DivShape* s = find_div_shape(net->cfg.n_particles, net->cfg.n_dim);
+  if (!s) return fail(PITA_EUNSUPPORTED, "pita_egnn_div_work: no kernel for this particle system");
+  const int N = s->n, K = s->K, L = net->cfg.n_layers, D = s->n * s->dim;
+  const double launches = (D + K - 1) / K;
+  const double tiles_per_walker = (double)((s->G * N + 31) / 32) / s->G;
+  double m16 = 0, m32 = 0;
+  if (div_fast_enabled(net)) {
+    for (int l = 0; l < L; ++l) {
+      const bool first = l == 0, lastl = l == L - 1;
+      m16 += 12 + (N - 1) * 18.0 + (lastl ? 0 : 18);
+      m32 += N - 1;
+      if (first) m16 += (N - 1) * 6.0;
+      else if (lastl) m16 += (N - 1) * 6.0;
+      else { m16 += (N - 1) * 6.0 * K; m32 += (N - 1) * K; }
+      if (!first) m16 += 12.0 * K + (lastl ? 0 : 6.0 * K);
+      if (!lastl) m16 += 12.0 * K;
+    }
+  } else {  // bf16x3 kernel: 12 MFMAs per dense layer, every tangent repeats the primal's GEMMs
+    for (int l = 0; l < L; ++l) {
+      const bool first = l == 0, lastl = l == L - 1;
+      m16 += 24 + (N - 1) * 24.0 + (lastl ? 0 : 36);
+      m32 += N - 1;
+      m16 += K * ((N - 1) * 24.0 + (first ? 0 : 24) + (lastl ? 0 : (first ? 24 : 36)));
+      m32 += K * (N - 1);
+    }
+  }
+  *mfma16_per_walker = m16 * tiles_per_walker * launches;
+  *mfma32_per_walker = m32 * tiles_per_walker * launches;
+  return PITA_OK;
+}
+
 static int div_launch(const DivShape* s, void (*kernel)(DivParams), pita_egnn_t* net, const DivParams& p, void* stream) {
   const size_t lds = s->lds_bytes(p.n_layers);
   PITA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -617,6 +617,202 @@ __global__ void __launch_bounds__(256, 2) lj13_descent_kernel(float* __restrict_
   }
 }
 
+
+// ---------------------------------------------------------------------------- fused MALA chain on the LJ13 target
+// All post_mcmc_steps of metropolis_hastings_mala(_adaptive) (sde_integration.py:362-470) in ONE launch with the walkers
+// resident in LDS: per step  force(x) -> proposal x' = (x + dt/2 F) + sqrt(dt) xi (:28-45) -> logp, force at x' ->
+// log q_f, log q_b, accept iff log u < (logp' - logp) + (log q_b - log q_f) -> the reference's float blend of x and
+// logp, optional centring, acceptance count -> step-size adaptation dt *= 1.1 / dt /= 1.1 on the GLOBAL acceptance rate
+// (:439-443).  The two target evaluations per step are the two halves of lj13_kernel<2> (half 1 hands its partial forces
+// and energy over through LDS), the elementwise arithmetic and its summation orders are those of mala_propose_kernel /
+// mala_accept_kernel / mala_adapt_kernel (sampler_kernels.hip): the chain is bit-identical to the launch-per-kernel
+// path.  The adaptive variant needs every block's acceptance count before the next step: one grid-wide barrier per step
+// (all blocks co-resident: checked by the launch wrapper).  Only the counter itself crosses blocks, so the barrier is ONE
+// relaxed agent-scope atomic add of (1 << 32 | accepted) per block and a relaxed polling load -- no release / acquire
+// fences, which at agent scope write back and invalidate the XCD's L2 (measured: ~80 us per step with them); bounded spin.
+struct MalaParams {
+  const float* noise;      // nullable [nsteps, B, 39]
+  const float* uniforms;   // nullable [nsteps, B]
+  const long long* walker_ids;
+  unsigned long long seed, walker_offset;
+  long long step0, total;
+  double dt0;              // unused (dt is read from dt_dev)
+  const double* dt_dev;
+  int nsteps, adaptive, remove_mean;
+  unsigned long long* sync;  // [nsteps + 1]: per step (blocks arrived << 32 | walkers accepted), error flag; zeroed by the wrapper
+};
+
+template <bool UNIT_RM>
+__global__ void __launch_bounds__(256, 2) lj13_mala_kernel(float* __restrict__ x, float* __restrict__ logp, long long B,
+                                                           PairParams p, MalaParams q) {
+  constexpr int D = 39, WPB = 128, N = 13;
+  __shared__ __attribute__((aligned(16))) float xs[WPB * D];   // current walkers
+  __shared__ __attribute__((aligned(16))) float xps[WPB * D];  // proposals
+  __shared__ __attribute__((aligned(16))) float fb[WPB * D];   // half 1's partial forces
+  __shared__ float es1[WPB];
+  __shared__ int cnt[4];
+  __shared__ int total_acc;
+  const int tid = threadIdx.x;
+  const int half = tid / WPB, wl = tid - half * WPB;
+  const long long nblk = (B + WPB - 1) / WPB;
+  // adaptive: exactly one tile per block (the wrapper launches nblk blocks); else a grid-stride loop over tiles
+  for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const long long w0 = blk * WPB;
+    const int nw = (int)((B - w0) < WPB ? (B - w0) : WPB);
+    const int nfl = nw * D;
+    {
+      const float4* src4 = reinterpret_cast<const float4*>(x + w0 * D);
+      float4* dst4 = reinterpret_cast<float4*>(xs);
+      for (int i = tid; i < nfl / 4; i += 256) dst4[i] = src4[i];
+      for (int i = (nfl & ~3) + tid; i < nfl; i += 256) xs[i] = x[w0 * D + i];
+    }
+    __syncthreads();
+    const bool act = wl < nw;
+    const int row = (act ? wl : 0) * D;
+    const long long wg = w0 + (act ? wl : 0);
+    const unsigned long long key = q.walker_ids ? (unsigned long long)q.walker_ids[wg] : q.walker_offset + (unsigned long long)wg;
+    float lp = (half == 0 && act) ? logp[wg] : 0.f;
+    double dt = q.dt_dev[0];
+    for (int s = 0; s < q.nsteps; ++s) {
+      const float hdt = (float)(0.5 * dt), sdt = (float)sqrt(dt), tdt = (float)(2.0 * dt);
+      float fr[39], e;
+      // ---- A: target force at x
+      if (half == 0) {
+        lj13_partial<2, 1, false, false, UNIT_RM>(xs + row, fr, e, p);
+      } else {
+        lj13_partial<2, 2, true, false, UNIT_RM>(xs + row, fr, e, p);
+        if (act) {
+#pragma unroll
+          for (int k = 0; k < N; ++k) {
+            const int pk = ((2 * k) % N) * 3;
+            fb[row + pk] = fr[k * 3]; fb[row + pk + 1] = fr[k * 3 + 1]; fb[row + pk + 2] = fr[k * 3 + 2];
+          }
+        }
+      }
+      __syncthreads();
+      // ---- B: proposal and log q_f (half 0 owns the walker)
+      float sf = 0.f;
+      if (half == 0 && act) {
+#pragma unroll 1
+        for (int i = 0; i < N; ++i) {
+          float xi[4] = {0.f, 0.f, 0.f, 0.f};
+          if (q.noise) {
+            const float* nz = q.noise + (((long long)s * B + wg) * D + i * 3);
+            xi[0] = nz[0]; xi[1] = nz[1]; xi[2] = nz[2];
+          } else {
+            philox_normal4(q.seed, key, q.step0 + s, (uint32_t)i, xi);
+          }
+          float sfi = 0.f;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const int k = i * 3 + c;
+            const float F = fr[k] + fb[row + k];
+            const float t1 = xs[row + k] + hdt * F;
+            const float xp = t1 + sdt * xi[c];
+            xps[row + k] = xp;
+            const float df = xp - t1;
+            sfi += df * df;
+          }
+          sf += sfi;
+        }
+      }
+      __syncthreads();
+      // ---- C: target log-density and force at x'
+      if (half == 0) {
+        lj13_partial<2, 1, false, true, UNIT_RM>(xps + row, fr, e, p);
+      } else {
+        lj13_partial<2, 2, true, true, UNIT_RM>(xps + row, fr, e, p);
+        if (act) {
+#pragma unroll
+          for (int k = 0; k < N; ++k) {
+            const int pk = ((2 * k) % N) * 3;
+            fb[row + pk] = fr[k * 3]; fb[row + pk + 1] = fr[k * 3 + 1]; fb[row + pk + 2] = fr[k * 3 + 2];
+          }
+          es1[wl] = e;
+        }
+      }
+      __syncthreads();
+      // ---- D: accept / reject, blend, centring, acceptance count
+      bool acc = false;
+      if (half == 0 && act) {
+        const float lpp = -p.inv_T * (e + es1[wl]);
+        float sb = 0.f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          float sbi = 0.f;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const int k = i * 3 + c;
+            const float Fp = fr[k] + fb[row + k];
+            const float db = xs[row + k] - (xps[row + k] + hdt * Fp);
+            sbi += db * db;
+          }
+          sb += sbi;
+        }
+        const float lqf = -sf / tdt, lqb = -sb / tdt;
+        const float ratio = (lpp - lp) + (lqb - lqf);
+        const float u = q.uniforms ? q.uniforms[(long long)s * B + wg] : philox_uniform(q.seed, key, q.step0 + s, 0xFFFFFu);
+        const float af = (logf(u) < ratio) ? 1.0f : 0.0f;
+        acc = af != 0.f;
+        lp = af * lpp + (1.0f - af) * lp;
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 39; ++k) fr[k] = af * xps[row + k] + (1.0f - af) * xs[row + k];
+        if (q.remove_mean) {
+#pragma unroll
+          for (int k = 0; k < N; ++k) { m0 += fr[k * 3]; m1 += fr[k * 3 + 1]; m2 += fr[k * 3 + 2]; }
+          m0 /= (float)N; m1 /= (float)N; m2 /= (float)N;
+#pragma unroll
+          for (int k = 0; k < N; ++k) { fr[k * 3] -= m0; fr[k * 3 + 1] -= m1; fr[k * 3 + 2] -= m2; }
+        }
+#pragma unroll
+        for (int k = 0; k < 39; ++k) xs[row + k] = fr[k];
+      }
+      const unsigned long long bal = __ballot(acc);
+      if ((tid & 63) == 0) cnt[tid >> 6] = __popcll(bal);
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned long long c = (unsigned long long)(cnt[0] + cnt[1] + cnt[2] + cnt[3]);
+        __hip_atomic_fetch_add(&q.sync[s], (1ull << 32) | c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (q.adaptive) {  // grid-wide barrier: wait until every block has added its count
+          unsigned long long v = 0;
+          int spins = 0;
+          while (((v = __hip_atomic_load(&q.sync[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) < gridDim.x) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1 << 22)) { q.sync[q.nsteps] = 1; break; }  // never hang the device
+          }
+          total_acc = (int)(v & 0xFFFFFFFFull);
+        }
+      }
+      __syncthreads();
+      if (q.adaptive) {
+        const float rate = (float)total_acc / (float)q.total;
+        dt = ((double)rate > 0.55) ? dt * 1.1 : dt / 1.1;  // sde_integration.py:439-443
+      }
+    }
+    {
+      float4* dst4 = reinterpret_cast<float4*>(x + w0 * D);
+      const float4* src4 = reinterpret_cast<const float4*>(xs);
+      for (int i = tid; i < nfl / 4; i += 256) dst4[i] = src4[i];
+      for (int i = (nfl & ~3) + tid; i < nfl; i += 256) x[w0 * D + i] = xs[i];
+    }
+    if (half == 0 && act) logp[wg] = lp;
+    __syncthreads();
+  }
+}
+
+// acceptance rates of all steps and the final step size from the per-step counts (same arithmetic as mala_adapt_kernel)
+__global__ void mala_finish_kernel(double* dt_dev, const unsigned long long* sync, int nsteps, long long total, int adaptive,
+                                   float* rates_out) {
+  double dt = dt_dev[0];
+  for (int s = 0; s < nsteps; ++s) {
+    const float rate = (float)(int)(sync[s] & 0xFFFFFFFFull) / (float)total;
+    if (rates_out) rates_out[s] = rate;
+    if (adaptive) dt = ((double)rate > 0.55) ? dt * 1.1 : dt / 1.1;
+  }
+  dt_dev[0] = dt;
+}
+
 template <int KIND>
 static int launch_descent(float* x, const float* noise, int64_t B, int n, int d, const PairParams& p, const DescentParams& q,
                           void* stream) {
@@ -838,4 +1034,53 @@ extern "C" int pita_dw_descent(float* x, const float* noise, int64_t B, int n, i
   p.inv_T = 1.0f / temperature; p.a = a; p.b = b; p.c = c; p.d0 = d0;
   return launch_descent<E_DW>(x, noise, B, n, d, p,
                               descent_params(nsteps, dt, noise_scale, sqrt_dt, seed, walker_offset, step0, remove_mean), stream);
+}
+
+extern "C" size_t pita_lj_mala_workspace_bytes(int nsteps) { return 8 * (size_t)((nsteps > 0 ? nsteps : 0) + 1); }
+
+extern "C" int pita_lj_mala(float* x, float* logp, const float* noise, const float* uniforms, int64_t B, int n, int d,
+                            float temperature, float energy_factor, float dist_eps, float eps, float rm, float osc_scale,
+                            int nsteps, double* dt_dev, int adaptive, int64_t total, uint64_t seed,
+                            uint64_t walker_offset, const int64_t* walker_ids, int64_t step0, int remove_mean,
+                            float* rates_out, void* workspace, void* stream) {
+  PITA_REQUIRE(temperature > 0.f, "pita_lj_mala: temperature must be > 0");
+  PITA_REQUIRE(B >= 0 && nsteps >= 0 && total > 0, "pita_lj_mala: bad argument");
+  if (n != 13 || d != 3) return fail(PITA_EUNSUPPORTED, "pita_lj_mala: only the LJ13 kernel is fused (n = %d, d = %d)", n, d);
+  if (nsteps == 0) return PITA_OK;
+  PITA_REQUIRE(dt_dev && workspace && (B == 0 || (x && logp)), "pita_lj_mala: null argument");
+  PairParams p{};
+  p.inv_T = 1.0f / temperature; p.energy_factor = energy_factor; p.dist_eps = dist_eps; p.eps = eps;
+  p.rm2 = rm * rm; p.osc_scale = osc_scale;
+  p.cw = -p.inv_T * (2.0f * energy_factor * eps * 12.0f / p.rm2); p.co = -p.inv_T * osc_scale;
+  hipStream_t s = (hipStream_t)stream;
+  PITA_REQUIRE(((uintptr_t)workspace & 7) == 0, "pita_lj_mala: workspace must be 8-byte aligned");
+  unsigned long long* sync = static_cast<unsigned long long*>(workspace);
+  PITA_HIP_CHECK(hipMemsetAsync(sync, 0, pita_lj_mala_workspace_bytes(nsteps), s));
+  const long long nblk = (B + 127) / 128;
+  const bool unit = p.rm2 == 1.0f;
+  if (nblk > 0) {
+    static int capacity = 0;  // co-resident blocks of the chain kernel on this device
+    if (capacity == 0) {
+      int per_cu = 0, dev = 0;
+      hipDeviceProp_t prop;
+      PITA_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lj13_mala_kernel<true>, 256, 0));
+      PITA_HIP_CHECK(hipGetDevice(&dev));
+      PITA_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+      capacity = per_cu * prop.multiProcessorCount;
+    }
+    if (adaptive && nblk > capacity)
+      return fail(PITA_EUNSUPPORTED, "pita_lj_mala: the adaptive chain needs all %lld blocks resident (capacity %d)", nblk,
+                  capacity);
+    MalaParams q{};
+    q.noise = noise; q.uniforms = uniforms; q.walker_ids = (const long long*)walker_ids; q.seed = seed;
+    q.walker_offset = walker_offset; q.step0 = step0; q.total = total; q.dt_dev = dt_dev; q.nsteps = nsteps;
+    q.adaptive = adaptive; q.remove_mean = remove_mean; q.sync = sync;
+    const unsigned grid = (unsigned)(nblk < capacity ? nblk : capacity);
+    if (unit) hipLaunchKernelGGL(lj13_mala_kernel<true>, dim3(grid), dim3(256), 0, s, x, logp, (long long)B, p, q);
+    else hipLaunchKernelGGL(lj13_mala_kernel<false>, dim3(grid), dim3(256), 0, s, x, logp, (long long)B, p, q);
+    PITA_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(mala_finish_kernel, dim3(1), dim3(1), 0, s, dt_dev, sync, nsteps, (long long)total, adaptive, rates_out);
+  PITA_LAUNCH_CHECK();
+  return PITA_OK;
 }

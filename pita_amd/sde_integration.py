@@ -424,7 +424,7 @@ class WeightedSDEIntegrator:
         return x
 
     def _mala(self, x, energy_function, adaptive, dt, noise=None, uniforms=None, return_acceptance_rate=False,
-              walker_offset=0, comm=None):
+              walker_offset=0, comm=None, fused=True):
         """MALA with the reference's finite-mask semantics (:362-470): non-finite-logp walkers are set aside and
         re-appended AFTER the valid ones (order not preserved, quirk Q7).  Proposal, accept/reject and the step-size
         adaptation run as HIP kernels with the step size on the device: no host synchronisation inside the chain.
@@ -459,6 +459,23 @@ class WeightedSDEIntegrator:
             # :397-398 centres through maybe_remove_mean, the adaptive variant (:458-461) unconditionally
             rm = int(bool(getattr(energy_function, "is_molecule", False)) and (adaptive or bool(self.should_mean_free)))
             st = _lib.stream_ptr(dev)
+            # pair targets with a fused chain kernel: every step in ONE launch, walkers LDS-resident (bit-identical
+            # to the loop below); the global acceptance rate of several ranks needs the per-step all-reduce below
+            if fused and world == 1 and Bv > 0 and hasattr(energy_function, "fused_mala"):
+                nz = uu = None
+                if noise is not None:
+                    nz = torch.stack([_lib.dev_tensor(noise[i], "noise") for i in range(steps)]).contiguous()
+                    if tuple(nz.shape) != (steps,) + tuple(x_valid.shape):
+                        raise ValueError(f"MALA noise has shape {tuple(nz.shape)}, expected {(steps,) + tuple(x_valid.shape)}")
+                if uniforms is not None:
+                    uu = torch.stack([_lib.dev_tensor(uniforms[i], "uniforms").reshape(-1) for i in range(steps)]).contiguous()
+                    if tuple(uu.shape) != (steps, Bv):
+                        raise ValueError(f"MALA uniforms have shape {tuple(uu.shape)}, expected {(steps, Bv)}")
+                if energy_function.fused_mala(x_valid, logp, steps, dt_dev, adaptive, total, noise=nz, uniforms=uu, seed=key,
+                                              walker_offset=walker_offset, walker_ids=ids, step0=0, remove_mean=rm,
+                                              rates_out=rates) is not None:
+                    done = steps
+                    steps = 0
             for i in range(steps):
                 if Bv > 0:
                     _, grad = energy_function(x_valid, return_force=True)
@@ -486,11 +503,11 @@ class WeightedSDEIntegrator:
         return (out, rates[:done].tolist()) if return_acceptance_rate else (out, None)
 
     def metropolis_hastings_mala(self, x, energy_function, return_acceptance_rate=False, noise=None, uniforms=None,
-                                 walker_offset=0, comm=None):
+                                 walker_offset=0, comm=None, fused=True):
         return self._mala(x, energy_function, False, float(self.dt_negative_time), noise, uniforms,
-                          return_acceptance_rate, walker_offset, comm)
+                          return_acceptance_rate, walker_offset, comm, fused)
 
     def metropolis_hastings_mala_adaptive(self, x, energy_function, dt_init, return_acceptance_rate=False, noise=None,
-                                          uniforms=None, walker_offset=0, comm=None):
+                                          uniforms=None, walker_offset=0, comm=None, fused=True):
         return self._mala(x, energy_function, True, float(dt_init), noise, uniforms, return_acceptance_rate,
-                          walker_offset, comm)
+                          walker_offset, comm, fused)

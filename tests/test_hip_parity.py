@@ -504,6 +504,55 @@ def test_post_processing_golden(pa, golden):
     assert rel(xa, g["x_mala_adaptive"]) < 1e-5
 
 
+@pytest.mark.parametrize("adaptive", [False, True])
+@pytest.mark.parametrize("B,steps", [(777, 6), (128, 3), (5, 4), (65536, 5)])
+def test_fused_mala_equals_per_step(pa, golden, B, steps, adaptive):
+    """pita_lj_mala (all steps, both target evaluations per step, accept / reject and step-size adaptation in one launch)
+    == the launch-per-kernel chain, bit for bit: walkers, acceptance rates, with Philox and with injected noise /
+    uniforms, with and without centring, ragged and full blocks, and with a walker that is set aside (quirk Q7)."""
+    g = golden("post_lj13.npz")
+    e = pa.LennardJonesEnergy(39, 13, 3)
+    gen = torch.Generator().manual_seed(B + steps)
+    base = T(g["x0"])
+    x0 = base[torch.arange(B) % base.shape[0]] + 0.02 * torch.randn(B, 39, generator=gen)
+    x0 = O.remove_mean(x0, 13, 3).cuda()
+    for mean_free in (True, False):
+        for inject in (False, True):
+            if inject and B > 1000:
+                continue
+            kw = {}
+            if inject:
+                kw = dict(noise=torch.randn(steps, B, 39, generator=gen).cuda(),
+                          uniforms=torch.rand(steps, B, generator=gen).cuda())
+            outs = []
+            for fused in (True, False):
+                integ = pa.WeightedSDEIntegrator(sde=None, num_integration_steps=1, start_resampling_step=0,
+                                                 end_resampling_step=1, post_mcmc_steps=steps, dt_negative_time=3e-4,
+                                                 adaptive_mcmc=adaptive, should_mean_free=mean_free, seed=9)
+                if adaptive:
+                    outs.append(integ.metropolis_hastings_mala_adaptive(x0.clone(), e, dt_init=3e-4,
+                                                                        return_acceptance_rate=True, fused=fused, **kw))
+                else:
+                    outs.append(integ.metropolis_hastings_mala(x0.clone(), e, return_acceptance_rate=True, fused=fused, **kw))
+            assert torch.equal(outs[0][0], outs[1][0]), (mean_free, inject)
+            assert outs[0][1] == outs[1][1] and len(outs[0][1]) == steps
+            if B >= 100:
+                assert 0.0 < max(outs[0][1]) and min(outs[0][1]) < 1.0  # a chain that actually accepts and rejects
+    if B == 777:  # a non-finite walker in the middle: Philox keys follow the original indices in both paths
+        xb = x0.clone()
+        xb[300, 0] = float("inf")  # log p is not finite: the walker is set aside and re-appended last
+        outs = []
+        for fused in (True, False):
+            integ = pa.WeightedSDEIntegrator(sde=None, num_integration_steps=1, start_resampling_step=0,
+                                             end_resampling_step=1, post_mcmc_steps=steps, dt_negative_time=3e-4,
+                                             adaptive_mcmc=adaptive, seed=9)
+            fn = integ.metropolis_hastings_mala_adaptive if adaptive else integ.metropolis_hastings_mala
+            akw = dict(dt_init=3e-4) if adaptive else {}
+            outs.append(fn(xb.clone(), e, return_acceptance_rate=True, fused=fused, **akw))
+        assert torch.equal(outs[0][0][:-1], outs[1][0][:-1]) and outs[0][1] == outs[1][1]
+        assert integ._last_mala_valid == B - 1 and torch.isinf(outs[0][0][-1, 0]) and torch.isinf(outs[1][0][-1, 0])
+
+
 def test_mala_sets_non_finite_walkers_aside(pa, golden):
     """Quirk Q7 (sde_integration.py:366-369,400): walkers whose target log-density is not finite are taken out before
     the chain and re-appended AFTER the valid ones (order not preserved); the chain itself runs on the valid rows with
