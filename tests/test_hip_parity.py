@@ -653,6 +653,8 @@ def test_full_size_lj13_properties(pa, golden):
     lpp, fp = e(xp, return_force=True)
     np.testing.assert_allclose(lpp.cpu().numpy(), lp.cpu().numpy(), rtol=2e-5, atol=3e-5)
     assert rel(fp, f.reshape(B, 13, 3)[:, perm.cuda()].reshape(B, 39)) < 1e-5
+    # the fused sampler at the metric's batch: one step of all 65 536 walkers, a sample of them against the oracle
+    _one_step_vs_oracle(pa, golden, 13, 3, B, 0.05)
 
 
 def _one_step_vs_oracle(pa, golden, n, d, B, sigma_min, subset=24, seed=0):
