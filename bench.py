@@ -213,14 +213,16 @@ def debiased_leg(pita_amd, net, cfg, dev, B, with_cpu):
     pk = pm.get(f"divergence_{cfg['name']}")
     out = {"metric": f"walker-steps/s, debiased (Feynman-Kac) regime, {n}x{d}D", "value": B / dt, "walkers": B,
            "ms_per_step": dt * 1e3,
-           "launches_per_step": f"{-(-n * d // K)} x (divergence + its repair pass), 1 reverse-mode, assembly, clamp, update",
-           "roofline": {"kernel": f"egnn_div_fast_kernel, {-(-n * d // K)} launches of {K} directions (exact trace of J_x D)",
+           "launches_per_step": "exact trace of J_x D (1 launch with the primal + tangent-only launches from the primal "
+                                "cache, each followed by its repair pass), 1 reverse-mode launch, assembly, clamp, update",
+           "roofline": {"kernel": "egnn_div_fast_kernel + egnn_div_tangent_kernel (pita_egnn_jacobian_trace)",
                         "bound": "mfma", "achieved": tf, "peak": PEAK_MFMA16_TFLOPS, "unit": "TFLOP/s",
                         "frac": tf / PEAK_MFMA16_TFLOPS, "ms_per_trace": tr_ms,
                         "executed_mfma_flop_per_walker": a.value * MFMA16_FLOP,
                         "executed_f32_mfma_flop_per_walker": b.value * MFMA32_FLOP,
                         "valu_issue_frac": pk.get("valu_issue_frac") if pk and pk.get("walkers") == B else None,
-                        "note": "one wavefront per SIMD (512 registers): VALU-issue- and latency-bound, DESIGN.md 4.5"}}
+                        "note": "one wavefront per SIMD (512 registers); the tangent-only launches stream the primal cache "
+                                "(~12 GB per launch at 65 536 LJ13 walkers) at ~4 TB/s: DESIGN.md 4.5"}}
     assert 0.0 < out["roofline"]["frac"] <= 1.0
     if with_cpu:
         from oracle import pita_oracle as O

@@ -207,6 +207,13 @@ int pita_egnn_div_accumulate(pita_egnn_t* net, const float* h, const float* x, c
                              float* diag_acc, float* denoiser_out /*nullable: D(h, x) of the shared primal*/, int64_t B,
                              void* stream);
 
+/* The whole trace in one call: trace[b] = trace(J_x D(h_b, x_b)) (overwritten), optionally D itself.  Handles of
+ * precision 2 compute the primal network ONCE: the first launch stores the per-edge primal factors the tangent chains
+ * consume in a handle-owned cache (about 180 KB per LJ13 walker; batches beyond PITA_DIV_CACHE_GB, default 24, go in chunks
+ * of walkers) and the remaining directions run as tangent-only launches, four directions each, streaming that cache. */
+int pita_egnn_jacobian_trace(pita_egnn_t* net, const float* h, const float* x, const float* beta, float* trace,
+                             float* denoiser_out /*nullable*/, int64_t B, void* stream);
+
 /* Work accounting for the roofline of the debiased leg (bench.py): matrix-core wave-instructions per walker for one full
  * trace (all n_particles * n_dim directions) on the path this handle takes; units as pita_egnn_sampler_work. */
 int pita_egnn_div_work(const pita_egnn_t* net, double* mfma16_per_walker, double* mfma32_per_walker);

@@ -77,6 +77,7 @@ _PROTOS = {
     "pita_egnn_div_directions": (c_int, [c_void_p]),
     "pita_egnn_div_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                          c_int64, c_void_p]),
+    "pita_egnn_jacobian_trace": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "pita_egnn_div_work": (c_int, [c_void_p, POINTER(c_double), POINTER(c_double)]),
     "pita_fk_assemble": (c_int, [c_void_p] * 9 + [c_float, c_float, c_void_p, c_void_p, c_float, c_float, c_void_p] +
                          [c_void_p] * 6 + [c_int64, c_int, c_void_p]),

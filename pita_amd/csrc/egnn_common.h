@@ -291,6 +291,8 @@ struct pita_egnn {
   int n_cu = 256;
   float* d_ws = nullptr;         // reverse-mode checkpoint scratch (egnn_vjp_kernel.hip), grown on demand
   size_t ws_bytes = 0;
+  float* d_divcache = nullptr;   // precision 2: per-edge primal factors of one trace (egnn_div_kernel.hip, DivCache)
+  size_t divcache_bytes = 0;
   int* d_mark = nullptr;         // precision 2 divergence kernel: walkers left to the bf16x3 kernel (egnn_div_kernel.hip)
   size_t mark_bytes = 0;
   void* d_bk = nullptr;          // precision 2 sampler: walker backup + owed-moments markers for the repair launch

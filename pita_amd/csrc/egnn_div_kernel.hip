@@ -24,6 +24,8 @@ struct DivParams {
   const float* vecs;
   const float* vecs_h;      // vectors with the f16-path scale factors folded in (fast kernel)
   const float* vecs_div;    // [L][3][32] k-step weights in fragment order (fast kernel)
+  float* cache;             // fast kernel: nullable, receives the per-edge primal factors the tangent chains consume
+                            // (DivCache layout); egnn_div_tangent_kernel: reads them
   int* mark;                // [B] fast kernel: 1 = this launch's contribution of the walker was non-finite and NOT added;
                             // this kernel with repair != 0: recompute and add exactly the marked walkers
   int repair;
@@ -389,6 +391,50 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_kernel(DivParams p) {
 
 
 // ------------------------------------------------------------------------------------------------------------------
+// Primal cache.  The primal network is the same for all D directions of a trace; the fast kernel recomputes it in each
+// of its D / K launches (61 % of its vector work).  With `cache` set, the FIRST launch stores what the tangent chains
+// consume from the primal -- per layer the positions entering it, per node the scaled SiLU derivative of the node model,
+// per edge one (first / last layer) or four (middle layers) 16-float-per-lane vectors and a few scalars -- and
+// egnn_div_tangent_kernel runs the remaining directions from that cache, six per launch, without touching the primal:
+// ≈180 KB per walker (12 GB at 65 536 walkers: HBM capacity is what this GPU has to spare), streamed once per launch in
+// 1 KB wave-loads.  Layout per walker group g (a wave's G walkers) and layer l, in floats:
+//   [pos: POSF] then per tile T: [gn: 1024] [edge dd = 1..N-1: nv(l) x 1024 vectors | 8 x 64 scalars]
+// scalar slots: 0 cs, 1 dcs_f (incl. the tangent scales), 2 att, 3 att (1 - att), 4 vcdmu | qr, 5 qe.
+template <int N, int DIM, int NT>
+struct DivCache {
+  static constexpr int POSF = ((NT * 32 * DIM + 63) / 64) * 64;
+  static __host__ __device__ int nvec(int l, int L) { return (l == 0 || l == L - 1) ? 1 : 4; }
+  static __host__ __device__ size_t edge_f(int l, int L) { return (size_t)nvec(l, L) * 1024 + 512; }
+  static __host__ __device__ size_t tile_f(int l, int L) { return 1024 + (size_t)(N - 1) * edge_f(l, L); }
+  static __host__ __device__ size_t layer_f(int l, int L) { return POSF + (size_t)NT * tile_f(l, L); }
+  static __host__ __device__ size_t group_f(int L) {
+    size_t t = 0;
+    for (int l = 0; l < L; ++l) t += layer_f(l, L);
+    return t;
+  }
+  static __host__ __device__ size_t layer_off(int l, int L) {
+    size_t t = 0;
+    for (int q = 0; q < l; ++q) t += layer_f(q, L);
+    return t;
+  }
+};
+__device__ __forceinline__ void cache_store16(float* base, int lane, const f32x16& v) {
+  f32x4* d = reinterpret_cast<f32x4*>(base) + lane;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) d[q * 64] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+}
+__device__ __forceinline__ f32x16 cache_load16(const float* base, int lane) {
+  const f32x4* d = reinterpret_cast<const f32x4*>(base) + lane;
+  f32x16 r;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 v = d[q * 64];
+    r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+  }
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Fast variant (handles built with precision 2).  Same mapping and LDS tables; two changes in the arithmetic:
 //
 // (1) dense layers on the f16 two-piece path (egnn_common.h, PREC 2).  Feature tangents (dh, dz, dm, dagg and the LDS
@@ -444,10 +490,14 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_fast_kernel(DivParams 
   const long long quota = (p.B + total_waves - 1) / total_waves;
   const long long wbeg = ((long long)blockIdx.x * WAVES + wave) * quota;
   const long long wend = (wbeg + quota < p.B) ? wbeg + quota : p.B;
+  using CA = DivCache<N, DIM, NT>;
+  const long long groups_per_wave = (quota + G - 1) / G;
   for (long long walker0 = wbeg; walker0 < wend; walker0 += G) {
     const int nwalk = (int)((wend - walker0) < G ? (wend - walker0) : G);
     const int ncol = nwalk * N;
     const int ntile = (ncol + 31) >> 5;
+    float* cgrp = p.cache ? p.cache + (size_t)(((long long)blockIdx.x * WAVES + wave) * groups_per_wave +
+                                                 (walker0 - wbeg) / G) * CA::group_f(L) : nullptr;
     int col[NT], nodei[NT];
     bool valid[NT];
     float c_s[NT], c_in[NT], c_out[NT];
@@ -508,6 +558,9 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_fast_kernel(DivParams 
       const float* vl = lds + VEC_EMB_F + l * VEC_LAYER_F + hh * 16;
       const bool first = (l == 0), last = (l == L - 1) && !first;
       const float* poscur = posb + cur * C::POS_F;
+      float* clay = cgrp ? cgrp + CA::layer_off(l, L) : nullptr;
+      if (clay)
+        for (int i = lane; i < C::POS_F; i += 64) clay[i] = poscur[i];
       {
         WFrag<2> wb;
         wb.load(nullptr, mats16h, M_WB, lane);
@@ -644,6 +697,15 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_fast_kernel(DivParams 
             dradial[d] *= 2.0f;
             dea[d] *= 2.0f;
           }
+          float* crec = clay ? clay + CA::POSF + (size_t)T * CA::tile_f(l, L) + 1024 + (size_t)(dd - 1) * CA::edge_f(l, L)
+                             : nullptr;
+          float* cscal = crec ? crec + (size_t)CA::nvec(l, L) * 1024 : nullptr;
+          if (cscal) {
+            cscal[lane] = cs;
+            cscal[64 + lane] = dcs_f;
+            cscal[128 + lane] = att;
+            cscal[192 + lane] = datt_f;
+          }
           float dcs[K];
           if (first) {
             // every direction: dz1 = dradial_d (w_r + w_e) (radial == edge_attr, dh == 0): one shared tangent chain
@@ -656,6 +718,10 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_fast_kernel(DivParams 
               for (int r = 0; r < 16; ++r) dmu[r] = fmaf(dattu, m2[r], dmu[r]);
             }
             const float vcdmu = xhalf_sum(dot16(vc, dmu));
+            if (crec) {
+              cache_store16(crec, lane, dmu);
+              cscal[256 + lane] = vcdmu;
+            }
 #pragma unroll
             for (int d = 0; d < K; ++d) {
               const float w_ = dradial[d] * aggw;
@@ -676,6 +742,11 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_fast_kernel(DivParams 
             qv *= g1 * F16_UNSCALE;
             const float qr = DIV_ST * xhalf_sum(dot16(qv, lds_vec16(vd + EH)));
             const float qe = DIV_ST * xhalf_sum(dot16(qv, lds_vec16(vd + 2 * EH)));
+            if (crec) {
+              cache_store16(crec, lane, qv);
+              cscal[256 + lane] = qr;
+              cscal[320 + lane] = qe;
+            }
 #pragma unroll
             for (int d = 0; d < K; ++d) {
               const f32x16 dz1 = (DAL ? lds_vec16(dA + d * C::PB_F + col[T] * PBS + hh * 16) : dAr[DAL ? 0 : d]) +
@@ -685,6 +756,12 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_fast_kernel(DivParams 
             }
           } else {
             const f32x16 g2s = g2 * F16_UNSCALE;
+            if (crec) {
+              cache_store16(crec, lane, g1);
+              cache_store16(crec + 1024, lane, g2s);
+              cache_store16(crec + 2048, lane, m2);
+              cache_store16(crec + 3072, lane, vc);
+            }
 #pragma unroll
             for (int d = 0; d < K; ++d) {
               f32x16 dz = (DAL ? lds_vec16(dA + d * C::PB_F + col[T] * PBS + hh * 16) : dAr[DAL ? 0 : d]) +
@@ -739,6 +816,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_fast_kernel(DivParams 
           f32x16 yn, gn;
           silu_dsilu16(zn, F16_UNSCALE, yn, gn);
           gn *= F16_UNSCALE;
+          if (clay) cache_store16(clay + CA::POSF + (size_t)T * CA::tile_f(l, L), lane, gn);
           wn.load(nullptr, mats16h, M_WN2, lane);
           f32x16 o = wn.mul(yn, lds_vec16(vl + V_BN2 * EH));
           o *= F16_UNSCALE;
@@ -827,6 +905,314 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_fast_kernel(DivParams 
   }
 }
 
+
+// Tangent-only kernel: K unit directions per launch from the primal cache written by egnn_div_fast_kernel (same grid,
+// same walker quota, hence the same walker groups).  Per edge it recomputes the geometry from the cached layer
+// positions (same expressions as the fast kernel: same bits), loads the edge record and runs exactly the tangent
+// arithmetic of the fast kernel; no primal GEMM, no activation.  Wa dh_i lives in registers (no primal state competes
+// for them), so the LDS budget goes to K = 6 partner tables.
+template <int N, int DIM, int G, int WAVES, int K>
+struct DivTanCfg {
+  static constexpr int NCOL = G * N;
+  static constexpr int NT = (NCOL + 31) / 32;
+  static constexpr int NCOLP = NT * 32;
+  static constexpr int PB_F = NCOLP * PBS;
+  static constexpr int POS_F = NCOLP * DIM;
+  static constexpr int WAVE_F = K * PB_F + 2 * POS_F + 3 * K * POS_F;  // dPB[K]; pos, pos0; dpos[K][2], dpos0[K]
+  static __host__ __device__ constexpr int vec_f(int L) { return ((VEC_EMB_F + L * VEC_LAYER_F) + 3) & ~3; }
+  static __host__ __device__ constexpr size_t lds_bytes(int L) {
+    return sizeof(float) * (size_t)(vec_f(L) + WAVES * WAVE_F);
+  }
+};
+
+template <int N, int DIM, int G, int WAVES, int K>
+__global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_tangent_kernel(DivParams p) {
+  using C = DivTanCfg<N, DIM, G, WAVES, K>;
+  constexpr int NT = C::NT;
+  using CA = DivCache<N, DIM, NT>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int L = p.n_layers;
+  const int vec_f = C::vec_f(L);
+  for (int i = threadIdx.x; i < VEC_EMB_F + L * VEC_LAYER_F; i += WAVES * 64) lds[i] = p.vecs_h[i];
+  __syncthreads();
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cl = lane & 31, hh = lane >> 5;
+  float* dPB = lds + vec_f + wave * C::WAVE_F;     // [K][PB_F]  DIV_ST x Wb dh_j
+  float* posc = dPB + K * C::PB_F;                 // positions entering the current layer
+  float* pos0 = posc + C::POS_F;
+  float* dposb = pos0 + C::POS_F;                  // [K][2][POS_F]
+  float* dpos0 = dposb + 2 * K * C::POS_F;         // [K][POS_F]
+  const f32x16 zero16 = {0};
+
+  const long long total_waves = (long long)gridDim.x * WAVES;
+  const long long quota = (p.B + total_waves - 1) / total_waves;
+  const long long wbeg = ((long long)blockIdx.x * WAVES + wave) * quota;
+  const long long wend = (wbeg + quota < p.B) ? wbeg + quota : p.B;
+  const long long groups_per_wave = (quota + G - 1) / G;
+  for (long long walker0 = wbeg; walker0 < wend; walker0 += G) {
+    const int nwalk = (int)((wend - walker0) < G ? (wend - walker0) : G);
+    const int ncol = nwalk * N;
+    const int ntile = (ncol + 31) >> 5;
+    const float* cgrp = p.cache + (size_t)(((long long)blockIdx.x * WAVES + wave) * groups_per_wave + (walker0 - wbeg) / G) *
+                                      CA::group_f(L);
+    int col[NT], nodei[NT];
+    bool valid[NT];
+    float c_s[NT], cc[NT];
+    float dposi[NT][K][DIM], dp0i[NT][K][DIM];
+    f32x16 dhf[NT][K];
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+      col[T] = T * 32 + cl;
+      const int w = col[T] / N;
+      nodei[T] = col[T] - w * N;
+      valid[T] = col[T] < ncol;
+      const long long wid = valid[T] ? walker0 + w : p.B - 1;
+      const float hv = p.h[wid];
+      const float op = 1.0f + hv, rs = 1.0f / sqrtf(op);
+      c_s[T] = 1.0f / op;
+      cc[T] = (sqrtf(hv) * rs) * rs;  // c_out c_in
+#pragma unroll
+      for (int k = 0; k < DIM; ++k)
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+          const float v = (valid[T] && q < p.ndir && nodei[T] * DIM + k == p.dir0 + q) ? 1.0f : 0.f;
+          dposi[T][q][k] = v;
+          dp0i[T][q][k] = v;
+          if (hh == 0) {
+            dpos0[q * C::POS_F + col[T] * DIM + k] = v;
+            dposb[(2 * q) * C::POS_F + col[T] * DIM + k] = v;
+          }
+        }
+#pragma unroll
+      for (int q = 0; q < K; ++q) dhf[T][q] = zero16;
+    }
+    for (int i = lane; i < C::POS_F; i += 64) pos0[i] = cgrp[i];  // layer 0's entry positions are pos0
+    wave_lds_fence();
+
+    int cur = 0;
+    for (int l = 0; l < L; ++l) {
+      const unsigned* mats16h = p.mats16h + (size_t)l * M_COUNT * MAT_WH;
+      const bool first = (l == 0), last = (l == L - 1) && !first;
+      const float* clay = cgrp + CA::layer_off(l, L);
+      for (int i = lane; i < C::POS_F; i += 64) posc[i] = clay[i];
+      if (!first) {
+        WFrag<2> wb;
+        wb.load(nullptr, mats16h, M_WB, lane);
+#pragma unroll
+        for (int T = 0; T < NT; ++T) {
+          if (T >= ntile) continue;
+#pragma unroll
+          for (int d = 0; d < K; ++d) {
+            f32x16 dpb = wb.mul(dhf[T][d], zero16);
+            dpb *= F16_UNSCALE;
+            f32x4* ddst = reinterpret_cast<f32x4*>(dPB + d * C::PB_F + col[T] * PBS + hh * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ddst[q] = f32x4{dpb[4 * q], dpb[4 * q + 1], dpb[4 * q + 2], dpb[4 * q + 3]};
+          }
+        }
+      }
+      wave_lds_fence();
+      WFrag<2> w2f;
+      if (!first && !last) w2f.load(nullptr, mats16h, M_W2, lane);
+      const float a_re = lds[VEC_EMB_F + l * VEC_LAYER_F + V_WRE * EH + lane];
+      const float aggw = (l == L - 1) ? 0.0f : 1.0f;
+#pragma unroll
+      for (int T = 0; T < NT; ++T) {
+        if (T >= ntile) continue;
+        f32x16 dAr[K];
+        if (!first) {
+          WFrag<2> wa;
+          wa.load(nullptr, mats16h, M_WA, lane);
+#pragma unroll
+          for (int d = 0; d < K; ++d) {
+            dAr[d] = wa.mul(dhf[T][d], zero16);
+            dAr[d] *= F16_UNSCALE;
+          }
+        }
+        f32x16 dagg[K];
+        float dxacc[K][DIM], pown[DIM], p0own[DIM];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          pown[k] = posc[col[T] * DIM + k];
+          p0own[k] = pos0[col[T] * DIM + k];
+        }
+#pragma unroll
+        for (int d = 0; d < K; ++d) {
+          dagg[d] = zero16;
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) dxacc[d][k] = 0.f;
+        }
+        const int cbase = col[T] - nodei[T];
+        const float* ctile = clay + CA::POSF + (size_t)T * CA::tile_f(l, L);
+        for (int dd = 1; dd < N; ++dd) {
+          asm volatile("" ::: "memory");
+          int j = nodei[T] + dd;
+          j = (j >= N) ? j - N : j;
+          const int cj = (col[T] < ncol) ? cbase + j : col[T];
+          const float* crec = ctile + 1024 + (size_t)(dd - 1) * CA::edge_f(l, L);
+          const float* cscal = crec + (size_t)CA::nvec(l, L) * 1024;
+          const float cs = cscal[lane], dcs_f = cscal[64 + lane];
+          float df[DIM], e0[DIM], radial = 0.f;
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) {
+            df[k] = pown[k] - posc[cj * DIM + k];
+            radial = fmaf(df[k], df[k], radial);
+            e0[k] = p0own[k] - pos0[cj * DIM + k];
+          }
+          const float sq = __builtin_amdgcn_sqrtf(radial + 1e-8f), inv = __builtin_amdgcn_rcpf(sq + 1.0f);
+          const float hsq = 0.5f * __builtin_amdgcn_rcpf(sq);
+          float u[DIM];
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) u[k] = df[k] * inv;
+          float ddf[K][DIM], dradial[K], dea[K];
+#pragma unroll
+          for (int d = 0; d < K; ++d) {
+            const float* dposcur = dposb + (2 * d + cur) * C::POS_F;
+            dradial[d] = 0.f;
+            dea[d] = 0.f;
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+              ddf[d][k] = dposi[T][d][k] - dposcur[cj * DIM + k];
+              dradial[d] = fmaf(df[k], ddf[d][k], dradial[d]);
+              dea[d] = fmaf(e0[k], dp0i[T][d][k] - dpos0[d * C::POS_F + cj * DIM + k], dea[d]);
+            }
+            dradial[d] *= 2.0f;
+            dea[d] *= 2.0f;
+          }
+          float dcs[K];
+          if (first) {
+            const f32x16 dmu = cache_load16(crec, lane);
+            const float vcdmu = cscal[256 + lane];
+#pragma unroll
+            for (int d = 0; d < K; ++d) {
+              const float w_ = dradial[d] * aggw;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) dagg[d][r] = fmaf(dmu[r], w_, dagg[d][r]);
+              dcs[d] = dcs_f * (dradial[d] * vcdmu);
+            }
+          } else if (last) {
+            const f32x16 qv = cache_load16(crec, lane);
+            const float qr = cscal[256 + lane], qe = cscal[320 + lane];
+#pragma unroll
+            for (int d = 0; d < K; ++d) {
+              const f32x16 dz1 = dAr[d] + lds_vec16(dPB + d * C::PB_F + cj * PBS + hh * 16);
+              const float sdot = xhalf_sum(dot16(qv, dz1));
+              dcs[d] = dcs_f * fmaf(qr, dradial[d], fmaf(qe, dea[d], sdot));
+            }
+          } else {
+            const f32x16 g1 = cache_load16(crec, lane), g2s = cache_load16(crec + 1024, lane);
+            const f32x16 m2 = cache_load16(crec + 2048, lane), vc = cache_load16(crec + 3072, lane);
+            const float att = cscal[128 + lane], datt_f = cscal[192 + lane];
+            const f32x16 v_watt = lds_vec16(lds + VEC_EMB_F + l * VEC_LAYER_F + hh * 16 + V_WATT * EH);
+#pragma unroll
+            for (int d = 0; d < K; ++d) {
+              f32x16 dz = dAr[d] + lds_vec16(dPB + d * C::PB_F + cj * PBS + hh * 16);
+              dz = __builtin_amdgcn_mfma_f32_32x32x2f32(a_re, DIV_ST * (hh ? dea[d] : dradial[d]), dz, 0, 0, 0);
+              dz *= g1;
+              dz = w2f.mul(dz, zero16);
+              dz *= g2s;  // dm2
+              f32x16 dm = dz * att;
+              if (p.attention) {
+                const float datt = datt_f * xhalf_sum(dot16(v_watt, dz));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dm[r] = fmaf(datt, m2[r], dm[r]);
+              }
+#pragma unroll
+              for (int r = 0; r < 16; ++r) dagg[d][r] = fmaf(dm[r], aggw, dagg[d][r]);
+              dcs[d] = dcs_f * xhalf_sum(dot16(vc, dm));
+            }
+          }
+#pragma unroll
+          for (int d = 0; d < K; ++d) {
+            const float dnrm = dradial[d] * hsq;
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+              const float du = (ddf[d][k] - u[k] * dnrm) * inv;
+              dxacc[d][k] = fmaf(du, cs, fmaf(u[k], dcs[d], dxacc[d][k]));
+            }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < DIM; ++k)
+#pragma unroll
+          for (int d = 0; d < K; ++d) {
+            dposi[T][d][k] += dxacc[d][k];
+            if (hh == 0) dposb[(2 * d + (cur ^ 1)) * C::POS_F + col[T] * DIM + k] = dposi[T][d][k];
+          }
+        if (l != L - 1) {
+          const f32x16 gn = cache_load16(ctile, lane);
+          WFrag<2> wn;
+          f32x16 dzn[K];
+          if (!first) {
+            wn.load(nullptr, mats16h, M_WN1A, lane);
+#pragma unroll
+            for (int d = 0; d < K; ++d) dzn[d] = wn.mul(dhf[T][d], zero16);
+          } else {
+#pragma unroll
+            for (int d = 0; d < K; ++d) dzn[d] = zero16;
+          }
+          wn.load(nullptr, mats16h, M_WN1B, lane);
+#pragma unroll
+          for (int d = 0; d < K; ++d) dzn[d] = wn.mul(dagg[d], dzn[d]);
+          wn.load(nullptr, mats16h, M_WN2, lane);
+#pragma unroll
+          for (int d = 0; d < K; ++d) {
+            dzn[d] *= gn;
+            f32x16 dho = wn.mul(dzn[d], zero16);
+            dho *= F16_UNSCALE;
+            dhf[T][d] += dho;
+          }
+        }
+      }
+      wave_lds_fence();
+      cur ^= 1;
+    }
+
+    // epilogue: as egnn_div_fast_kernel
+    float* dscr = dPB;  // [K][NCOLP*DIM]
+    float* tsl = dPB + K * C::POS_F;  // [G][K]
+#pragma unroll
+    for (int T = 0; T < NT; ++T)
+#pragma unroll
+      for (int d = 0; d < K; ++d)
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          dposi[T][d][k] -= dp0i[T][d][k];  // dF
+          if (hh == 0) dscr[d * C::POS_F + col[T] * DIM + k] = dposi[T][d][k];
+        }
+    if (lane < G * K) tsl[lane] = 0.f;
+    wave_lds_fence();
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+      const int cb = (col[T] < ncol) ? col[T] - nodei[T] : 0;
+#pragma unroll
+      for (int d = 0; d < K; ++d)
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          if (!(valid[T] && hh == 0 && d < p.ndir && nodei[T] * DIM + k == p.dir0 + d)) continue;
+          float ds = 0.f;
+          for (int q = 0; q < N; ++q) ds += dscr[d * C::POS_F + (cb + q) * DIM + k];
+          const float dF = dposi[T][d][k] - ds / (float)N;
+          tsl[(col[T] / N) * K + d] = fmaf(cc[T], dF, c_s[T]);
+        }
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+      const int w = col[T] / N;
+      float sum = 0.f;
+#pragma unroll
+      for (int d = 0; d < K; ++d) sum += tsl[(valid[T] ? w : 0) * K + d];
+      if (valid[T] && hh == 0 && nodei[T] == 0) {
+        const bool bad = !__builtin_isfinite(sum);
+        if (!bad) p.diag_acc[walker0 + w] += sum;
+        p.mark[walker0 + w] = bad ? 1 : 0;
+      }
+    }
+    wave_lds_fence();
+  }
+}
+
 struct DivShape {
   int n, dim, G, waves, K;
   void (*kernel)(DivParams);
@@ -864,6 +1250,42 @@ static const DivShape* find_div_shape(int n, int dim) {
 }
 // f16 kernel with more directions per launch than the bf16x3 kernel's LDS budget allows (Wa dh_i in registers);
 // PITA_DIV_FAST_K=0 falls back to the bf16x3 kernel's K (development aid)
+// tangent-only kernels (primal cache): same G / WAVES as the fast kernel of the particle system
+struct DivTanShape {
+  int n, dim, G, waves, K;
+  void (*kernel)(DivParams);
+  size_t (*lds_bytes)(int);
+  size_t (*group_f)(int);  // cache floats per walker group
+};
+template <int N, int DIM, int G, int WAVES, int K>
+static size_t divtan_lds_of(int L) { return DivTanCfg<N, DIM, G, WAVES, K>::lds_bytes(L); }
+template <int N, int DIM, int G>
+static size_t divcache_group_f(int L) { return DivCache<N, DIM, (G * N + 31) / 32>::group_f(L); }
+#define PITA_DIVTAN_SHAPE(N, DIM, G, WAVES, K) \
+  DivTanShape { N, DIM, G, WAVES, K, egnn_div_tangent_kernel<N, DIM, G, WAVES, K>, divtan_lds_of<N, DIM, G, WAVES, K>, \
+                divcache_group_f<N, DIM, G> }
+// LJ13, all 39 directions at 65 536 walkers (first launch 5.7 ms incl. the 12 GB cache write): K = 3: 34.9 ms, K = 4:
+// 32.9 ms (9 launches of 3.0 ms = 4 TB/s of cache reads), K = 5: 39.6 ms, K = 6: 44.0 ms (528 / 860 B/lane of scratch);
+// without the cache (13 fast launches): 59-62 ms.
+static const DivTanShape kDivTan[] = {
+    PITA_DIVTAN_SHAPE(4, 2, 8, 4, 5),
+    PITA_DIVTAN_SHAPE(13, 3, 2, 4, 4),
+    PITA_DIVTAN_SHAPE(22, 3, 1, 4, 4),
+    PITA_DIVTAN_SHAPE(55, 3, 1, 4, 3),
+};
+static const DivTanShape kDivTanAlt[] = {PITA_DIVTAN_SHAPE(13, 3, 2, 4, 3)};  // PITA_DIV_TAN_K=3
+static const DivTanShape* find_div_tan_shape(int n, int dim) {
+  static const bool off = getenv("PITA_DIV_NOCACHE") != nullptr;  // development aid: A/B against the cache-free path
+  if (off) return nullptr;
+  static const int altk = getenv("PITA_DIV_TAN_K") ? atoi(getenv("PITA_DIV_TAN_K")) : 0;
+  if (altk)
+    for (const auto& c : kDivTanAlt)
+      if (c.n == n && c.dim == dim && c.K == altk) return &c;
+  for (const auto& c : kDivTan)
+    if (c.n == n && c.dim == dim) return &c;
+  return nullptr;
+}
+
 // measured: K = 4 for LJ13 (PITA_DIV_FAST_SHAPE(13, 3, 2, 4, 4)): 65.3 ms for the 39 directions against 61.9 ms with K = 3
 // (800 B/lane of scratch: the fourth direction's state no longer fits the 512 registers) -- not instantiated
 static const DivShape* find_div_fast_shape(int n, int dim) { return find_div_shape(n, dim); }
@@ -883,8 +1305,8 @@ extern "C" int pita_egnn_div_directions(const pita_egnn_t* net) {
   return s ? s->K : PITA_EUNSUPPORTED;
 }
 
-// Matrix-core wave-instructions per walker for one FULL trace (all D directions) on the path the handle takes, counted on
-// the kernels' loop structure (bench.py: roofline of the debiased leg).  Fast kernel per column tile and launch: primal
+// Matrix-core wave-instructions per walker for one FULL trace (all D directions) on the path pita_egnn_jacobian_trace takes
+// with this handle, counted on the kernels' loop structure (bench.py: roofline of the debiased leg).  Fast kernel per column tile and launch: primal
 // 6 (Wb) + 6 (Wa) + (N-1)(18 f16 + 1 f32 k-step) per layer, + 6 x 3 node-model GEMMs except in the last layer; tangents:
 // first layer one shared W2 chain per edge (6), middle layers K (6 f16 + 1 f32) per edge, last layer one W2^T chain (6)
 // per edge; per direction 6 x (Wb, Wa, Wn1a) from the second layer on and 6 x (Wn1b, Wn2) in every layer but the last.
@@ -893,10 +1315,12 @@ extern "C" int pita_egnn_div_work(const pita_egnn_t* net, double* mfma16_per_wal
   const DivShape* s = find_div_shape(net->cfg.n_particles, net->cfg.n_dim);
   if (!s) return fail(PITA_EUNSUPPORTED, "pita_egnn_div_work: no kernel for this particle system");
   const int N = s->n, K = s->K, L = net->cfg.n_layers, D = s->n * s->dim;
-  const double launches = (D + K - 1) / K;
+  double launches = (D + K - 1) / K;
   const double tiles_per_walker = (double)((s->G * N + 31) / 32) / s->G;
-  double m16 = 0, m32 = 0;
-  if (div_fast_enabled(net)) {
+  double m16 = 0, m32 = 0, t16 = 0, t32 = 0;  // per tile: one K-direction launch with primal; one tangent-only direction
+  const bool fast = div_fast_enabled(net);
+  const bool cached = fast && find_div_tan_shape(N, s->dim) != nullptr && D > K;
+  if (fast) {
     for (int l = 0; l < L; ++l) {
       const bool first = l == 0, lastl = l == L - 1;
       m16 += 12 + (N - 1) * 18.0 + (lastl ? 0 : 18);
@@ -906,6 +1330,10 @@ extern "C" int pita_egnn_div_work(const pita_egnn_t* net, double* mfma16_per_wal
       else { m16 += (N - 1) * 6.0 * K; m32 += (N - 1) * K; }
       if (!first) m16 += 12.0 * K + (lastl ? 0 : 6.0 * K);
       if (!lastl) m16 += 12.0 * K;
+      // tangent-only kernel, per direction: Wb, Wa from the second layer on; W2 per edge in middle layers; node model
+      if (!first) t16 += 12.0 + (lastl ? 0 : 6.0);
+      if (!first && !lastl) { t16 += (N - 1) * 6.0; t32 += N - 1; }
+      if (!lastl) t16 += 12.0;
     }
   } else {  // bf16x3 kernel: 12 MFMAs per dense layer, every tangent repeats the primal's GEMMs
     for (int l = 0; l < L; ++l) {
@@ -915,6 +1343,11 @@ extern "C" int pita_egnn_div_work(const pita_egnn_t* net, double* mfma16_per_wal
       m16 += K * ((N - 1) * 24.0 + (first ? 0 : 24) + (lastl ? 0 : (first ? 24 : 36)));
       m32 += K * (N - 1);
     }
+  }
+  if (cached) {  // pita_egnn_jacobian_trace: one launch with the primal, the other D - K directions from the cache
+    *mfma16_per_walker = (m16 + (D - K) * t16) * tiles_per_walker;
+    *mfma32_per_walker = (m32 + (D - K) * t32) * tiles_per_walker;
+    return PITA_OK;
   }
   *mfma16_per_walker = m16 * tiles_per_walker * launches;
   *mfma32_per_walker = m32 * tiles_per_walker * launches;
@@ -974,6 +1407,112 @@ extern "C" int pita_egnn_div_accumulate(pita_egnn_t* net, const float* h, const 
     p.out = (d0 == 0) ? out : nullptr;
     rc = div_launch(s, s->kernel, net, p, stream);
     if (rc != PITA_OK) return rc;
+  }
+  return PITA_OK;
+}
+
+
+// Exact trace of the denoiser Jacobian over ALL directions: trace[b] = sum_d (J_x D(h, x) e_d)_d (overwritten), optionally
+// the denoiser itself.  Precision-2 handles with a tangent-only kernel take the primal-cache path: ONE launch of the fast
+// kernel (first K directions, writes the per-edge primal factors), then tangent-only launches of up to six directions
+// that stream the cache -- each followed by the bf16x3 repair pass for marked walkers.  The cache (≈180 KB per walker for
+// LJ13) is owned by the handle; batches whose cache would exceed PITA_DIV_CACHE_GB (default 24) are processed in chunks
+// of walkers.  Other handles loop pita_egnn_div_accumulate.
+extern "C" int pita_egnn_jacobian_trace(pita_egnn_t* net, const float* h, const float* x, const float* beta, float* trace,
+                                        float* denoiser_out, int64_t B, void* stream) {
+  PITA_REQUIRE(net && B >= 0, "pita_egnn_jacobian_trace: bad argument");
+  if (B == 0) return PITA_OK;
+  PITA_REQUIRE(h && x && trace, "pita_egnn_jacobian_trace: null argument");
+  PITA_REQUIRE(beta || net->cfg.in_node_nf == 1, "pita_egnn_jacobian_trace: beta required for in_node_nf=2");
+  const int n = net->cfg.n_particles, dim = net->cfg.n_dim, D = n * dim, L = net->cfg.n_layers;
+  const DivShape* s = find_div_shape(n, dim);
+  if (!s) return fail(PITA_EUNSUPPORTED, "pita_egnn_jacobian_trace: no kernel for this particle system");
+  hipStream_t st = (hipStream_t)stream;
+  PITA_HIP_CHECK(hipMemsetAsync(trace, 0, sizeof(float) * (size_t)B, st));
+  const DivTanShape* ts = div_fast_enabled(net) ? find_div_tan_shape(n, dim) : nullptr;
+  if (!ts || ts->G != s->G || ts->waves != s->waves || D <= s->K) {
+    const int K = pita_egnn_div_directions(net);
+    for (int d0 = 0; d0 < D; d0 += K) {
+      const int rc = pita_egnn_div_accumulate(net, h, x, beta, d0, (D - d0) < K ? (D - d0) : K, trace,
+                                              d0 == 0 ? denoiser_out : nullptr, B, stream);
+      if (rc != PITA_OK) return rc;
+    }
+    return PITA_OK;
+  }
+  // walkers per chunk: the cache of a chunk must fit the budget
+  static const double budget_gb = getenv("PITA_DIV_CACHE_GB") ? atof(getenv("PITA_DIV_CACHE_GB")) : 24.0;
+  const double per_walker = 4.0 * (double)ts->group_f(L) / s->G;
+  long long chunk = (long long)(budget_gb * 1e9 / per_walker);
+  chunk = chunk / 1024 * 1024;
+  if (chunk < 1024) chunk = 1024;
+  if (chunk > B) chunk = B;
+  for (long long b0 = 0; b0 < B; b0 += chunk) {
+    const long long Bc = (B - b0) < chunk ? (B - b0) : chunk;
+    DivParams p{};
+    p.mats16 = net->d_mats16; p.mats16h = net->d_mats16h; p.vecs = net->d_vecs; p.vecs_h = net->d_vecs_h;
+    p.vecs_div = net->d_vecs_div;
+    p.n_layers = L; p.in_nf = net->cfg.in_node_nf;
+    p.attention = net->cfg.attention; p.tanh_on = net->cfg.tanh; p.feature_layout = net->cfg.feature_layout;
+    p.coord_scale = net->cfg.coords_range / (float)L;
+    p.B = Bc; p.h = h + b0; p.x = x + b0 * D; p.beta = beta ? beta + b0 : nullptr; p.diag_acc = trace + b0;
+    // grid of the fast / tangent kernels (identical: the cache is indexed by wave and group)
+    const long long ngroups = (Bc + s->G - 1) / s->G;
+    long long want = (ngroups + s->waves - 1) / s->waves;
+    const long long grid = want < (long long)net->n_cu ? want : (long long)net->n_cu;
+    const long long total_waves = grid * s->waves;
+    const long long quota = (Bc + total_waves - 1) / total_waves;
+    const long long groups_per_wave = (quota + s->G - 1) / s->G;
+    const size_t need = sizeof(float) * ts->group_f(L) * (size_t)(total_waves * groups_per_wave);
+    if (need > net->divcache_bytes) {
+      PITA_HIP_CHECK(hipStreamSynchronize(st));
+      (void)hipFree(net->d_divcache);
+      net->d_divcache = nullptr;
+      net->divcache_bytes = 0;
+      PITA_HIP_CHECK(hipMalloc(&net->d_divcache, need));
+      net->divcache_bytes = need;
+    }
+    if (sizeof(int) * (size_t)Bc > net->mark_bytes) {
+      PITA_HIP_CHECK(hipStreamSynchronize(st));
+      (void)hipFree(net->d_mark);
+      net->d_mark = nullptr;
+      net->mark_bytes = 0;
+      PITA_HIP_CHECK(hipMalloc(&net->d_mark, sizeof(int) * (size_t)Bc));
+      net->mark_bytes = sizeof(int) * (size_t)Bc;
+    }
+    p.mark = net->d_mark;
+    p.cache = net->d_divcache;
+    auto repair = [&](int dir0, int ndir, float* out) -> int {  // bf16x3 kernel for the marked walkers, its own K at a time
+      DivParams r = p;
+      r.repair = 1;
+      r.cache = nullptr;
+      for (int d0 = 0; d0 < ndir; d0 += s->K) {
+        r.dir0 = dir0 + d0;
+        r.ndir = (ndir - d0) < s->K ? (ndir - d0) : s->K;
+        r.out = (d0 == 0) ? out : nullptr;
+        const int rc = div_launch(s, s->kernel, net, r, stream);
+        if (rc != PITA_OK) return rc;
+      }
+      return PITA_OK;
+    };
+    // first K directions: primal + tangents, cache written
+    p.dir0 = 0; p.ndir = s->K < D ? s->K : D; p.out = denoiser_out ? denoiser_out + b0 * D : nullptr;
+    int rc = div_launch(s, s->fast, net, p, stream);
+    if (rc != PITA_OK) return rc;
+    rc = repair(0, p.ndir, p.out);
+    if (rc != PITA_OK) return rc;
+    // remaining directions from the cache
+    p.out = nullptr;
+    const size_t lds = ts->lds_bytes(L);
+    PITA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ts->kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds));
+    for (int d0 = s->K; d0 < D; d0 += ts->K) {
+      p.dir0 = d0;
+      p.ndir = (D - d0) < ts->K ? (D - d0) : ts->K;
+      hipLaunchKernelGGL(ts->kernel, dim3((unsigned)grid), dim3(s->waves * 64), lds, st, p);
+      PITA_LAUNCH_CHECK();
+      rc = repair(d0, p.ndir, nullptr);
+      if (rc != PITA_OK) return rc;
+    }
   }
   return PITA_OK;
 }

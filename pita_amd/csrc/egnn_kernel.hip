@@ -782,6 +782,7 @@ extern "C" int pita_egnn_destroy(pita_egnn_t* net) {
   (void)hipFree(net->d_ws);
   (void)hipFree(net->d_bk);
   (void)hipFree(net->d_mark);
+  (void)hipFree(net->d_divcache);
   delete net;
   return PITA_OK;
 }

@@ -184,25 +184,21 @@ class EGNN_dynamics(nn.Module):
         return out, dout
 
     def jacobian_trace(self, h_t, x_t, beta, want_denoiser=False):
-        """trace(J_x D_theta(h, x)) per walker, exactly: dim unit directions, K per launch sharing the primal
-        evaluation (pita_egnn_div_accumulate).  ``want_denoiser``: also return D_theta(h, x), a by-product of the
-        first launch's primal -> (trace, D)."""
+        """trace(J_x D_theta(h, x)) per walker, exactly, over all dim unit directions (pita_egnn_jacobian_trace: the
+        primal network is evaluated once, its per-edge factors cached for the tangent-only launches that follow).
+        ``want_denoiser``: also return D_theta(h, x), a by-product of the primal -> (trace, D)."""
         x_t = _lib.dev_tensor(x_t, "x_t")
         B, D = x_t.shape
         h_t = _lib.dev_tensor(h_t, "h_t").reshape(-1).expand(B).contiguous()
         b = _as_batch(beta, B, x_t.device) if self.condition_temperature else None
         L = _lib.lib()
         net = self._native(x_t.device)
-        K = L.pita_egnn_div_directions(net)
-        if K < 1:
-            raise _lib.PitaHipError("pita_egnn_div_directions: no divergence kernel for this particle system")
-        trace = torch.zeros(B, device=x_t.device)
+        trace = torch.empty(B, device=x_t.device)
         den = torch.empty_like(x_t) if want_denoiser else None
-        st = _lib.stream_ptr(x_t.device)
-        for d0 in range(0, D, K):
-            _lib.check(L.pita_egnn_div_accumulate(net, h_t.data_ptr(), x_t.data_ptr(), _lib.ptr(b), d0, min(K, D - d0),
-                                                  trace.data_ptr(), _lib.ptr(den) if d0 == 0 else None, B, st),
-                       "pita_egnn_div_accumulate")
+        with torch.cuda.device(x_t.device):
+            _lib.check(L.pita_egnn_jacobian_trace(net, h_t.data_ptr(), x_t.data_ptr(), _lib.ptr(b), trace.data_ptr(),
+                                                  _lib.ptr(den), B, _lib.stream_ptr(x_t.device)),
+                       "pita_egnn_jacobian_trace")
         return (trace, den) if want_denoiser else trace
 
     def vjp(self, h_t, x_t, beta, cot=None, want_primal=True, want_dot_h=False):
