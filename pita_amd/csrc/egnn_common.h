@@ -273,8 +273,13 @@ __device__ __forceinline__ float dot16(const f32x16& w, const f32x16& m) {
 }
 
 __device__ __forceinline__ float xhalf_sum(float v) {
-  // add the value held by the partner lane (l ^ 32): the other 16 features of the same column
-  return v + __shfl_xor(v, 32, 64);
+  // add the value held by the partner lane (l ^ 32): the other 16 features of the same column.  v_permlane32_swap_b32
+  // (gfx950) exchanges the upper half of one register with the lower half of another inside the VALU: after swapping two
+  // copies of v, one holds (lo, lo) and the other (hi, hi) -- no LDS round trip (ds_bpermute) on the edge loop's critical
+  // path (attention gate, coordinate head).  lo + hi in every lane: the same bits as v + shfl_xor(v, 32).
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 }  // namespace pita
