@@ -293,6 +293,7 @@ struct pita_egnn {
   float* d_vecs_h = nullptr;     // the same vectors with the PREC 2 scale factors folded in
   float* d_vecs_div = nullptr;   // [L][4][32] fragment order: DIV_ST kS (w_r + w_e), kS w_r, kS w_e, DIV_SV w_c2 / kS
   const void* shape = nullptr;   // pita::EgnnShape of egnn_kernel.hip
+  const void* shape_small = nullptr;  // optional mapping with fewer walkers per wave, for batches that underfill the GPU
   int n_cu = 256;
   float* d_ws = nullptr;         // reverse-mode checkpoint scratch (egnn_vjp_kernel.hip), grown on demand
   size_t ws_bytes = 0;

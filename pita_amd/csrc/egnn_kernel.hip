@@ -518,6 +518,13 @@ static const EgnnShape kShapes[] = {
     PITA_EGNN_SHAPE(22, 3, 4, 4, 2),
     PITA_EGNN_SHAPE(55, 3, 1, 4, 2),
 };
+// Fewer walkers per wave for batches that cannot give every SIMD two waves with the mapping above (a lone wave issues a
+// vector instruction every ~5 cycles, two waves one every ~2.5: tools/ubench/isa_rates.hip): more, shorter waves at a
+// lower column fill.  Results do not depend on the grouping (tested bitwise).
+static const EgnnShape kShapesSmall[] = {
+    PITA_EGNN_SHAPE(13, 3, 2, 4, 2),
+    PITA_EGNN_SHAPE(22, 3, 2, 4, 2),
+};
 
 }  // namespace pita
 
@@ -545,8 +552,11 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
   PITA_REQUIRE(n_weights == pita_egnn_num_weights(cfg), "pita_egnn_create: got %lld weights, expected %lld",
                (long long)n_weights, (long long)pita_egnn_num_weights(cfg));
   const EgnnShape* shape = nullptr;
+  const EgnnShape* shape_small = nullptr;
   for (const auto& s : kShapes)
     if (s.n == cfg->n_particles && s.dim == cfg->n_dim) shape = &s;
+  for (const auto& s : kShapesSmall)
+    if (s.n == cfg->n_particles && s.dim == cfg->n_dim) shape_small = &s;
   const int H = EH, L = cfg->n_layers, nf = cfg->in_node_nf;
   const size_t n_mats = (size_t)L * M_COUNT * MAT_F, n_vecs = VEC_EMB_F + (size_t)L * VEC_LAYER_F;
   float* h_mats = new float[n_mats];
@@ -719,6 +729,7 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
   pita_egnn* net = new pita_egnn();
   net->cfg = *cfg;
   net->shape = shape;
+  net->shape_small = shape_small;
   hipError_t e1 = hipMalloc(&net->d_mats, n_mats * sizeof(float));
   hipError_t e2 = hipMalloc(&net->d_vecs, n_vecs * sizeof(float));
   hipError_t e0 = hipMalloc(&net->d_mats16, n_mats16 * sizeof(unsigned));
@@ -760,9 +771,13 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
   size_t lds = shape->lds_bytes(L);
   hipError_t e3 = hipSuccess;
   for (int a = 0; a < 3 && e3 == hipSuccess; ++a)
-    for (int b = 0; b < 2 && e3 == hipSuccess; ++b)
+    for (int b = 0; b < 2 && e3 == hipSuccess; ++b) {
       e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(shape->kernel[a][b]),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e3 == hipSuccess && shape_small)
+        e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(shape_small->kernel[a][b]),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shape_small->lds_bytes(L));
+    }
   if (e3 != hipSuccess) {
     pita_egnn_destroy(net);
     return fail(PITA_EHIP, "pita_egnn_create: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e3));
@@ -787,8 +802,18 @@ extern "C" int pita_egnn_destroy(pita_egnn_t* net) {
   return PITA_OK;
 }
 
-static int egnn_launch(pita_egnn_t* net, EgnnParams& p, void* stream) {
+// the mapping for a batch of B walkers: the small-group shape when the regular one leaves SIMDs with a single wave
+static const EgnnShape* shape_for(const pita_egnn_t* net, long long B) {
   const EgnnShape* s = static_cast<const EgnnShape*>(net->shape);
+  const EgnnShape* t = static_cast<const EgnnShape*>(net->shape_small);
+  if (!t) return s;
+  const long long two_per_simd = (long long)net->n_cu * 8;  // waves
+  const long long waves_s = (B + s->G - 1) / s->G;
+  return waves_s < two_per_simd ? t : s;
+}
+
+static int egnn_launch(pita_egnn_t* net, EgnnParams& p, void* stream) {
+  const EgnnShape* s = shape_for(net, p.B);
   const int prec = net->cfg.precision;
   p.mats = net->d_mats;
   p.mats16 = net->d_mats16;
@@ -847,7 +872,7 @@ static int egnn_launch(pita_egnn_t* net, EgnnParams& p, void* stream) {
 extern "C" int pita_egnn_sampler_work(const pita_egnn_t* net, int64_t B, double* mfma16_per_walker_step,
                                       double* mfma32_per_walker_step) {
   PITA_REQUIRE(net && B > 0 && mfma16_per_walker_step && mfma32_per_walker_step, "pita_egnn_sampler_work: bad argument");
-  const EgnnShape* s = static_cast<const EgnnShape*>(net->shape);
+  const EgnnShape* s = shape_for(net, B);
   const int L = net->cfg.n_layers, N = s->n, G = s->G;
   const size_t lds = s->lds_bytes(L);
   int blocks_per_cu = (int)((160 * 1024) / lds);
