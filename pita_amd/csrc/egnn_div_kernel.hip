@@ -1266,7 +1266,10 @@ static size_t divcache_group_f(int L) { return DivCache<N, DIM, (G * N + 31) / 3
                 divcache_group_f<N, DIM, G> }
 // LJ13, all 39 directions at 65 536 walkers (first launch 5.7 ms incl. the 12 GB cache write): K = 3: 34.9 ms, K = 4:
 // 32.9 ms (9 launches of 3.0 ms = 4 TB/s of cache reads), K = 5: 39.6 ms, K = 6: 44.0 ms (528 / 860 B/lane of scratch);
-// without the cache (13 fast launches): 59-62 ms.
+// without the cache (13 fast launches): 59-62 ms.  Also measured: the four waves of a block sharing ONE walker group with
+// K = 2 directions each at two waves per SIMD, every wave streaming the same records and counting on the L2 for the
+// repeats: 46.4 ms -- each wave's stream goes to HBM (5 launches of 8 ms = 4 x 12 GB at 5.5 TB/s); sharing would have to
+// be explicit (records staged once per block in LDS).
 static const DivTanShape kDivTan[] = {
     PITA_DIVTAN_SHAPE(4, 2, 8, 4, 5),
     PITA_DIVTAN_SHAPE(13, 3, 2, 4, 4),
