@@ -35,7 +35,8 @@ struct DivParams {
   const float* h;     // [B] sigma^2
   const float* x;     // [B, D]
   const float* beta;  // [B] or null
-  int dir0, ndir;     // unit directions dir0 .. dir0 + ndir - 1 (ndir <= K)
+  int dir0, ndir;     // unit directions dir0 .. dir0 + ndir - 1 (ndir <= K; block-shared tangent kernel: <= NW K)
+  long long cache_waves;  // block-shared tangent kernel: waves of the launch that wrote the cache (its group layout)
   float* diag_acc;    // [B] += sum_k dD_k[b, dir0 + k]
   float* out;         // [B, D] denoiser D of the primal (nullable: the caller asks for it with the first launch only)
 };
@@ -398,13 +399,18 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_kernel(DivParams p) {
 // egnn_div_tangent_kernel runs the remaining directions from that cache, six per launch, without touching the primal:
 // ≈180 KB per walker (12 GB at 65 536 walkers: HBM capacity is what this GPU has to spare), streamed once per launch in
 // 1 KB wave-loads.  Layout per walker group g (a wave's G walkers) and layer l, in floats:
-//   [pos: POSF] then per tile T: [gn: 1024] [edge dd = 1..N-1: nv(l) x 1024 vectors | 8 x 64 scalars]
-// scalar slots: 0 cs, 1 dcs_f (incl. the tangent scales), 2 att, 3 att (1 - att), 4 vcdmu | qr, 5 qe.
+//   [pos: POSF] then per tile T: [edge dd = 1..N-1: nv(l) x 1024 vectors | 8 x 64 scalars] [gn: 1024]
+// scalar slots: 0 cs, 1 dcs_f (incl. the tangent scales), 2 att, 3 att (1 - att), 4 vcdmu | qr, 5 qe.  The position
+// block carries, behind the NT x 32 x DIM positions, c_skip and c_out c_in of every column (layer 0's block is the one
+// read).  Every item is a whole number of 1 KB chunks and a group's items lie in the order the tangent sweep consumes
+// them, so the block-shared tangent kernel can stream a group as plain 1 KB pieces.
 template <int N, int DIM, int NT>
 struct DivCache {
-  static constexpr int POSF = ((NT * 32 * DIM + 63) / 64) * 64;
+  static constexpr int POSX = NT * 32 * DIM;                          // offset of the per-column c_skip | c_out c_in
+  static constexpr int POSF = ((POSX + 2 * NT * 32 + 255) / 256) * 256;
   static __host__ __device__ int nvec(int l, int L) { return (l == 0 || l == L - 1) ? 1 : 4; }
   static __host__ __device__ size_t edge_f(int l, int L) { return (size_t)nvec(l, L) * 1024 + 512; }
+  static __host__ __device__ size_t gn_off(int l, int L) { return (size_t)(N - 1) * edge_f(l, L); }
   static __host__ __device__ size_t tile_f(int l, int L) { return 1024 + (size_t)(N - 1) * edge_f(l, L); }
   static __host__ __device__ size_t layer_f(int l, int L) { return POSF + (size_t)NT * tile_f(l, L); }
   static __host__ __device__ size_t group_f(int L) {
@@ -559,8 +565,15 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_fast_kernel(DivParams 
       const bool first = (l == 0), last = (l == L - 1) && !first;
       const float* poscur = posb + cur * C::POS_F;
       float* clay = cgrp ? cgrp + CA::layer_off(l, L) : nullptr;
-      if (clay)
+      if (clay) {
         for (int i = lane; i < C::POS_F; i += 64) clay[i] = poscur[i];
+        if (first && hh == 0)
+#pragma unroll
+          for (int T = 0; T < NT; ++T) {
+            clay[CA::POSX + col[T]] = c_s[T];
+            clay[CA::POSX + NT * 32 + col[T]] = c_out[T] * c_in[T];
+          }
+      }
       {
         WFrag<2> wb;
         wb.load(nullptr, mats16h, M_WB, lane);
@@ -697,7 +710,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_fast_kernel(DivParams 
             dradial[d] *= 2.0f;
             dea[d] *= 2.0f;
           }
-          float* crec = clay ? clay + CA::POSF + (size_t)T * CA::tile_f(l, L) + 1024 + (size_t)(dd - 1) * CA::edge_f(l, L)
+          float* crec = clay ? clay + CA::POSF + (size_t)T * CA::tile_f(l, L) + (size_t)(dd - 1) * CA::edge_f(l, L)
                              : nullptr;
           float* cscal = crec ? crec + (size_t)CA::nvec(l, L) * 1024 : nullptr;
           if (cscal) {
@@ -816,7 +829,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_fast_kernel(DivParams 
           f32x16 yn, gn;
           silu_dsilu16(zn, F16_UNSCALE, yn, gn);
           gn *= F16_UNSCALE;
-          if (clay) cache_store16(clay + CA::POSF + (size_t)T * CA::tile_f(l, L), lane, gn);
+          if (clay) cache_store16(clay + CA::POSF + (size_t)T * CA::tile_f(l, L) + CA::gn_off(l, L), lane, gn);
           wn.load(nullptr, mats16h, M_WN2, lane);
           f32x16 o = wn.mul(yn, lds_vec16(vl + V_BN2 * EH));
           o *= F16_UNSCALE;
@@ -1049,7 +1062,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_tangent_kernel(DivPara
           int j = nodei[T] + dd;
           j = (j >= N) ? j - N : j;
           const int cj = (col[T] < ncol) ? cbase + j : col[T];
-          const float* crec = ctile + 1024 + (size_t)(dd - 1) * CA::edge_f(l, L);
+          const float* crec = ctile + (size_t)(dd - 1) * CA::edge_f(l, L);
           const float* cscal = crec + (size_t)CA::nvec(l, L) * 1024;
           const float cs = cscal[lane], dcs_f = cscal[64 + lane];
           float df[DIM], e0[DIM], radial = 0.f;
@@ -1140,7 +1153,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_tangent_kernel(DivPara
             if (hh == 0) dposb[(2 * d + (cur ^ 1)) * C::POS_F + col[T] * DIM + k] = dposi[T][d][k];
           }
         if (l != L - 1) {
-          const f32x16 gn = cache_load16(ctile, lane);
+          const f32x16 gn = cache_load16(ctile + CA::gn_off(l, L), lane);
           WFrag<2> wn;
           f32x16 dzn[K];
           if (!first) {
@@ -1213,6 +1226,559 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_tangent_kernel(DivPara
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Block-shared tangent kernel.  The wave-owned kernel above runs one wave per SIMD (K = 4 directions need all 512
+// registers, a quarter of its instructions are v_accvgpr moves, and a lone wave issues at half the vector rate) and
+// every launch re-reads the whole cache for four directions.  Here the NW waves of a block (two per SIMD, K = 2
+// directions each: everything fits the 256 VALU-visible registers) work on the SAME walker group, so a group's cache
+// is streamed from HBM once per NW K directions.  The block moves it through an LDS ring with LDS-DMA
+// (global_load_lds_dwordx4: no registers, no staging instructions) in 1 KB pieces; the sweep consumes it in ITEMS of
+// at most SHR_S = 18 pieces (one middle-layer edge record; three first/last-layer records; a layer's [Wb Wa W2 |
+// positions]; a tile's [Wn1a Wn1b Wn2 | gn]), every item padded to SHR_S pieces in the piece numbering, so that an
+// item is one contiguous ring slot (compile-time LDS offsets) and piece F of the sequence is issued by wave F mod NW
+// into ring position F mod (NSLOT SHR_S).  Per item ONE workgroup barrier:
+//     wait for my own pieces of the item (counted s_waitcnt vmcnt) -> barrier -> refill the slots of the items already
+//     consumed by every wave -> compute from LDS.
+// No other vector-memory instruction runs inside the stream -- loads return in order, so any register load (or a
+// register spill: scratch is vector memory) would wait behind the whole prefetch window: the layer's weight
+// fragments travel through the ring as well (4 KB lane-linear blocks, L2-resident, spliced into the group's sequence
+// where the sweep needs them; padding pieces re-read the first weight block), c_skip / c_out c_in arrive with the
+// position block, results are parked in LDS and flushed every RES_G groups behind a full drain -- so the hand-counted
+// vmcnt is exact.
+constexpr int SHR_LMAX = 4;  // layers the block-shared kernel's LDS budget is sized for
+constexpr int SHR_S = 18;  // pieces per item slot: one middle-layer edge record (4 vectors + 2 KB of scalars)
+template <int N, int DIM, int G, int NW, int K>
+struct DivShrCfg {
+  static constexpr int NCOL = G * N;
+  static constexpr int NT = (NCOL + 31) / 32;
+  static constexpr int NCOLP = NT * 32;
+  static constexpr int PB_F = NCOLP * PBS;
+  static constexpr int POS_F = NCOLP * DIM;
+  static constexpr int WAVE_F = K * PB_F + 3 * K * POS_F;   // dPB[K]; dpos[K][2], dpos0[K]
+  static constexpr int RES_G = 32;                           // groups between result flushes
+  static constexpr int MAX_P = 128 * NW;                     // pieces of one group's sequence (two table registers per wave)
+  // pos, pos0; c_s, cc; comb; res, walker0; piece table (+ count)
+  static constexpr int SHARED_F = 2 * POS_F + 2 * NCOLP + NW * G + RES_G * G + RES_G + MAX_P + 4;
+  static constexpr int LMAX = SHR_LMAX;
+  static __host__ __device__ constexpr int vec_f(int L) { return ((VEC_EMB_F + L * VEC_LAYER_F) + 3) & ~3; }
+  static constexpr int FIXED_F = ((vec_f(LMAX) + SHARED_F + NW * WAVE_F) + 255) & ~255;
+  // ring slots: what the 160 KB leave (the ring sits at the bottom of the allocation)
+  static constexpr int NSLOT = (160 * 1024 - 4 * FIXED_F) / (SHR_S * 1024);
+  // an item is loaded by D waves (SHR_S / D pieces each), item j by waves (j D) mod NW ...; a wave's turns are NW / D
+  // items apart, at least the NSLOT - 1 items of prefetch distance, so it never has two batches in flight and "my part
+  // of this item has landed" is vmcnt(0)
+  static constexpr int D = (NW % 3 == 0 && NW / 3 >= NSLOT) ? 3 : ((NW % 2 == 0 && NW / 2 >= NSLOT) ? 2 : 1);
+  static constexpr int PPW = SHR_S / D;
+  static_assert(NSLOT >= 3 && NW / D >= NSLOT && SHR_S % D == 0, "ring / duty split");
+  static __host__ __device__ constexpr size_t lds_bytes(int) { return (size_t)NSLOT * SHR_S * 1024 + sizeof(float) * (size_t)FIXED_F; }
+};
+
+// workgroup barrier that leaves vector-memory operations in flight (__syncthreads() drains them)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+// LDS-DMA of one 1 KB piece: lane i's 16 bytes from sbase + voff land at LDS byte lds_byte + 16 i
+__device__ __forceinline__ void glds16s(unsigned lds_byte, const float* sbase, unsigned voff) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+}
+// at most n of this wave's vector-memory operations pending (rare path: start and end of the stream)
+__device__ __forceinline__ void wait_vmcnt_upto(int n) {
+#define PITA_VMW(k) asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory")
+  if (n >= 8) { if (n >= 12) PITA_VMW(12); else PITA_VMW(8); }
+  else if (n >= 4) { if (n >= 6) PITA_VMW(6); else if (n == 5) PITA_VMW(5); else PITA_VMW(4); }
+  else if (n >= 2) { if (n == 3) PITA_VMW(3); else PITA_VMW(2); }
+  else if (n == 1) PITA_VMW(1);
+  else PITA_VMW(0);
+#undef PITA_VMW
+}
+template <int N_>
+__device__ __forceinline__ void wait_vmcnt_const() {
+#define PITA_VMC(k) if constexpr (N_ == k) asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory")
+  PITA_VMC(1); PITA_VMC(2); PITA_VMC(3); PITA_VMC(4); PITA_VMC(5); PITA_VMC(6); PITA_VMC(7); PITA_VMC(8);
+  PITA_VMC(9); PITA_VMC(10); PITA_VMC(11); PITA_VMC(12); PITA_VMC(13); PITA_VMC(14); PITA_VMC(15); PITA_VMC(16);
+#undef PITA_VMC
+}
+__device__ __forceinline__ f32x16 slot_vec16(const float* rec, int v, int lane) {  // vector v of a record (cache_store16 layout)
+  const f32x4* d = reinterpret_cast<const f32x4*>(rec + v * 1024) + lane;
+  f32x16 r;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 t = d[q * 64];
+    r[4 * q] = t.x; r[4 * q + 1] = t.y; r[4 * q + 2] = t.z; r[4 * q + 3] = t.w;
+  }
+  return r;
+}
+__device__ __forceinline__ WFrag<2> slot_wfrag(const float* item, int m, int lane) {  // matrix block m of an item (WFrag<2>::load layout)
+  const u32x4* d = reinterpret_cast<const u32x4*>(item + m * MAT_WH) + lane;
+  WFrag<2> f;
+#pragma unroll
+  for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+    for (int st = 0; st < 2; ++st) f.w[pc][st] = d[(pc * 2 + st) * 64];
+  return f;
+}
+
+template <int N, int DIM, int G, int NW, int K>
+__global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(DivParams p) {
+  using C = DivShrCfg<N, DIM, G, NW, K>;
+  constexpr int NT = C::NT;
+  constexpr int S = SHR_S;
+  using CA = DivCache<N, DIM, NT>;
+  static_assert(12 + CA::POSF / 256 <= S && MAT_WH == 1024, "an item must fit a ring slot");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int L = p.n_layers;
+  constexpr int NSLOT = C::NSLOT, RC = NSLOT * S;
+  float* ring = lds;                                 // [NSLOT][S][256]
+  float* vecs = lds + RC * 256;
+  for (int i = threadIdx.x; i < VEC_EMB_F + L * VEC_LAYER_F; i += NW * 64) vecs[i] = p.vecs_h[i];
+  float* posc = vecs + C::vec_f(C::LMAX);            // block-shared: positions entering the current layer
+  float* pos0 = posc + C::POS_F;
+  float* cstab = pos0 + C::POS_F;                    // [NCOLP] c_skip, [NCOLP] c_out c_in
+  float* comb = cstab + 2 * C::NCOLP;                // [NW][G]
+  float* res = comb + NW * G;                        // [RES_G][G]
+  int* resw = reinterpret_cast<int*>(res + C::RES_G * G);  // [RES_G] first walker of the group
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, cl = lane & 31, hh = lane >> 5;
+  int* ptab = resw + C::RES_G;                       // [MAX_P] source of every piece of a group's sequence: bit 31 weights / cache, piece offset; then the count
+  float* dPB = reinterpret_cast<float*>(ptab + C::MAX_P + 4) + wave * C::WAVE_F;  // [K][PB_F]  DIV_ST x Wb dh_j
+  float* dposb = dPB + K * C::PB_F;                  // [K][2][POS_F]
+  float* dpos0 = dposb + 2 * K * C::POS_F;           // [K][POS_F]
+  const unsigned ring_byte = (unsigned)(size_t)ring;
+  const f32x16 zero16 = {0};
+  // this wave's directions
+  const int mydir0 = p.dir0 + wave * K;
+  const int myndir = (p.ndir - wave * K) < 0 ? 0 : ((p.ndir - wave * K) > K ? K : (p.ndir - wave * K));
+  const bool active = myndir > 0;
+
+  // walker groups as the fast kernel laid them out: cache_waves waves of `quota` walkers, gpw groups each
+  const long long cwaves = p.cache_waves;
+  const long long quota = (p.B + cwaves - 1) / cwaves;
+  const long long gpw = (quota + G - 1) / G;
+  const long long total_groups = cwaves * gpw;
+  const size_t group_f = CA::group_f(L);
+  if (threadIdx.x == 0) {  // the pieces of one group's sweep, item by item (every item padded to S pieces)
+    int np = 0;
+    auto add = [&](int kind, long long first_piece, int n) {
+      for (int q = 0; q < n && np < C::MAX_P; ++q) ptab[np++] = (int)((kind ? 0x80000000u : 0u) | (unsigned)(first_piece + q));
+    };
+    for (int l = 0; l < L; ++l) {
+      const bool first = (l == 0), last = (l == L - 1) && !first;
+      int n = 0;
+      if (!first) {  // Wa, Wb[, W2]: consecutive blocks of the layer's matrices
+        n = last ? 8 : 12;
+        add(1, ((long long)l * M_COUNT + M_WA) * 4, n);
+      }
+      const long long lo = (long long)(CA::layer_off(l, L) / 256);
+      add(0, lo, CA::POSF / 256);
+      add(1, 0, S - n - CA::POSF / 256);
+      const int ep = (int)(CA::edge_f(l, L) / 256), epi = S / ep;
+      for (int T = 0; T < NT; ++T) {
+        const long long to = lo + CA::POSF / 256 + (long long)T * (long long)(CA::tile_f(l, L) / 256);
+        for (int q = 0; q < N - 1; q += epi) {
+          const int nrec = (N - 1 - q) < epi ? (N - 1 - q) : epi;
+          add(0, to + (long long)q * ep, nrec * ep);
+          add(1, 0, S - nrec * ep);
+        }
+        n = 0;
+        if (l != L - 1) {  // [Wn1a,] Wn1b, Wn2
+          n = first ? 8 : 12;
+          add(1, ((long long)l * M_COUNT + (first ? M_WN1B : M_WN1A)) * 4, n);
+        }
+        add(0, to + (long long)(CA::gn_off(l, L) / 256), 4);
+        add(1, 0, S - n - 4);
+      }
+    }
+    ptab[C::MAX_P] = np;
+  }
+  __syncthreads();
+  const int IPG = ptab[C::MAX_P] / S;  // items per group (host: fits MAX_P)
+  const int ngroups_i = (int)total_groups, gpw_i = (int)gpw, nblk = (int)gridDim.x;  // host: total_groups < 2^31
+  auto group_walkers = [&](int g, long long& w0) -> int {
+    const int wg = g / gpw_i, lg = g - wg * gpw_i;
+    w0 = (long long)wg * quota + (long long)lg * G;
+    long long we = (long long)(wg + 1) * quota;
+    we = we < p.B ? we : p.B;
+    const long long n = we - w0;
+    return (int)(n < 0 ? 0 : (n > G ? G : n));
+  };
+  auto next_group = [&](int g) -> int {
+    long long w0;
+    while (g < ngroups_i && group_walkers(g, w0) == 0) g += nblk;
+    return g;
+  };
+
+  // refill cursor (block-uniform): the next item to load is item ri of group rgrp, into ring slot rs; its D loading
+  // waves start at wave rt
+  constexpr int D = C::D, PPW = C::PPW;
+  int ri = 0, rs = 0, rt = 0;
+  int rgrp = next_group(blockIdx.x);
+  const float* wsrc = reinterpret_cast<const float*>(p.mats16h);
+  const float* gsrc = p.cache + (size_t)(rgrp < ngroups_i ? rgrp : 0) * group_f;
+  const unsigned lane16 = lane * 16;
+  auto load_next_item = [&]() {
+    if (rgrp >= ngroups_i) return;
+    const int d = wave - rt;
+    if ((unsigned)d < (unsigned)D) {
+      const int ents = ptab[ri * S + d * PPW + (lane < PPW ? lane : 0)];
+      const unsigned dst = ring_byte + (unsigned)(rs * S + d * PPW) * 1024u;
+#pragma unroll
+      for (int q = 0; q < PPW; ++q) {
+        const int ent = __builtin_amdgcn_readlane(ents, q);
+        glds16s(dst + q * 1024u, (ent < 0 ? wsrc : gsrc) + (size_t)(ent & 0x7fffffff) * 256, lane16);
+      }
+    }
+    rs = (rs + 1 == NSLOT) ? 0 : rs + 1;
+    rt = (rt + D == NW) ? 0 : rt + D;
+    if (++ri == IPG) {
+      ri = 0;
+      rgrp = next_group(rgrp + nblk);
+      if (rgrp < ngroups_i) gsrc = p.cache + (size_t)rgrp * group_f;
+    }
+  };
+  // consumer state: the current item sits in ring slot cslot and was loaded by waves ct .. ct + D - 1
+  int cslot = 0, ct = 0;
+  const float* item = ring;
+  auto begin_item = [&]() {
+    if ((unsigned)(wave - ct) < (unsigned)D) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my part of it has landed
+    lds_barrier();
+    load_next_item();  // into the slot of the item every wave has just left
+  };
+  auto end_item = [&]() {
+    cslot = (cslot + 1 == NSLOT) ? 0 : cslot + 1;
+    ct = (ct + D == NW) ? 0 : ct + D;
+    item = ring + cslot * (S * 256);
+  };
+  __syncthreads();
+  for (int q = 0; q < NSLOT - 1; ++q) load_next_item();
+
+  int nres = 0;
+  auto flush = [&]() {  // wave 0: add the parked results to the trace; a full drain keeps the piece count exact
+    if (wave == 0) {
+      for (int i = lane; i < nres * G; i += 64) {
+        const int gi = i / G, w = i - gi * G;
+        const float v = res[i];
+        if (!(v == 0.0f && __builtin_signbit(v))) {  // -0.0 marks "no such walker"
+          const long long wid = (long long)resw[gi] + w;
+          const bool bad = !__builtin_isfinite(v);
+          if (!bad) p.diag_acc[wid] += v;
+          p.mark[wid] = bad ? 1 : 0;
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    nres = 0;
+  };
+
+  for (int gid = next_group(blockIdx.x); gid < ngroups_i; gid = next_group(gid + nblk)) {
+    long long walker0;
+    const int nwalk = group_walkers(gid, walker0);
+    const int ncol = nwalk * N;
+    const int ntile = (ncol + 31) >> 5;
+    int col[NT], nodei[NT];
+    bool valid[NT];
+    float dposi[NT][K][DIM];
+    auto unit = [&](int T, int q, int k) -> float {  // component k of column col[T] of this wave's unit direction q
+      return (valid[T] && q < myndir && nodei[T] * DIM + k == mydir0 + q) ? 1.0f : 0.f;
+    };
+    f32x16 dhf[NT][K];
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+      col[T] = T * 32 + cl;
+      const int w = col[T] / N;
+      nodei[T] = col[T] - w * N;
+      valid[T] = col[T] < ncol;
+#pragma unroll
+      for (int k = 0; k < DIM; ++k)
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+          const float v = unit(T, q, k);
+          dposi[T][q][k] = v;
+          if (hh == 0) {
+            dpos0[q * C::POS_F + col[T] * DIM + k] = v;
+            dposb[(2 * q) * C::POS_F + col[T] * DIM + k] = v;
+          }
+        }
+#pragma unroll
+      for (int q = 0; q < K; ++q) dhf[T][q] = zero16;
+    }
+
+    int cur = 0;
+    for (int l = 0; l < L; ++l) {
+      const bool first = (l == 0), last = (l == L - 1) && !first;
+      // first item of the layer: [Wb Wa W2 |] position block; the positions are copied to the block's tables (the
+      // ring moves on), the fragments to registers
+      const int nwm = first ? 0 : (last ? 2 : 3);  // matrices ahead of the positions
+      begin_item();
+      {
+        const float* ipos = item + nwm * MAT_WH;
+        for (int i = threadIdx.x; i < C::POS_F; i += NW * 64) {
+          const float v = ipos[i];
+          posc[i] = v;
+          if (first) pos0[i] = v;
+        }
+        if (first)
+          for (int i = threadIdx.x; i < 2 * C::NCOLP; i += NW * 64) cstab[i] = ipos[CA::POSX + i];
+      }
+      WFrag<2> wa, w2f;
+      if (!first && active) {
+        const WFrag<2> wb = slot_wfrag(item, 1, lane);
+        wa = slot_wfrag(item, 0, lane);
+        if (!last) w2f = slot_wfrag(item, 2, lane);
+#pragma unroll
+        for (int T = 0; T < NT; ++T) {
+          if (T >= ntile) continue;
+#pragma unroll
+          for (int d = 0; d < K; ++d) {
+            f32x16 dpb = wb.mul(dhf[T][d], zero16);
+            dpb *= F16_UNSCALE;
+            f32x4* ddst = reinterpret_cast<f32x4*>(dPB + d * C::PB_F + col[T] * PBS + hh * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ddst[q] = f32x4{dpb[4 * q], dpb[4 * q + 1], dpb[4 * q + 2], dpb[4 * q + 3]};
+          }
+        }
+      }
+      end_item();
+      const float a_re = vecs[VEC_EMB_F + l * VEC_LAYER_F + V_WRE * EH + lane];
+      const float aggw = (l == L - 1) ? 0.0f : 1.0f;
+      const int nv = CA::nvec(l, L), erec = nv * 1024 + 512, epi = S / (nv * 4 + 2);  // floats per record, records per item
+#pragma unroll
+      for (int T = 0; T < NT; ++T) {
+        const bool tile_on = active && T < ntile;
+        f32x16 dAr[K];
+        if (!first && tile_on) {
+#pragma unroll
+          for (int d = 0; d < K; ++d) {
+            dAr[d] = wa.mul(dhf[T][d], zero16);
+            dAr[d] *= F16_UNSCALE;
+          }
+        }
+        f32x16 dagg[K];
+        float dxacc[K][DIM];
+#pragma unroll
+        for (int d = 0; d < K; ++d) {
+          dagg[d] = zero16;
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) dxacc[d][k] = 0.f;
+        }
+        const int cbase = col[T] - nodei[T];
+        for (int dd0 = 1; dd0 < N; dd0 += epi) {
+          begin_item();  // the barrier also orders this layer's posc / pos0 / dPB writes before their first use
+          for (int e = 0; e < epi && tile_on; ++e) {
+            const int dd = dd0 + e;
+            if (dd >= N) break;
+            const float* rec = item + e * erec;
+            int j = nodei[T] + dd;
+            j = (j >= N) ? j - N : j;
+            const int cj = (col[T] < ncol) ? cbase + j : col[T];
+            const float* sc = rec + nv * 1024;
+            const float cs = sc[lane], dcs_f = sc[64 + lane];
+            float df[DIM], e0[DIM], radial = 0.f;
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+              df[k] = posc[col[T] * DIM + k] - posc[cj * DIM + k];
+              radial = fmaf(df[k], df[k], radial);
+              e0[k] = pos0[col[T] * DIM + k] - pos0[cj * DIM + k];
+            }
+            const float sq = __builtin_amdgcn_sqrtf(radial + 1e-8f), inv = __builtin_amdgcn_rcpf(sq + 1.0f);
+            const float hsq = 0.5f * __builtin_amdgcn_rcpf(sq);
+            float u[DIM];
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) u[k] = df[k] * inv;
+            float ddf[K][DIM], dradial[K], dea[K];
+#pragma unroll
+            for (int d = 0; d < K; ++d) {
+              const float* dposcur = dposb + (2 * d + cur) * C::POS_F;
+              dradial[d] = 0.f;
+              dea[d] = 0.f;
+#pragma unroll
+              for (int k = 0; k < DIM; ++k) {
+                ddf[d][k] = dposi[T][d][k] - dposcur[cj * DIM + k];
+                dradial[d] = fmaf(df[k], ddf[d][k], dradial[d]);
+                dea[d] = fmaf(e0[k], unit(T, d, k) - dpos0[d * C::POS_F + cj * DIM + k], dea[d]);
+              }
+              dradial[d] *= 2.0f;
+              dea[d] *= 2.0f;
+            }
+            float dcs[K];
+            if (first) {
+              const f32x16 dmu = slot_vec16(rec, 0, lane);
+              const float vcdmu = sc[256 + lane];
+#pragma unroll
+              for (int d = 0; d < K; ++d) {
+                const float w_ = dradial[d] * aggw;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dagg[d][r] = fmaf(dmu[r], w_, dagg[d][r]);
+                dcs[d] = dcs_f * (dradial[d] * vcdmu);
+              }
+            } else if (last) {
+              const f32x16 qv = slot_vec16(rec, 0, lane);
+              const float qr = sc[256 + lane], qe = sc[320 + lane];
+#pragma unroll
+              for (int d = 0; d < K; ++d) {
+                const f32x16 dz1 = dAr[d] + lds_vec16(dPB + d * C::PB_F + cj * PBS + hh * 16);
+                const float sdot = xhalf_sum(dot16(qv, dz1));
+                dcs[d] = dcs_f * fmaf(qr, dradial[d], fmaf(qe, dea[d], sdot));
+              }
+            } else {
+              const float att = sc[128 + lane], datt_f = sc[192 + lane];
+              const float* wattp = vecs + VEC_EMB_F + l * VEC_LAYER_F + hh * 16 + V_WATT * EH;
+              // the K chains side by side: each record vector is read from the ring once, the chains' matrix
+              // instructions and LDS latencies overlap
+              f32x16 dz[K];
+              {
+                const f32x16 g1 = slot_vec16(rec, 0, lane);
+#pragma unroll
+                for (int d = 0; d < K; ++d) {
+                  dz[d] = dAr[d] + lds_vec16(dPB + d * C::PB_F + cj * PBS + hh * 16);
+                  dz[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_re, DIV_ST * (hh ? dea[d] : dradial[d]), dz[d], 0, 0, 0);
+                  dz[d] *= g1;
+                }
+              }
+              u32x4 xs[K][2][2];
+#pragma unroll
+              for (int d = 0; d < K; ++d) WFrag<2>::split(dz[d], xs[d]);
+#pragma unroll
+              for (int d = 0; d < K; ++d) dz[d] = w2f.mul_split(xs[d], zero16);
+              {
+                const f32x16 g2s = slot_vec16(rec, 1, lane);
+#pragma unroll
+                for (int d = 0; d < K; ++d) dz[d] *= g2s;  // dm2
+              }
+              float datt[K];
+              if (p.attention) {
+                const f32x16 v_watt = lds_vec16(wattp);
+#pragma unroll
+                for (int d = 0; d < K; ++d) datt[d] = datt_f * xhalf_sum(dot16(v_watt, dz[d]));
+              }
+#pragma unroll
+              for (int d = 0; d < K; ++d) dz[d] *= att;  // dm without the gate's own tangent
+              if (p.attention) {
+                const f32x16 m2 = slot_vec16(rec, 2, lane);
+#pragma unroll
+                for (int d = 0; d < K; ++d)
+#pragma unroll
+                  for (int r = 0; r < 16; ++r) dz[d][r] = fmaf(datt[d], m2[r], dz[d][r]);
+              }
+              {
+                const f32x16 vc = slot_vec16(rec, 3, lane);
+#pragma unroll
+                for (int d = 0; d < K; ++d) {
+#pragma unroll
+                  for (int r = 0; r < 16; ++r) dagg[d][r] = fmaf(dz[d][r], aggw, dagg[d][r]);
+                  dcs[d] = dcs_f * xhalf_sum(dot16(vc, dz[d]));
+                }
+              }
+            }
+#pragma unroll
+            for (int d = 0; d < K; ++d) {
+              const float dnrm = dradial[d] * hsq;
+#pragma unroll
+              for (int k = 0; k < DIM; ++k) {
+                const float du = (ddf[d][k] - u[k] * dnrm) * inv;
+                dxacc[d][k] = fmaf(du, cs, fmaf(u[k], dcs[d], dxacc[d][k]));
+              }
+            }
+          }
+          end_item();
+        }
+        if (tile_on) {
+#pragma unroll
+          for (int k = 0; k < DIM; ++k)
+#pragma unroll
+            for (int d = 0; d < K; ++d) {
+              dposi[T][d][k] += dxacc[d][k];
+              if (hh == 0) dposb[(2 * d + (cur ^ 1)) * C::POS_F + col[T] * DIM + k] = dposi[T][d][k];
+            }
+        }
+        const int nnm = (l == L - 1) ? 0 : (first ? 2 : 3);  // node-model matrices ahead of gn
+        begin_item();
+        if (tile_on && l != L - 1) {
+          const f32x16 gn = slot_vec16(item, nnm, lane);
+          f32x16 dzn[K];
+          if (!first) {
+            const WFrag<2> wn = slot_wfrag(item, 0, lane);
+#pragma unroll
+            for (int d = 0; d < K; ++d) dzn[d] = wn.mul(dhf[T][d], zero16);
+          } else {
+#pragma unroll
+            for (int d = 0; d < K; ++d) dzn[d] = zero16;
+          }
+          {
+            const WFrag<2> wn = slot_wfrag(item, nnm - 2, lane);
+#pragma unroll
+            for (int d = 0; d < K; ++d) dzn[d] = wn.mul(dagg[d], dzn[d]);
+          }
+          const WFrag<2> wn = slot_wfrag(item, nnm - 1, lane);
+#pragma unroll
+          for (int d = 0; d < K; ++d) {
+            dzn[d] *= gn;
+            f32x16 dho = wn.mul(dzn[d], zero16);
+            dho *= F16_UNSCALE;
+            dhf[T][d] += dho;
+          }
+        }
+        end_item();
+      }
+      cur ^= 1;
+    }
+
+    // epilogue: as egnn_div_fast_kernel, per wave for its own directions, then the block's waves are summed in order
+    float* dscr = dPB;                 // [K][NCOLP*DIM]
+    float* tsl = dPB + K * C::POS_F;   // [G][K]
+    wave_lds_fence();
+#pragma unroll
+    for (int T = 0; T < NT; ++T)
+#pragma unroll
+      for (int d = 0; d < K; ++d)
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          dposi[T][d][k] -= unit(T, d, k);  // dF
+          if (hh == 0) dscr[d * C::POS_F + col[T] * DIM + k] = dposi[T][d][k];
+        }
+    if (lane < G * K) tsl[lane] = 0.f;
+    wave_lds_fence();
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+      const int cb = (col[T] < ncol) ? col[T] - nodei[T] : 0;
+#pragma unroll
+      for (int d = 0; d < K; ++d)
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          if (!(valid[T] && hh == 0 && d < myndir && nodei[T] * DIM + k == mydir0 + d)) continue;
+          float ds = 0.f;
+          for (int q = 0; q < N; ++q) ds += dscr[d * C::POS_F + (cb + q) * DIM + k];
+          const float dF = dposi[T][d][k] - ds / (float)N;
+          tsl[(col[T] / N) * K + d] = fmaf(cstab[C::NCOLP + col[T]], dF, cstab[col[T]]);
+        }
+    }
+    wave_lds_fence();
+    if (lane < G) {
+      float sum = 0.f;
+#pragma unroll
+      for (int d = 0; d < K; ++d) sum += tsl[lane * K + d];
+      comb[wave * G + lane] = sum;
+    }
+    lds_barrier();
+    if (wave == 0 && lane < G) {
+      float sum = 0.f;
+      for (int w = 0; w < NW; ++w) sum += comb[w * G + lane];
+      res[nres * G + lane] = (lane < nwalk) ? sum : -0.0f;
+      if (lane == 0) resw[nres] = (int)walker0;
+    }
+    ++nres;
+    if (nres == C::RES_G) {
+      wave_lds_fence();
+      flush();
+    }
+  }
+  wave_lds_fence();
+  flush();
+}
+
 struct DivShape {
   int n, dim, G, waves, K;
   void (*kernel)(DivParams);
@@ -1253,6 +1819,7 @@ static const DivShape* find_div_shape(int n, int dim) {
 // tangent-only kernels (primal cache): same G / WAVES as the fast kernel of the particle system
 struct DivTanShape {
   int n, dim, G, waves, K;
+  int shared;              // 1: block-shared kernel (`waves` waves on one walker group, waves x K directions per launch)
   void (*kernel)(DivParams);
   size_t (*lds_bytes)(int);
   size_t (*group_f)(int);  // cache floats per walker group
@@ -1262,7 +1829,12 @@ static size_t divtan_lds_of(int L) { return DivTanCfg<N, DIM, G, WAVES, K>::lds_
 template <int N, int DIM, int G>
 static size_t divcache_group_f(int L) { return DivCache<N, DIM, (G * N + 31) / 32>::group_f(L); }
 #define PITA_DIVTAN_SHAPE(N, DIM, G, WAVES, K) \
-  DivTanShape { N, DIM, G, WAVES, K, egnn_div_tangent_kernel<N, DIM, G, WAVES, K>, divtan_lds_of<N, DIM, G, WAVES, K>, \
+  DivTanShape { N, DIM, G, WAVES, K, 0, egnn_div_tangent_kernel<N, DIM, G, WAVES, K>, divtan_lds_of<N, DIM, G, WAVES, K>, \
+                divcache_group_f<N, DIM, G> }
+template <int N, int DIM, int G, int NW, int K>
+static size_t divshr_lds_of(int L) { return DivShrCfg<N, DIM, G, NW, K>::lds_bytes(L); }
+#define PITA_DIVSHR_SHAPE(N, DIM, G, NW, K) \
+  DivTanShape { N, DIM, G, NW, K, 1, egnn_div_tangent_shared_kernel<N, DIM, G, NW, K>, divshr_lds_of<N, DIM, G, NW, K>, \
                 divcache_group_f<N, DIM, G> }
 // LJ13, all 39 directions at 65 536 walkers (first launch 5.7 ms incl. the 12 GB cache write): K = 3: 34.9 ms, K = 4:
 // 32.9 ms (9 launches of 3.0 ms = 4 TB/s of cache reads), K = 5: 39.6 ms, K = 6: 44.0 ms (528 / 860 B/lane of scratch);
@@ -1270,22 +1842,40 @@ static size_t divcache_group_f(int L) { return DivCache<N, DIM, (G * N + 31) / 3
 // K = 2 directions each at two waves per SIMD, every wave streaming the same records and counting on the L2 for the
 // repeats: 46.4 ms -- each wave's stream goes to HBM (5 launches of 8 ms = 4 x 12 GB at 5.5 TB/s); sharing would have to
 // be explicit (records staged once per block in LDS).
+// Block-shared kernel (LDS-DMA ring), same batch: (8 waves, K = 2) 26.3 ms, (12 waves, K = 1) 25.6-26.3 ms, (6 waves, K = 2)
+// 28.5 ms: three launches of 6.3-6.8 ms that stream the cache once per 16 / 12 directions.  Per launch the LDS pipe is
+// busy ~3 ms (every wave reads the records it shares: 24 KB per direction and middle-layer edge), the vector ALUs ~2 ms,
+// the scalar ALU (one per CU: the ring bookkeeping of all waves) ~1 ms, the stream alone takes 2.1-2.5 ms; the waves
+// run in lock step (one barrier per item), so these overlap only partly.
 static const DivTanShape kDivTan[] = {
     PITA_DIVTAN_SHAPE(4, 2, 8, 4, 5),
-    PITA_DIVTAN_SHAPE(13, 3, 2, 4, 4),
-    PITA_DIVTAN_SHAPE(22, 3, 1, 4, 4),
+    PITA_DIVSHR_SHAPE(13, 3, 2, 8, 2),
+    PITA_DIVSHR_SHAPE(22, 3, 1, 8, 2),
     PITA_DIVTAN_SHAPE(55, 3, 1, 4, 3),
 };
-static const DivTanShape kDivTanAlt[] = {PITA_DIVTAN_SHAPE(13, 3, 2, 4, 3)};  // PITA_DIV_TAN_K=3
-static const DivTanShape* find_div_tan_shape(int n, int dim) {
+// wave-owned kernels for the systems above that default to the block-shared one (networks deeper than its LDS budget
+// is sized for; PITA_DIV_TAN_ALT=1 selects them for A/B runs), then experiments (PITA_DIV_TAN_ALT=<index + 1>)
+static const DivTanShape kDivTanAlt[] = {PITA_DIVTAN_SHAPE(13, 3, 2, 4, 4), PITA_DIVTAN_SHAPE(22, 3, 1, 4, 4),
+                                         PITA_DIVSHR_SHAPE(13, 3, 2, 12, 1)};
+static const DivTanShape* find_div_tan_shape(int n, int dim, int n_layers) {
   static const bool off = getenv("PITA_DIV_NOCACHE") != nullptr;  // development aid: A/B against the cache-free path
   if (off) return nullptr;
-  static const int altk = getenv("PITA_DIV_TAN_K") ? atoi(getenv("PITA_DIV_TAN_K")) : 0;
-  if (altk)
-    for (const auto& c : kDivTanAlt)
-      if (c.n == n && c.dim == dim && c.K == altk) return &c;
+  static const int alt = getenv("PITA_DIV_TAN_ALT") ? atoi(getenv("PITA_DIV_TAN_ALT")) : 0;
+  const int nalt = (int)(sizeof(kDivTanAlt) / sizeof(kDivTanAlt[0]));
+  if (alt == 1) {
+    for (int i = 0; i < 2; ++i)
+      if (kDivTanAlt[i].n == n && kDivTanAlt[i].dim == dim) return &kDivTanAlt[i];
+  } else if (alt >= 2 && alt <= nalt) {
+    const auto& c = kDivTanAlt[alt - 1];
+    if (c.n == n && c.dim == dim && (!c.shared || n_layers <= SHR_LMAX)) return &c;
+  }
   for (const auto& c : kDivTan)
-    if (c.n == n && c.dim == dim) return &c;
+    if (c.n == n && c.dim == dim) {
+      if (!c.shared || n_layers <= SHR_LMAX) return &c;
+      for (int i = 0; i < 2; ++i)
+        if (kDivTanAlt[i].n == n && kDivTanAlt[i].dim == dim) return &kDivTanAlt[i];
+      return nullptr;
+    }
   return nullptr;
 }
 
@@ -1322,7 +1912,7 @@ extern "C" int pita_egnn_div_work(const pita_egnn_t* net, double* mfma16_per_wal
   const double tiles_per_walker = (double)((s->G * N + 31) / 32) / s->G;
   double m16 = 0, m32 = 0, t16 = 0, t32 = 0;  // per tile: one K-direction launch with primal; one tangent-only direction
   const bool fast = div_fast_enabled(net);
-  const bool cached = fast && find_div_tan_shape(N, s->dim) != nullptr && D > K;
+  const bool cached = fast && find_div_tan_shape(N, s->dim, L) != nullptr && D > K;
   if (fast) {
     for (int l = 0; l < L; ++l) {
       const bool first = l == 0, lastl = l == L - 1;
@@ -1432,8 +2022,8 @@ extern "C" int pita_egnn_jacobian_trace(pita_egnn_t* net, const float* h, const 
   if (!s) return fail(PITA_EUNSUPPORTED, "pita_egnn_jacobian_trace: no kernel for this particle system");
   hipStream_t st = (hipStream_t)stream;
   PITA_HIP_CHECK(hipMemsetAsync(trace, 0, sizeof(float) * (size_t)B, st));
-  const DivTanShape* ts = div_fast_enabled(net) ? find_div_tan_shape(n, dim) : nullptr;
-  if (!ts || ts->G != s->G || ts->waves != s->waves || D <= s->K) {
+  const DivTanShape* ts = div_fast_enabled(net) ? find_div_tan_shape(n, dim, L) : nullptr;
+  if (!ts || ts->G != s->G || (!ts->shared && ts->waves != s->waves) || D <= s->K) {
     const int K = pita_egnn_div_directions(net);
     for (int d0 = 0; d0 < D; d0 += K) {
       const int rc = pita_egnn_div_accumulate(net, h, x, beta, d0, (D - d0) < K ? (D - d0) : K, trace,
@@ -1484,6 +2074,8 @@ extern "C" int pita_egnn_jacobian_trace(pita_egnn_t* net, const float* h, const 
     }
     p.mark = net->d_mark;
     p.cache = net->d_divcache;
+    p.cache_waves = total_waves;
+    PITA_REQUIRE(total_waves * groups_per_wave < 0x7fffffffLL, "pita_egnn_jacobian_trace: too many walker groups in one chunk");
     auto repair = [&](int dir0, int ndir, float* out) -> int {  // bf16x3 kernel for the marked walkers, its own K at a time
       DivParams r = p;
       r.repair = 1;
@@ -1508,10 +2100,13 @@ extern "C" int pita_egnn_jacobian_trace(pita_egnn_t* net, const float* h, const 
     const size_t lds = ts->lds_bytes(L);
     PITA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ts->kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds));
-    for (int d0 = s->K; d0 < D; d0 += ts->K) {
+    const int per_launch = ts->shared ? ts->K * ts->waves : ts->K;
+    const long long tgrid = !ts->shared ? grid : (total_waves * groups_per_wave < (long long)net->n_cu
+                                                      ? total_waves * groups_per_wave : (long long)net->n_cu);
+    for (int d0 = s->K; d0 < D; d0 += per_launch) {
       p.dir0 = d0;
-      p.ndir = (D - d0) < ts->K ? (D - d0) : ts->K;
-      hipLaunchKernelGGL(ts->kernel, dim3((unsigned)grid), dim3(s->waves * 64), lds, st, p);
+      p.ndir = (D - d0) < per_launch ? (D - d0) : per_launch;
+      hipLaunchKernelGGL(ts->kernel, dim3((unsigned)tgrid), dim3(ts->waves * 64), lds, st, p);
       PITA_LAUNCH_CHECK();
       rc = repair(d0, p.ndir, nullptr);
       if (rc != PITA_OK) return rc;
