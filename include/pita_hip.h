@@ -56,6 +56,16 @@ int pita_lj_logp_force(const float* x, float* logp, float* force /*nullable*/, i
                        int n_particles, int n_dim, float temperature, float energy_factor,
                        float dist_eps, float eps, float rm, float osc_scale, void* stream);
 
+/* The same target with the reference's smooth core (LennardJonesEnergy(smooth=True),
+ * pita/src/energies/lennardjones_energy.py:39-54,114-119,131-133): for r < range_min the pair energy is the first
+ * interval of the cubic spline fitted to the LJ curve on [range_min, range_max] -- coef4 = its four coefficients
+ * (host memory; scipy CubicSpline(...).c[:, 0] as the reference computes them), evaluated as
+ * c0 u^3 + c1 u^2 + c2 u + c3 with u = r - range_min.  The force is the analytic derivative of that expression. */
+int pita_lj_smooth_logp_force(const float* x, float* logp, float* force /*nullable*/, int64_t B,
+                              int n_particles, int n_dim, float temperature, float energy_factor,
+                              float dist_eps, float eps, float rm, float osc_scale, float range_min,
+                              const float* coef4, void* stream);
+
 /* DW4-style multi double well  E = sum_{i<j} a (d-d0)^4 + b (d-d0)^2 + c.
  * Not present in the reference tree (only a dead import, base_datamodule.py:13); formula of
  * bgflow.MultiDoubleWellPotential. */

@@ -224,6 +224,50 @@ def lj_logp_force(x: Tensor, n_particles: int, n_dim: int, temperature: float = 
     return lj_logp(x, n_particles, n_dim, temperature, energy_factor, dist_eps, eps, rm, osc_scale), force
 
 
+def lj_smooth_coeffs(range_min: float = 0.65, range_max: float = 2.0, interpolation: int = 1000, eps: float = 1.0,
+                     rm: float = 1.0) -> Tuple[Tensor, Tensor]:
+    """(breakpoints x [interpolation], coefficients c [4, interpolation-1]) of the spline the reference fits in
+    LennardJonesPotential.__init__ (lennardjones_energy.py:114-119): scipy CubicSpline through the float32 LJ curve."""
+    from scipy.interpolate import CubicSpline
+    pts = torch.linspace(range_min, range_max, interpolation)
+    es = eps * ((rm / pts) ** 12 - 2 * (rm / pts) ** 6)
+    c = CubicSpline(pts.numpy(), es.numpy()).c
+    return pts, torch.tensor(c).float()
+
+
+def lj_smooth_logp(x: Tensor, n_particles: int, n_dim: int, temperature: float = 1.0, energy_factor: float = 1.0,
+                   dist_eps: float = 1e-6, eps: float = 1.0, rm: float = 1.0, osc_scale: float = 1.0,
+                   range_min: float = 0.65, range_max: float = 2.0, interpolation: int = 1000) -> Tensor:
+    """lj_logp with smooth=True: pair energies below range_min come from the spline (cubic_spline,
+    lennardjones_energy.py:39-54: bucketize - 1 clamped to [0, len-2], so every r < range_min lands in interval 0), blended
+    as ``lj * ~filter + filter * spline(r)`` (:131-133)."""
+    B = x.shape[0]
+    v = x.reshape(B, n_particles, n_dim)
+    diff = v[:, :, None, :] - v[:, None, :, :]
+    mask = ~torch.eye(n_particles, dtype=torch.bool)
+    diff = diff[:, mask].reshape(B, n_particles, n_particles - 1, n_dim)
+    r = (diff.pow(2).sum(dim=-1) + dist_eps).sqrt()
+    lj = eps * ((rm / r) ** 12 - 2 * (rm / r) ** 6)
+    xs, c = lj_smooth_coeffs(range_min, range_max, interpolation, eps, rm)
+    iv = torch.clamp(torch.bucketize(r, xs) - 1, 0, len(xs) - 2)
+    dx = r - xs[iv]
+    spl = c[0, iv] * dx**3 + c[1, iv] * dx**2 + c[2, iv] * dx + c[3, iv]
+    filt = r < range_min
+    lj = lj * ~filt + filt * spl
+    e = lj.reshape(B, -1).sum(dim=-1) * energy_factor
+    cc = v - v.mean(dim=1, keepdim=True)
+    e = e + 0.5 * cc.pow(2).sum(dim=(-2, -1)) * osc_scale
+    return -e / temperature
+
+
+def lj_smooth_logp_force(x: Tensor, n_particles: int, n_dim: int, **kw) -> Tuple[Tensor, Tensor]:
+    """(logp, d logp / dx) by autograd, as the reference does (lennardjones_energy.py:222-225)."""
+    xg = x.detach().clone().requires_grad_(True)
+    lp = lj_smooth_logp(xg, n_particles, n_dim, **kw)
+    (g,) = torch.autograd.grad(lp.sum(), xg)
+    return lp.detach(), g
+
+
 def lj_energy2(x: Tensor, n_particles: int) -> Tensor:
     """Second, in-tree restatement of the LJ log-density: sampling/sample_lj13.py:24-30
     (2*sum_{i<j} via pdist, NO distance eps)."""

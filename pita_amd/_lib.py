@@ -51,6 +51,8 @@ _PROTOS = {
     "pita_device_count": (c_int, []),
     "pita_lj_logp_force": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_float, c_float,
                                    c_float, c_float, c_float, c_void_p]),
+    "pita_lj_smooth_logp_force": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_float, c_float,
+                                          c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
     "pita_dw_logp_force": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_float, c_float,
                                    c_float, c_float, c_void_p]),
     "pita_lj_descent": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int] + [c_float] * 6 + [c_int, c_float, c_float,

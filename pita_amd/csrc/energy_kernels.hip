@@ -16,13 +16,34 @@
 
 namespace pita {
 
-enum { E_LJ = 0, E_DW = 1 };
+enum { E_LJ = 0, E_DW = 1, E_LJS = 2 };  // E_LJS: LJ with the reference's cubic core below range_min (smooth=True)
+template <int KIND> constexpr bool is_lj() { return KIND == E_LJ || KIND == E_LJS; }
 
 struct PairParams {
   float inv_T, energy_factor, dist_eps, eps, rm2, osc_scale;  // LJ
   float cw, co;  // LJ13 fast path: -inv_T * 24 ef eps / rm^2 (pair force weight), -inv_T * osc_scale
   float a, b, c, d0;                                          // DW
+  float sm_min, sc0, sc1, sc2, sc3;  // E_LJS: below r = sm_min the pair energy is sc0 u^3 + sc1 u^2 + sc2 u + sc3, u = r - sm_min
 };
+
+// pair energy and e'(r)/r of the smooth-core LJ (lennardjones_energy.py:39-54,131-133): the reference evaluates
+// `lj * ~filter + filter * spline(r)`, the spline clamped to its first interval for r < range_min -- one cubic in
+// (r - range_min), same operation order (c0 dx**3 + c1 dx**2 + c2 dx + c3)
+__device__ __forceinline__ void lj_smooth_pair(float r2, const PairParams& p, float& e, float& coef) {
+  const float inv = __builtin_amdgcn_rcpf(r2);
+  if (r2 < 1.001f * p.sm_min * p.sm_min) {  // cheap pre-test; the reference's filter is the exact `r < range_min` below
+    const float r = sqrtf(r2);
+    if (r < p.sm_min) {
+      const float u = r - p.sm_min, u2 = u * u, u3 = u2 * u;
+      e = ((p.sc0 * u3 + p.sc1 * u2) + p.sc2 * u) + p.sc3;
+      coef = (fmaf(3.0f * p.sc0, u2, fmaf(2.0f * p.sc1, u, p.sc2))) / r;
+      return;
+    }
+  }
+  const float s2 = p.rm2 * inv, s6 = s2 * s2 * s2;
+  e = p.eps * fmaf(s6, s6, -2.0f * s6);
+  coef = p.eps * (12.0f * fmaf(-s6, s6, s6)) * inv;
+}
 
 // logp-force of particle i of one walker whose coordinates xw[n*DIM] sit in LDS: f = d logp / d x_i,
 // e = this particle's share of the energy (ordered pairs for LJ, half of each unordered pair for DW).
@@ -51,6 +72,12 @@ __device__ __forceinline__ void pair_force(const float* xw, int i, int n, const 
       const float coef = p.eps * (12.0f * fmaf(-s6, s6, s6)) * inv;  // e'(r)/r = eps*12*(s^6 - s^12)/r^2
 #pragma unroll
       for (int k = 0; k < DIM; ++k) f[k] = fmaf(coef, d[k], f[k]);
+    } else if (KIND == E_LJS) {
+      float ep, coef;
+      lj_smooth_pair(r2 + p.dist_eps, p, ep, coef);
+      e += ep;
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) f[k] = fmaf(coef, d[k], f[k]);
     } else {
       const float dist = sqrtf(r2);
       const float u = dist - p.d0, u2 = u * u;
@@ -60,7 +87,7 @@ __device__ __forceinline__ void pair_force(const float* xw, int i, int n, const 
       for (int k = 0; k < DIM; ++k) f[k] = fmaf(coef, d[k], f[k]);
     }
   }
-  if (KIND == E_LJ) {
+  if (is_lj<KIND>()) {
     // E = ef * sum_{i != j} lj + 0.5*osc*sum |x - mean|^2 ; each unordered pair appears twice
     float osc = 0.f;
 #pragma unroll
@@ -151,7 +178,7 @@ __device__ __forceinline__ void pair_force_n3l(const float* xw, float* fw, float
   float xi[DIM], mean[DIM];
 #pragma unroll
   for (int k = 0; k < DIM; ++k) { f[k] = 0.f; xi[k] = xw[i * DIM + k]; fw[i * DIM + k] = 0.f; }
-  if (KIND == E_LJ) walker_mean<DIM>(xw, ms, i, n, mean);
+  if (is_lj<KIND>()) walker_mean<DIM>(xw, ms, i, n, mean);
   e = 0.f;
   const int nh = (n - 1) >> 1, npass = nh + ((n & 1) ? 0 : 1);
   for (int dd = 1; dd <= npass; ++dd) {
@@ -172,6 +199,9 @@ __device__ __forceinline__ void pair_force_n3l(const float* xw, float* fw, float
       const float s2 = p.rm2 * inv, s6 = s2 * s2 * s2;
       ep = 2.0f * (p.eps * fmaf(s6, s6, -2.0f * s6));              // the reference sums ordered pairs
       coef = p.eps * (12.0f * fmaf(-s6, s6, s6)) * inv;             // e'(r)/r = eps*12*(s^6 - s^12)/r^2
+    } else if (KIND == E_LJS) {
+      lj_smooth_pair(r2 + p.dist_eps, p, ep, coef);
+      ep *= 2.0f;
     } else {
       const float dist = sqrtf(r2);
       const float u = dist - p.d0, u2 = u * u;
@@ -191,7 +221,7 @@ __device__ __forceinline__ void pair_force_n3l(const float* xw, float* fw, float
   pair_wave_fence();
 #pragma unroll
   for (int k = 0; k < DIM; ++k) f[k] += fw[i * DIM + k];
-  if (KIND == E_LJ) {
+  if (is_lj<KIND>()) {
     // E = ef * sum_{i != j} lj + 0.5*osc*sum |x - mean|^2
     float osc = 0.f;
 #pragma unroll
@@ -945,6 +975,18 @@ __global__ void __launch_bounds__(256) gmm_kernel(const float* __restrict__ x, f
 }  // namespace pita
 
 using namespace pita;
+
+extern "C" int pita_lj_smooth_logp_force(const float* x, float* logp, float* force, int64_t B, int n, int d,
+                                         float temperature, float energy_factor, float dist_eps, float eps, float rm,
+                                         float osc_scale, float range_min, const float* coef4, void* stream) {
+  PITA_REQUIRE(temperature > 0.f, "pita_lj_smooth_logp_force: temperature must be > 0");
+  PITA_REQUIRE(coef4 && range_min > 0.f, "pita_lj_smooth_logp_force: spline coefficients / range_min");
+  PairParams p{};
+  p.inv_T = 1.0f / temperature; p.energy_factor = energy_factor; p.dist_eps = dist_eps; p.eps = eps;
+  p.rm2 = rm * rm; p.osc_scale = osc_scale;
+  p.sm_min = range_min; p.sc0 = coef4[0]; p.sc1 = coef4[1]; p.sc2 = coef4[2]; p.sc3 = coef4[3];
+  return launch_pair<E_LJS>(x, logp, force, B, n, d, p, stream);
+}
 
 extern "C" int pita_lj_logp_force(const float* x, float* logp, float* force, int64_t B, int n, int d, float temperature,
                                   float energy_factor, float dist_eps, float eps, float rm, float osc_scale,

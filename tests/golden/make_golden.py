@@ -113,6 +113,31 @@ def gen_lj():
         save(f"lj{n}_logp_force.npz", **out)
 
 
+def gen_lj_smooth():
+    """LennardJonesEnergy(smooth=True): the spline core below r = 0.65 (lennardjones_energy.py:114-119,131-133)."""
+    n, D = 13, 39
+    gen = torch.Generator().manual_seed(4013)
+    cold = lattice_cluster(n, 3, 24, gen)
+    squeezed = lattice_cluster(n, 3, 24, gen, spacing=0.62, jitter=0.06)  # most neighbour pairs inside the core
+    hot = data_utils.remove_mean(torch.randn(16, D, generator=gen) * 0.7, n, 3)
+    x = torch.cat([cold, squeezed, hot])
+    out = {"x": x.numpy()}
+    for T, ef in ((1.0, 1.0), (2.0, 0.5)):
+        e = LJ(D, n, 3, data_path="", temperature=T, energy_factor=ef, smooth=True)
+        lp = e(x.clone())
+        lp2, f = e(x.clone(), return_force=True)
+        assert torch.equal(lp, lp2)
+        out[f"logp_T{T}_ef{ef}"] = lp.numpy()
+        out[f"force_T{T}_ef{ef}"] = f.numpy()
+    pot = e.lennard_jones
+    out["spline_c0"] = pot.splines.keywords["c"][:, 0].numpy()
+    out["spline_x0"] = pot.splines.keywords["x"][:1].numpy()
+    v = x.reshape(-1, n, 3)
+    dmin = torch.cdist(v, v).add(torch.eye(n) * 1e3).amin(dim=(1, 2))
+    out["n_core_walkers"] = int((dmin < 0.65).sum())
+    save("lj13_smooth_logp_force.npz", **out)
+
+
 # ----------------------------------------------------------------------------- GMM target
 def gen_gmm():
     out = {}
@@ -547,7 +572,7 @@ def gen_traj_gmm():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "lj", "gmm", "egnn", "mlp", "prior", "resample", "traj_nodebias",
+    which = sys.argv[1:] or ["schedules", "lj", "lj_smooth", "gmm", "egnn", "mlp", "prior", "resample", "traj_nodebias",
                              "traj_debias", "traj_debias_end", "debias_variants", "post", "traj_gmm"]
     for w in which:
         globals()["gen_" + w]()

@@ -58,6 +58,32 @@ def test_lj_golden(pa, golden, n):
     assert rel(f[:nphys], g["force_ef0.5"][:nphys]) < 1e-5
 
 
+def test_lj_smooth_core_golden(pa, golden):
+    """LennardJonesEnergy(smooth=True): cubic core below r = 0.65, against the reference's log-density and autograd force
+    (walkers with and without pairs inside the core), for LJ13 and, against the oracle, LJ55 / ragged batches."""
+    g = golden("lj13_smooth_logp_force.npz")
+    coef, r0 = pa.lennardjones_energy.smooth_core_coefficients()
+    np.testing.assert_array_equal(coef, g["spline_c0"])
+    assert np.float32(r0) == g["spline_x0"][0]
+    x = cu(g["x"])
+    for Tk, ef in ((1.0, 1.0), (2.0, 0.5)):
+        e = pa.LennardJonesEnergy(39, 13, 3, temperature=Tk, energy_factor=ef, smooth=True)
+        lp = e(x)
+        lp2, f = e(x, return_force=True)
+        assert torch.equal(lp, lp2)
+        np.testing.assert_allclose(lp.cpu().numpy(), g[f"logp_T{Tk}_ef{ef}"], rtol=1e-5, atol=2e-5)
+        assert rel(f, g[f"force_T{Tk}_ef{ef}"]) < 1e-5
+        assert e.fused_descent(x.clone(), 1, 1e-3, 0.0, 1.0) is None  # fused loops know the plain curve only
+    gen = torch.Generator().manual_seed(11)
+    for n, B in ((13, 1), (13, 21), (55, 37)):
+        xo = torch.randn(B, 3 * n, generator=gen) * 0.5 + torch.linspace(-1.5, 1.5, 3 * n)[None]
+        lp_o, f_o = O.lj_smooth_logp_force(xo, n, 3, temperature=1.5)
+        e = pa.LennardJonesEnergy(3 * n, n, 3, temperature=1.5, smooth=True)
+        lp, f = e(xo.cuda(), return_force=True)
+        np.testing.assert_allclose(lp.cpu().numpy(), lp_o.numpy(), rtol=2e-5)
+        assert rel(f, f_o) < 2e-5
+
+
 def test_lj_vs_oracle_random_and_edges(pa):
     gen = torch.Generator().manual_seed(3)
     for n, B in ((13, 1000), (13, 1), (13, 19), (13, 20), (55, 37)):

@@ -54,6 +54,25 @@ def test_lj(golden, n):
     assert rel(g["force_T1.0"][:nphys], f64[:nphys].numpy()) < 1e-5
 
 
+def test_lj_smooth_core(golden):
+    """smooth=True (lennardjones_energy.py:114-119,131-133): spline coefficients and the blended log-density / autograd
+    force against the reference's output; the fixture has walkers inside and outside the r < 0.65 core."""
+    g = golden("lj13_smooth_logp_force.npz")
+    assert int(g["n_core_walkers"]) >= 24
+    xs, c = O.lj_smooth_coeffs()
+    np.testing.assert_array_equal(c[:, 0].numpy(), g["spline_c0"])
+    np.testing.assert_array_equal(xs[:1].numpy(), g["spline_x0"])
+    x = T(g["x"])
+    for Tk, ef in ((1.0, 1.0), (2.0, 0.5)):
+        lp, f = O.lj_smooth_logp_force(x, 13, 3, temperature=Tk, energy_factor=ef)
+        np.testing.assert_allclose(lp.numpy(), g[f"logp_T{Tk}_ef{ef}"], rtol=2e-6)
+        assert rel(f.numpy(), g[f"force_T{Tk}_ef{ef}"]) < 2e-6
+    # the option changes the answer exactly where pairs sit inside the core
+    plain = O.lj_logp(x, 13, 3)
+    smooth = O.lj_smooth_logp(x, 13, 3)
+    assert torch.equal(plain[:24], smooth[:24]) and not torch.allclose(plain[24:48], smooth[24:48])
+
+
 def test_lj_energy2_second_oracle(golden):
     """The in-tree restatement sampling/sample_lj13.py:energy2 (no distance eps) agrees
     with the bgflow-shimmed reference on physical configurations."""
