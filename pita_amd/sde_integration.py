@@ -11,8 +11,9 @@ How the work is laid out on MI355X (differences from the reference are deliberat
     launch (pita_egnn_sampler_run): walkers stay in registers, no per-step launch, no per-step
     all_gather, no per-step device->host copy of SDETerms (reference :248-258,:289);
   * walkers are sharded over ranks by contiguous slices exactly like :227-233, and gathered ONCE
-    at the end (RCCL all_gather) -- or at each resampling event, which is global like the
-    reference's;
+    at the end (RCCL all_gather); a resampling event is global like the reference's, but only the
+    log-weights are gathered -- the walkers move in one all_to_all_single that carries each rank the
+    distinct parents it needs (_Comm.exchange_rows);
   * noise is Philox4x32-10 keyed by (seed, GLOBAL walker index, step): the result does not depend
     on the number of GPUs.  ``noise=`` injects recorded normals for parity tests.
 ``sde_terms_all`` has N entries like the reference's (:150,:212).  By default each field is a ``TermStats`` (sum,
@@ -96,6 +97,58 @@ class _Comm:
         if self.world == 1:
             return x
         return self.all_gather(x[None]).reshape(self.world, *x.shape).sum(0)
+
+    def shared_uniform(self, u):
+        """The resampling uniform of this event, identical on every rank (the reference draws it from each rank's CPU
+        generator, utils.py:111-120, and relies on identically seeded ranks; the exchange below needs agreement)."""
+        if u is None:
+            u = torch.rand(size=(1,), dtype=torch.float64)
+        u = torch.as_tensor(u, dtype=torch.float64).reshape(-1)[:1].clone()
+        if self.world > 1 and torch.distributed.is_available() and torch.distributed.is_initialized():
+            if torch.distributed.get_backend() == "nccl":
+                ud = u.cuda()
+                torch.distributed.broadcast(ud, 0)
+                u = ud.cpu()
+            else:
+                torch.distributed.broadcast(u, 0)
+        return u
+
+    def exchange_rows(self, x, ids, Bl):
+        """Rows ``ids[rank*Bl:(rank+1)*Bl]`` of the batch whose shards are the ranks' ``x`` [Bl, D]; ``ids`` [world*Bl]
+        are the parents of a global systematic resampling: identical on every rank, non-decreasing up to the cyclic
+        rotation by the event's uniform (utils.py:111-120: ``(u + i / bs) % 1``).  Instead of
+        all-gathering every walker to every rank (the reference, sde_integration.py:248-258), each rank sends a
+        destination only the DISTINCT parents it holds that the destination needs (one RCCL all_to_all_single with
+        uneven splits); repeated parents are expanded locally."""
+        W, r = self.world, self.rank
+        if W == 1:
+            return gather_rows(x, ids)
+        if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            return gather_rows(self.all_gather(x), ids)[r * Bl:(r + 1) * Bl].clone()  # Lightning's all_gather only
+        n = W * Bl
+        first = torch.ones(n, dtype=torch.bool, device=ids.device)
+        first[1:] = ids[1:] != ids[:-1]
+        first[::Bl] = True  # a destination's first walker always needs its parent
+        src = torch.div(ids, Bl, rounding_mode="floor")
+        dest = torch.div(torch.arange(n, device=ids.device), Bl, rounding_mode="floor")
+        counts = torch.bincount((dest * W + src)[first], minlength=W * W).reshape(W, W).tolist()  # [dest][src]
+        send = x[ids[first & (src == r)] - r * Bl].contiguous()  # grouped by destination, ascending
+        recv = torch.empty((sum(counts[r]), x.shape[1]), device=x.device, dtype=x.dtype)
+        in_split, out_split = [counts[d][r] for d in range(W)], counts[r]
+        if torch.distributed.get_backend() != "nccl" and x.is_cuda:  # gloo rehearsal: through the host
+            rc = torch.empty(recv.shape, dtype=x.dtype)
+            torch.distributed.all_to_all_single(rc, send.cpu(), output_split_sizes=out_split, input_split_sizes=in_split)
+            recv = rc.to(x.device)
+        else:
+            torch.distributed.all_to_all_single(recv, send, output_split_sizes=out_split, input_split_sizes=in_split)
+        self.rows_received = getattr(self, "rows_received", 0) + sum(counts[r]) - counts[r][r]
+        # the received rows are ordered by (source rank, position in my slice); my slice's runs are ordered by position
+        fl = first[r * Bl:(r + 1) * Bl]
+        jl = torch.nonzero(fl).reshape(-1)
+        order = torch.argsort(src[r * Bl:(r + 1) * Bl][jl] * Bl + jl)
+        pos = torch.empty_like(order)
+        pos[order] = torch.arange(order.numel(), device=order.device)
+        return recv[pos[torch.cumsum(fl.to(torch.int64), 0) - 1]]
 
 
 def _terms_from_stats(st4, st8, n_elem, n_walk, computed, debiased):
@@ -227,13 +280,11 @@ class WeightedSDEIntegrator:
                             sde_terms_all, st4)
             s = stop + 1
             if stop in events:
-                xg = comm.all_gather(x)
-                a = torch.zeros(xg.shape[0], device=dev)  # drift_A = 0 in the not-debiased regime
-                u = next(u_iter) if u_iter is not None else None
-                ids, _ = sample_cat_sys(xg.shape[0], a, u)
-                xg = gather_rows(xg, ids)
+                a = torch.zeros(comm.world * Bl, device=dev)  # drift_A = 0 in the not-debiased regime
+                u = comm.shared_uniform(next(u_iter) if u_iter is not None else None)
+                ids, _ = sample_cat_sys(a.shape[0], a, u)
                 num_unique_idxs[stop] = int(torch.unique(ids).numel())
-                x = xg[off:off + Bl].clone()
+                x = comm.exchange_rows(x, ids, Bl)
                 if mean_free:
                     x = remove_mean(x, n, d)
         # log-weights are identically zero here; a stride-0 view avoids N*B*4 bytes (reference stacks N copies)
@@ -303,12 +354,11 @@ class WeightedSDEIntegrator:
             due = not (resampling_interval == -1 or (step + 1) % resampling_interval != 0
                        or step >= self.end_resampling_step)
             if due:
-                xg, ag = comm.all_gather(x), comm.all_gather(a)
-                u = next(u_iter) if u_iter is not None else None
-                ids, _ = sample_cat_sys(xg.shape[0], ag, u)
-                xg = gather_rows(xg, ids)
+                ag = comm.all_gather(a)
+                u = comm.shared_uniform(next(u_iter) if u_iter is not None else None)
+                ids, _ = sample_cat_sys(ag.shape[0], ag, u)
                 n_unique = int(torch.unique(ids).numel())
-                x = xg[off:off + Bl].clone()
+                x = comm.exchange_rows(x, ids, Bl)
                 a = torch.zeros_like(a)
             if mean_free:
                 x = remove_mean(x, n, d)
@@ -355,18 +405,19 @@ class WeightedSDEIntegrator:
         (+ the running log-weights a), clamped at its 0.9 quantile, then global systematic resampling.
         Returns (local slice of the resampled walkers, a_next over the global batch, number of distinct parents)."""
         t_end = times[min(self.end_resampling_step, self.num_integration_steps - 1)]
-        xg = comm.all_gather(x)
-        tb = torch.full((xg.shape[0],), float(t_end), device=xg.device)
-        model_energy = self.sde.energy_net.forward_energy(self.sde.noise_schedule.h(tb), xg, beta,
+        # every rank evaluates its own shard (the reference evaluates the gathered batch on every rank); only the
+        # log-weights are gathered, the walkers move in the exchange
+        tb = torch.full((x.shape[0],), float(t_end), device=x.device)
+        model_energy = self.sde.energy_net.forward_energy(self.sde.noise_schedule.h(tb), x, beta,
                                                           pin=bool(getattr(self.sde, "pin_energy", False)),
                                                           energy_function=energy_function, t=tb)  # :166-173
-        a_next = energy_function(xg) + model_energy * _scalar(gamma_schedule.gamma(t_end))
+        a_next = energy_function(x) + model_energy * _scalar(gamma_schedule.gamma(t_end))
         if a is not None:
-            a_next = a_next + comm.all_gather(a)
-        a_next = _quantile_clamp(a_next, 0.9)
-        u = next(u_iter) if u_iter is not None else None
-        ids, _ = sample_cat_sys(xg.shape[0], a_next, u)
-        x = gather_rows(xg, ids)[off:off + Bl].clone()
+            a_next = a_next + a
+        a_next = _quantile_clamp(comm.all_gather(a_next.contiguous()), 0.9)
+        u = comm.shared_uniform(next(u_iter) if u_iter is not None else None)
+        ids, _ = sample_cat_sys(a_next.shape[0], a_next, u)
+        x = comm.exchange_rows(x, ids, Bl)
         return x, a_next, int(torch.unique(ids).numel())
 
     # ------------------------------------------------------------------ A2-A4 steps [s0, s1)

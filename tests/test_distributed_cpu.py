@@ -143,3 +143,60 @@ def test_single_rank_comm():
     assert (c.world, c.rank) == (1, 0)
     x = torch.randn(4, 3)
     assert c.all_gather(x) is x
+
+
+def _worker_exchange(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pita_amd.sde_integration import _Comm
+
+        comm = _Comm(None)
+        Bl, D = 7, 5
+        n = world * Bl
+        xg = torch.arange(n * D, dtype=torch.float32).reshape(n, D)
+        x = xg[rank * Bl:(rank + 1) * Bl].clone()
+        gen = torch.Generator().manual_seed(5)
+        patterns = [torch.arange(n),                                        # nobody moves
+                    torch.zeros(n, dtype=torch.int64),                      # one parent for everybody
+                    torch.full((n,), n - 1, dtype=torch.int64),             # ... living on the last rank
+                    torch.sort(torch.randint(0, n, (n,), generator=gen))[0],
+                    torch.sort(torch.randint(0, Bl, (n,), generator=gen))[0],        # all parents on rank 0
+                    torch.sort(torch.randint(n - 3, n, (n,), generator=gen))[0],
+                    torch.roll(torch.arange(n), -3),                        # the rotation by the event's uniform
+                    torch.roll(torch.sort(torch.randint(0, n, (n,), generator=gen))[0], 5)]
+        moved = []
+        for ids in patterns:
+            before = getattr(comm, "rows_received", 0)
+            got = comm.exchange_rows(x, ids, Bl)
+            assert torch.equal(got, xg[ids][rank * Bl:(rank + 1) * Bl]), ids
+            moved.append(comm.rows_received - before)
+        assert moved[0] == 0                      # identity resampling: no walker crosses a rank boundary
+        assert moved[1] == (0 if rank == 0 else 1)  # one distinct parent travels to each other rank, once
+        assert all(m <= Bl for m in moved)        # never more than a shard (the all-gather moves (world-1) shards)
+        # the resampling uniform is rank 0's on every rank
+        u = comm.shared_uniform(0.25 + 0.5 * rank)
+        assert float(u) == 0.25
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_resampling_exchange_moves_only_needed_parents(world):
+    """_Comm.exchange_rows (the all_to_all_single that replaces the reference's all-gather of every walker at a
+    resampling event, sde_integration.py:248-258) returns exactly the local slice of gathered[ids] and moves at most the
+    distinct remote parents a rank needs."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_exchange, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
