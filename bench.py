@@ -161,8 +161,9 @@ def cpu_baseline(cfg, n_walkers, n_steps, seed=12345):
 
 def debiased_leg(pita_amd, net, cfg, dev, B, with_cpu):
     """Secondary number: the debiased Feynman-Kac regime (PITA's default; sdes.py:151-239): drift of x and of the
-    log-weights through D/K multi-direction divergence launches (pita_egnn_div_accumulate) + 1 forward-mode
-    (pita_egnn_jvp, h direction) + 1 reverse-mode launch (pita_egnn_vjp) + assembly + quantile clamp, then the EM update."""
+    log-weights through the exact Jacobian trace (pita_egnn_jacobian_trace: one launch with the primal that writes the
+    primal cache, tangent-only launches that stream it) + 1 reverse-mode launch (pita_egnn_vjp, which also returns the
+    h-derivative term) + assembly + quantile clamp, then the EM update."""
     import copy
 
     import numpy as np
@@ -215,14 +216,16 @@ def debiased_leg(pita_amd, net, cfg, dev, B, with_cpu):
            "ms_per_step": dt * 1e3,
            "launches_per_step": "exact trace of J_x D (1 launch with the primal + tangent-only launches from the primal "
                                 "cache, each followed by its repair pass), 1 reverse-mode launch, assembly, clamp, update",
-           "roofline": {"kernel": "egnn_div_fast_kernel + egnn_div_tangent_kernel (pita_egnn_jacobian_trace)",
+           "roofline": {"kernel": "egnn_div_fast_kernel + egnn_div_tangent_(shared_)kernel (pita_egnn_jacobian_trace)",
                         "bound": "mfma", "achieved": tf, "peak": PEAK_MFMA16_TFLOPS, "unit": "TFLOP/s",
                         "frac": tf / PEAK_MFMA16_TFLOPS, "ms_per_trace": tr_ms,
                         "executed_mfma_flop_per_walker": a.value * MFMA16_FLOP,
                         "executed_f32_mfma_flop_per_walker": b.value * MFMA32_FLOP,
                         "valu_issue_frac": pk.get("valu_issue_frac") if pk and pk.get("walkers") == B else None,
-                        "note": "one wavefront per SIMD (512 registers); the tangent-only launches stream the primal cache "
-                                "(~12 GB per launch at 65 536 LJ13 walkers) at ~4 TB/s: DESIGN.md 4.5"}}
+                        "pmc_kernels": pk.get("kernels") if pk and pk.get("walkers") == B else None,
+                        "note": "the tangent-only launches trade matrix flops for streams of the primal cache (~12 GB per "
+                                "launch at 65 536 LJ13 walkers, one stream per 16 directions through an LDS ring); they "
+                                "are bound by LDS bandwidth and vector issue, not by the matrix pipe: DESIGN.md 4.5"}}
     assert 0.0 < out["roofline"]["frac"] <= 1.0
     if with_cpu:
         from oracle import pita_oracle as O

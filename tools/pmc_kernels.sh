@@ -13,9 +13,24 @@ for f in glob.glob(sys.argv[1] + "/p*/**/*counter_collection.csv", recursive=Tru
     for r in csv.DictReader(open(f)):
         if sys.argv[2] in r["Kernel_Name"]:
             acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+import json
+out = {}
 for k, v in acc.items():
     print(k)
+    m = {c: sum(vals) / len(vals) for c, vals in v.items()}
     for c, vals in sorted(v.items()):
-        print("    %-28s %.6g  (%d launches)" % (c, sum(vals) / len(vals), len(vals)))
+        print("    %-28s %.6g  (%d launches)" % (c, m[c], len(vals)))
+    g = m.get("GRBM_GUI_ACTIVE")
+    e = {"launches": max(len(x) for x in v.values()), "counters": m}
+    if g:  # GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / SQ_WAIT_* count quad-cycles
+        cyc = g / 8.0
+        e["kernel_cycles_per_xcd"] = cyc
+        if "SQ_ACTIVE_INST_VALU" in m: e["valu_issue_frac"] = 4.0 * m["SQ_ACTIVE_INST_VALU"] / (1024.0 * cyc)
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in m: e["mfma_pipe_busy_frac"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc)
+        if "SQ_INSTS_SALU" in m: e["salu_issue_frac"] = m["SQ_INSTS_SALU"] / (256.0 * cyc)
+        if "SQ_ACTIVE_INST_LDS" in m: e["lds_issue_frac"] = 4.0 * m["SQ_ACTIVE_INST_LDS"] / (1024.0 * cyc)
+        if "SQ_WAIT_ANY" in m and "SQ_WAVE_CYCLES" in m: e["wave_wait_any_frac"] = m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"]
+    out[k.replace("void pita::", "")] = e
+json.dump(out, open(sys.argv[1] + "/summary.json", "w"), indent=1)
 PY
 find $O -name "*.csv" -delete
