@@ -1805,6 +1805,17 @@ static const DivShape kDivShapes[] = {
 // in LDS), K = 4: 102.8 ms (more register shuffling; no longer fits in LDS), 39 single-direction JVP launches: 126 ms.
 // PITA_DIV_K selects an alternative for experiments.
 static const DivShape kDivAlt[] = {PITA_DIV_SHAPE(13, 3, 2, 4, 2)};
+// cache writers for the block-shared tangent kernel: the first launch of a trace carries ONE direction (the tangent-only
+// launches take 16 each, so 1 + 13 + 13 + 12 beats 3 + 16 + 16 + 4 for LJ13: the primal launch is lighter and the three
+// streams are balanced)
+static const DivShape kDivWriters[] = {PITA_DIV_FAST_SHAPE(13, 3, 2, 4, 1), PITA_DIV_FAST_SHAPE(22, 3, 1, 4, 1)};
+static const DivShape* find_div_writer(int n, int dim) {
+  static const bool off = getenv("PITA_DIV_NOWRITER") != nullptr;  // development aid
+  if (off) return nullptr;
+  for (const auto& c : kDivWriters)
+    if (c.n == n && c.dim == dim) return &c;
+  return nullptr;
+}
 static const DivShape* find_div_shape(int n, int dim) {
   static const int altk = getenv("PITA_DIV_K") ? atoi(getenv("PITA_DIV_K")) : 0;
   if (altk)
@@ -1907,7 +1918,13 @@ extern "C" int pita_egnn_div_work(const pita_egnn_t* net, double* mfma16_per_wal
   PITA_REQUIRE(net && mfma16_per_walker && mfma32_per_walker, "pita_egnn_div_work: null argument");
   const DivShape* s = find_div_shape(net->cfg.n_particles, net->cfg.n_dim);
   if (!s) return fail(PITA_EUNSUPPORTED, "pita_egnn_div_work: no kernel for this particle system");
-  const int N = s->n, K = s->K, L = net->cfg.n_layers, D = s->n * s->dim;
+  const int N = s->n, L = net->cfg.n_layers, D = s->n * s->dim;
+  int K = s->K;
+  {  // the cached path's first launch may carry fewer directions (cache writer)
+    const DivTanShape* ts0 = div_fast_enabled(net) ? find_div_tan_shape(N, s->dim, L) : nullptr;
+    const DivShape* wr = (ts0 && ts0->shared) ? find_div_writer(N, s->dim) : nullptr;
+    if (wr && wr->G == s->G && wr->waves == s->waves && D > s->K) K = wr->K;
+  }
   double launches = (D + K - 1) / K;
   const double tiles_per_walker = (double)((s->G * N + 31) / 32) / s->G;
   double m16 = 0, m32 = 0, t16 = 0, t32 = 0;  // per tile: one K-direction launch with primal; one tangent-only direction
@@ -2089,9 +2106,12 @@ extern "C" int pita_egnn_jacobian_trace(pita_egnn_t* net, const float* h, const 
       }
       return PITA_OK;
     };
-    // first K directions: primal + tangents, cache written
-    p.dir0 = 0; p.ndir = s->K < D ? s->K : D; p.out = denoiser_out ? denoiser_out + b0 * D : nullptr;
-    int rc = div_launch(s, s->fast, net, p, stream);
+    // first launch: primal + its own directions, cache written
+    const DivShape* wr = ts->shared ? find_div_writer(n, dim) : nullptr;
+    if (wr && (wr->G != s->G || wr->waves != s->waves)) wr = nullptr;
+    const int first_k = wr ? wr->K : s->K;
+    p.dir0 = 0; p.ndir = first_k < D ? first_k : D; p.out = denoiser_out ? denoiser_out + b0 * D : nullptr;
+    int rc = div_launch(wr ? wr : s, wr ? wr->fast : s->fast, net, p, stream);
     if (rc != PITA_OK) return rc;
     rc = repair(0, p.ndir, p.out);
     if (rc != PITA_OK) return rc;
@@ -2100,10 +2120,14 @@ extern "C" int pita_egnn_jacobian_trace(pita_egnn_t* net, const float* h, const 
     const size_t lds = ts->lds_bytes(L);
     PITA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ts->kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds));
-    const int per_launch = ts->shared ? ts->K * ts->waves : ts->K;
+    int per_launch = ts->shared ? ts->K * ts->waves : ts->K;
+    if (ts->shared && D > first_k) {  // equal shares for the launches the remaining directions need anyway
+      const int nl = (D - first_k + per_launch - 1) / per_launch;
+      per_launch = (D - first_k + nl - 1) / nl;
+    }
     const long long tgrid = !ts->shared ? grid : (total_waves * groups_per_wave < (long long)net->n_cu
                                                       ? total_waves * groups_per_wave : (long long)net->n_cu);
-    for (int d0 = s->K; d0 < D; d0 += per_launch) {
+    for (int d0 = first_k; d0 < D; d0 += per_launch) {
       p.dir0 = d0;
       p.ndir = (D - d0) < per_launch ? (D - d0) : per_launch;
       hipLaunchKernelGGL(ts->kernel, dim3((unsigned)tgrid), dim3(ts->waves * 64), lds, st, p);
