@@ -7,6 +7,8 @@ reference's own fp32-vs-fp64 error; per-step drift rel-L2 1e-4 at identical inpu
 index work (resampling ids) exact except where a uniform falls within fp32 rounding of a bin
 edge (counted, must be < 0.5 %, always off by one).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -14,6 +16,7 @@ import torch
 from oracle import pita_oracle as O
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 T = torch.tensor
 
@@ -838,6 +841,63 @@ def test_jacobian_trace_multi_direction(pa, golden):
             J = vmap(jacrev(one, argnums=1))(h.double(), x.double(), beta.double())
             want = torch.diagonal(J, dim1=1, dim2=2).sum(-1)
             np.testing.assert_allclose(tr.cpu().numpy(), want.numpy(), rtol=5e-5, atol=5e-5 * scale)
+
+
+@pytest.mark.parametrize("n,B", [(13, 40003), (22, 4099)])
+def test_jacobian_trace_large_batches_block_shared_stream(pa, golden, n, B):
+    """At production batch sizes every block of the block-shared tangent kernel sweeps MANY walker groups: the LDS ring
+    wraps thousands of times, the parked results are flushed every 32 groups, the last group of a wave's quota is ragged.
+    The trace must still equal the one assembled from single-direction forward-mode launches, walker by walker."""
+    w = golden("egnn_weights_trainedlike.npz")
+    net = make_net(pa, n, 3, w)
+    gen = torch.Generator().manual_seed(n + B)
+    h = torch.tensor([0.01, 0.3, 2.0, 40.0, 900.0])[torch.arange(B) % 5].cuda()
+    x = O.remove_mean(torch.randn(B, n * 3, generator=gen) * (1 + h.cpu().sqrt())[:, None], n, 3).cuda()
+    beta = (torch.rand(B, generator=gen) + 0.7).cuda()
+    tr = net.jacobian_trace(h, x, beta)
+    assert torch.equal(tr, net.jacobian_trace(h, x, beta))  # same bits on a second call (cache reuse)
+    acc = torch.zeros(B, device="cuda")
+    for k in range(n * 3):
+        net.jvp(h, x, beta, direction=k, want_primal=False, want_tangent=False, diag_acc=acc)
+    scale = float(acc.abs().mean()) + 1.0
+    np.testing.assert_allclose(tr.cpu().numpy(), acc.cpu().numpy(), rtol=2e-5, atol=2e-5 * scale)
+
+
+def test_jacobian_trace_in_cache_chunks(golden):
+    """A batch whose primal cache exceeds PITA_DIV_CACHE_GB is processed in chunks of walkers; the result does not
+    depend on the chunking (the budget is read once per process, so this runs in a child process)."""
+    import subprocess
+    import sys
+
+    code = """
+import os, sys, numpy as np, torch
+sys.path.insert(0, %r)
+import pita_amd as pa
+w = dict(np.load(os.path.join(%r, "tests", "golden", "egnn_weights_trainedlike.npz")))
+net = pa.EGNN_dynamics(13, 3, hidden_nf=32, n_layers=3, recurrent=True, tanh=True, attention=True,
+                       condition_time=True, condition_temperature=True, agg="sum")
+net.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
+B = 5003
+gen = torch.Generator().manual_seed(1)
+from pita_amd.data_utils import remove_mean
+x = remove_mean(torch.randn(B, 39, generator=gen).cuda() * 2.0, 13, 3)
+h = torch.full((B,), 1.5).cuda(); b = torch.ones(B).cuda()
+tr = net.jacobian_trace(h, x, b)
+torch.save(tr.cpu(), sys.argv[1])
+""" % (ROOT, ROOT)
+    import tempfile
+
+    outs = []
+    with tempfile.TemporaryDirectory() as td:
+        for gb in ("0.3", "24"):
+            env = dict(os.environ, PITA_DIV_CACHE_GB=gb)
+            path = os.path.join(td, f"tr_{gb}.pt")
+            r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=600, env=env)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs.append(torch.load(path))
+    assert torch.isfinite(outs[0]).all()
+    # chunking changes the wave quotas (which walkers share a tile), not the per-walker arithmetic
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_jacobian_trace_out_of_range_walkers_fall_back_to_bf16(pa, golden):
