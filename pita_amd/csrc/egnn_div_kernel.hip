@@ -2056,6 +2056,40 @@ extern "C" int pita_egnn_jacobian_trace(pita_egnn_t* net, const float* h, const 
   chunk = chunk / 1024 * 1024;
   if (chunk < 1024) chunk = 1024;
   if (chunk > B) chunk = B;
+  // cache bytes a chunk of Bc walkers needs (grid of the fast kernel: the cache is indexed by wave and group)
+  auto cache_need = [&](long long Bc) -> size_t {
+    const long long ngroups = (Bc + s->G - 1) / s->G;
+    const long long want = (ngroups + s->waves - 1) / s->waves;
+    const long long grid = want < (long long)net->n_cu ? want : (long long)net->n_cu;
+    const long long total_waves = grid * s->waves;
+    const long long quota = (Bc + total_waves - 1) / total_waves;
+    return sizeof(float) * ts->group_f(L) * (size_t)(total_waves * ((quota + s->G - 1) / s->G));
+  };
+  // the buffer is allocated for the largest (= first) chunk; when the device cannot give that much, smaller chunks are
+  // tried, and a handle that cannot even cache 1024 walkers falls back to the cache-free launches
+  while (cache_need(chunk) > net->divcache_bytes) {
+    PITA_HIP_CHECK(hipStreamSynchronize(st));
+    (void)hipFree(net->d_divcache);
+    net->d_divcache = nullptr;
+    net->divcache_bytes = 0;
+    const size_t need = cache_need(chunk);
+    if (hipMalloc(&net->d_divcache, need) == hipSuccess) {
+      net->divcache_bytes = need;
+      break;
+    }
+    (void)hipGetLastError();  // out of memory: not sticky
+    net->d_divcache = nullptr;
+    if (chunk <= 1024) {
+      const int K = pita_egnn_div_directions(net);
+      for (int d0 = 0; d0 < D; d0 += K) {
+        const int rc = pita_egnn_div_accumulate(net, h, x, beta, d0, (D - d0) < K ? (D - d0) : K, trace,
+                                                d0 == 0 ? denoiser_out : nullptr, B, stream);
+        if (rc != PITA_OK) return rc;
+      }
+      return PITA_OK;
+    }
+    chunk = (chunk / 2 + 1023) / 1024 * 1024;
+  }
   for (long long b0 = 0; b0 < B; b0 += chunk) {
     const long long Bc = (B - b0) < chunk ? (B - b0) : chunk;
     DivParams p{};
@@ -2072,15 +2106,8 @@ extern "C" int pita_egnn_jacobian_trace(pita_egnn_t* net, const float* h, const 
     const long long total_waves = grid * s->waves;
     const long long quota = (Bc + total_waves - 1) / total_waves;
     const long long groups_per_wave = (quota + s->G - 1) / s->G;
-    const size_t need = sizeof(float) * ts->group_f(L) * (size_t)(total_waves * groups_per_wave);
-    if (need > net->divcache_bytes) {
-      PITA_HIP_CHECK(hipStreamSynchronize(st));
-      (void)hipFree(net->d_divcache);
-      net->d_divcache = nullptr;
-      net->divcache_bytes = 0;
-      PITA_HIP_CHECK(hipMalloc(&net->d_divcache, need));
-      net->divcache_bytes = need;
-    }
+    PITA_REQUIRE(sizeof(float) * ts->group_f(L) * (size_t)(total_waves * groups_per_wave) <= net->divcache_bytes,
+                 "pita_egnn_jacobian_trace: cache smaller than a chunk");
     if (sizeof(int) * (size_t)Bc > net->mark_bytes) {
       PITA_HIP_CHECK(hipStreamSynchronize(st));
       (void)hipFree(net->d_mark);

@@ -900,6 +900,37 @@ torch.save(tr.cpu(), sys.argv[1])
     assert torch.equal(outs[0], outs[1])
 
 
+def test_jacobian_trace_survives_a_cache_the_device_cannot_hold():
+    """With an unlimited budget 1.7 million LJ13 walkers would need a 306 GB primal cache: the allocation fails, smaller
+    chunks are tried until one fits, and the walkers' traces are the ones a small batch gives (child process: the budget
+    is read once)."""
+    import subprocess
+    import sys
+
+    code = """
+import os, sys, numpy as np, torch
+sys.path.insert(0, %r)
+import pita_amd as pa
+from pita_amd.data_utils import remove_mean
+w = dict(np.load(os.path.join(%r, "tests", "golden", "egnn_weights_trainedlike.npz")))
+net = pa.EGNN_dynamics(13, 3, hidden_nf=32, n_layers=3, recurrent=True, tanh=True, attention=True,
+                       condition_time=True, condition_temperature=True, agg="sum")
+net.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
+B = 1700000
+x = remove_mean(torch.randn(B, 39, generator=torch.Generator().manual_seed(2)).cuda() * 2.0, 13, 3)
+h = torch.full((B,), 1.5).cuda(); b = torch.ones(B).cuda()
+tr = net.jacobian_trace(h, x, b)
+small = net.jacobian_trace(h[:3001], x[:3001], b[:3001])
+tail = net.jacobian_trace(h[-2000:], x[-2000:], b[-2000:])
+assert torch.isfinite(tr).all()
+assert torch.equal(tr[:3001], small) and torch.equal(tr[-2000:], tail)
+print("ok")
+""" % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, PITA_DIV_CACHE_GB="100000"))
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
 def test_jacobian_trace_out_of_range_walkers_fall_back_to_bf16(pa, golden):
     """The f16 divergence kernel marks walkers whose trace term is non-finite (operands beyond the f16 range) and the
     bf16x3 kernel recomputes exactly those: far-out walkers must equal the pure bf16x3 result, ordinary walkers keep
