@@ -300,7 +300,8 @@ struct pita_egnn {
   float* d_divcache = nullptr;   // precision 2: per-edge primal factors of one trace (egnn_div_kernel.hip, DivCache)
   size_t divcache_bytes = 0;
   int* d_mark = nullptr;         // precision 2 divergence kernel: walkers left to the bf16x3 kernel (egnn_div_kernel.hip)
-  size_t mark_bytes = 0;
+  size_t mark_bytes = 0;         // capacity of the marks; one flag word sits behind them (egnn_div_kernel.hip: bad_flag)
+  int div_seq = 0;               // sequence number of the last launch that could mark walkers
   void* d_bk = nullptr;          // precision 2 sampler: walker backup + owed-moments markers for the repair launch
   size_t bk_bytes = 0;
 };

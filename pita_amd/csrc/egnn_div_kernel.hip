@@ -29,6 +29,8 @@ struct DivParams {
   int* mark;                // [B] fast kernel: 1 = this launch's contribution of the walker was non-finite and NOT added;
                             // this kernel with repair != 0: recompute and add exactly the marked walkers
   int repair;
+  int* bad_flag;            // one word behind the marks: the launch that marked a walker leaves its sequence number
+  int bad_seq;              // here, and the repair launches behind a launch that marked nobody return at once
   int n_layers, in_nf, attention, tanh_on, feature_layout;
   float coord_scale;
   long long B;
@@ -67,6 +69,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_kernel(DivParams p) {
   using C = DivCfg<N, DIM, G, WAVES, K>;
   constexpr int NT = C::NT;
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (p.repair && p.bad_flag && *p.bad_flag != p.bad_seq) return;  // the fast launch marked nobody
   const int L = p.n_layers;
   const int vec_f = C::vec_f(L);
   for (int i = threadIdx.x; i < VEC_EMB_F + L * VEC_LAYER_F; i += WAVES * 64) lds[i] = p.vecs[i];
@@ -396,7 +399,8 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_kernel(DivParams p) {
 // of its D / K launches (61 % of its vector work).  With `cache` set, the FIRST launch stores what the tangent chains
 // consume from the primal -- per layer the positions entering it, per node the scaled SiLU derivative of the node model,
 // per edge one (first / last layer) or four (middle layers) 16-float-per-lane vectors and a few scalars -- and
-// egnn_div_tangent_kernel runs the remaining directions from that cache, six per launch, without touching the primal:
+// the tangent-only kernels (wave-owned: K directions per launch; block-shared: NW K) run the remaining directions from
+// that cache without touching the primal:
 // ≈180 KB per walker (12 GB at 65 536 walkers: HBM capacity is what this GPU has to spare), streamed once per launch in
 // 1 KB wave-loads.  Layout per walker group g (a wave's G walkers) and layer l, in floats:
 //   [pos: POSF] then per tile T: [edge dd = 1..N-1: nv(l) x 1024 vectors | 8 x 64 scalars] [gn: 1024]
@@ -888,6 +892,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_fast_kernel(DivParams 
       if (valid[T] && hh == 0 && nodei[T] == 0) {
         if (!bad[T]) p.diag_acc[walker0 + w] += sum;
         p.mark[walker0 + w] = bad[T] ? 1 : 0;
+        if (bad[T] && p.bad_flag) *p.bad_flag = p.bad_seq;
       }
     }
     wave_lds_fence();
@@ -923,7 +928,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_fast_kernel(DivParams 
 // same walker quota, hence the same walker groups).  Per edge it recomputes the geometry from the cached layer
 // positions (same expressions as the fast kernel: same bits), loads the edge record and runs exactly the tangent
 // arithmetic of the fast kernel; no primal GEMM, no activation.  Wa dh_i lives in registers (no primal state competes
-// for them), so the LDS budget goes to K = 6 partner tables.
+// for them), so the LDS budget goes to the K partner tables.
 template <int N, int DIM, int G, int WAVES, int K>
 struct DivTanCfg {
   static constexpr int NCOL = G * N;
@@ -1220,6 +1225,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_tangent_kernel(DivPara
         const bool bad = !__builtin_isfinite(sum);
         if (!bad) p.diag_acc[walker0 + w] += sum;
         p.mark[walker0 + w] = bad ? 1 : 0;
+        if (bad && p.bad_flag) *p.bad_flag = p.bad_seq;
       }
     }
     wave_lds_fence();
@@ -1466,6 +1472,7 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
           const bool bad = !__builtin_isfinite(v);
           if (!bad) p.diag_acc[wid] += v;
           p.mark[wid] = bad ? 1 : 0;
+          if (bad && p.bad_flag) *p.bad_flag = p.bad_seq;
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1964,6 +1971,20 @@ extern "C" int pita_egnn_div_work(const pita_egnn_t* net, double* mfma16_per_wal
   return PITA_OK;
 }
 
+// marks [B] + the flag word behind them (DivParams::bad_flag)
+static int ensure_marks(pita_egnn_t* net, size_t B, hipStream_t st) {
+  if (sizeof(int) * B > net->mark_bytes) {
+    PITA_HIP_CHECK(hipStreamSynchronize(st));
+    (void)hipFree(net->d_mark);
+    net->d_mark = nullptr;
+    net->mark_bytes = 0;
+    PITA_HIP_CHECK(hipMalloc(&net->d_mark, sizeof(int) * B + 64));
+    net->mark_bytes = sizeof(int) * B;
+    PITA_HIP_CHECK(hipMemsetAsync(net->d_mark + B, 0, 64, st));
+  }
+  return PITA_OK;
+}
+
 static int div_launch(const DivShape* s, void (*kernel)(DivParams), pita_egnn_t* net, const DivParams& p, void* stream) {
   const size_t lds = s->lds_bytes(p.n_layers);
   PITA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1999,15 +2020,13 @@ extern "C" int pita_egnn_div_accumulate(pita_egnn_t* net, const float* h, const 
   if (!fast) return div_launch(s, s->kernel, net, p, stream);
   // f16 kernel first: it adds the finite terms and marks the walkers whose term was not; then the bf16x3 kernel
   // recomputes exactly the marked ones (in chunks of its own K directions)
-  if (sizeof(int) * (size_t)B > net->mark_bytes) {
-    PITA_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-    (void)hipFree(net->d_mark);
-    net->d_mark = nullptr;
-    net->mark_bytes = 0;
-    PITA_HIP_CHECK(hipMalloc(&net->d_mark, sizeof(int) * (size_t)B));
-    net->mark_bytes = sizeof(int) * (size_t)B;
+  {
+    const int rc0 = ensure_marks(net, (size_t)B, (hipStream_t)stream);
+    if (rc0 != PITA_OK) return rc0;
   }
   p.mark = net->d_mark;
+  p.bad_flag = net->d_mark + net->mark_bytes / sizeof(int);
+  p.bad_seq = ++net->div_seq;
   int rc = div_launch(sf, sf->fast, net, p, stream);
   if (rc != PITA_OK) return rc;
   p.repair = 1;
@@ -2024,7 +2043,7 @@ extern "C" int pita_egnn_div_accumulate(pita_egnn_t* net, const float* h, const 
 
 // Exact trace of the denoiser Jacobian over ALL directions: trace[b] = sum_d (J_x D(h, x) e_d)_d (overwritten), optionally
 // the denoiser itself.  Precision-2 handles with a tangent-only kernel take the primal-cache path: ONE launch of the fast
-// kernel (first K directions, writes the per-edge primal factors), then tangent-only launches of up to six directions
+// kernel (its own directions, writes the per-edge primal factors), then tangent-only launches
 // that stream the cache -- each followed by the bf16x3 repair pass for marked walkers.  The cache (≈180 KB per walker for
 // LJ13) is owned by the handle; batches whose cache would exceed PITA_DIV_CACHE_GB (default 24) are processed in chunks
 // of walkers.  Other handles loop pita_egnn_div_accumulate.
@@ -2108,15 +2127,12 @@ extern "C" int pita_egnn_jacobian_trace(pita_egnn_t* net, const float* h, const 
     const long long groups_per_wave = (quota + s->G - 1) / s->G;
     PITA_REQUIRE(sizeof(float) * ts->group_f(L) * (size_t)(total_waves * groups_per_wave) <= net->divcache_bytes,
                  "pita_egnn_jacobian_trace: cache smaller than a chunk");
-    if (sizeof(int) * (size_t)Bc > net->mark_bytes) {
-      PITA_HIP_CHECK(hipStreamSynchronize(st));
-      (void)hipFree(net->d_mark);
-      net->d_mark = nullptr;
-      net->mark_bytes = 0;
-      PITA_HIP_CHECK(hipMalloc(&net->d_mark, sizeof(int) * (size_t)Bc));
-      net->mark_bytes = sizeof(int) * (size_t)Bc;
+    {
+      const int rc0 = ensure_marks(net, (size_t)Bc, st);
+      if (rc0 != PITA_OK) return rc0;
     }
     p.mark = net->d_mark;
+    p.bad_flag = net->d_mark + net->mark_bytes / sizeof(int);
     p.cache = net->d_divcache;
     p.cache_waves = total_waves;
     PITA_REQUIRE(total_waves * groups_per_wave < 0x7fffffffLL, "pita_egnn_jacobian_trace: too many walker groups in one chunk");
@@ -2138,6 +2154,7 @@ extern "C" int pita_egnn_jacobian_trace(pita_egnn_t* net, const float* h, const 
     if (wr && (wr->G != s->G || wr->waves != s->waves)) wr = nullptr;
     const int first_k = wr ? wr->K : s->K;
     p.dir0 = 0; p.ndir = first_k < D ? first_k : D; p.out = denoiser_out ? denoiser_out + b0 * D : nullptr;
+    p.bad_seq = ++net->div_seq;
     int rc = div_launch(wr ? wr : s, wr ? wr->fast : s->fast, net, p, stream);
     if (rc != PITA_OK) return rc;
     rc = repair(0, p.ndir, p.out);
@@ -2157,6 +2174,7 @@ extern "C" int pita_egnn_jacobian_trace(pita_egnn_t* net, const float* h, const 
     for (int d0 = first_k; d0 < D; d0 += per_launch) {
       p.dir0 = d0;
       p.ndir = (D - d0) < per_launch ? (D - d0) : per_launch;
+      p.bad_seq = ++net->div_seq;
       hipLaunchKernelGGL(ts->kernel, dim3((unsigned)tgrid), dim3(ts->waves * 64), lds, st, p);
       PITA_LAUNCH_CHECK();
       rc = repair(d0, p.ndir, nullptr);

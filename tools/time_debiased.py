@@ -20,7 +20,7 @@ sde.f(t, x, 1.0, gam, None, None); torch.cuda.synchronize()
 t0 = time.perf_counter(); reps = 3
 for _ in range(reps): terms = sde.f(t, x, 1.0, gam, None, None)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
-print(f"debiased f: B={B}: {dt*1e3:.1f} ms per step -> {B/dt:.3e} walker-steps/s (13 div + 1 JVP + 1 VJP launches + assembly)")
+print(f"debiased f: B={B}: {dt*1e3:.1f} ms per step -> {B/dt:.3e} walker-steps/s (Jacobian trace + 1 reverse-mode launch + assembly)")
 _, d = net.jvp(torch.full((B,), 1.0).cuda(), x, torch.ones(B).cuda(), direction=0); torch.cuda.synchronize()
 t0 = time.perf_counter()
 for k in range(20): net.jvp(torch.full((B,), 1.0).cuda(), x, torch.ones(B).cuda(), direction=k, want_primal=False)
