@@ -473,8 +473,8 @@ __device__ __forceinline__ void silu_dsilu16(const f32x16& vin, float pre, f32x1
   }
 }
 
-template <int N, int DIM, int G, int WAVES, int K, int DAL>
-__global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_fast_kernel(DivParams p) {
+template <int N, int DIM, int G, int WAVES, int K, int DAL, int OCC = 1>
+__global__ void __launch_bounds__(WAVES * 64, OCC) egnn_div_fast_kernel(DivParams p) {
   using C = DivCfg<N, DIM, G, WAVES, K, DAL>;
   constexpr int NT = C::NT;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1791,6 +1791,7 @@ struct DivShape {
   void (*kernel)(DivParams);
   void (*fast)(DivParams);
   size_t (*lds_bytes)(int);
+  int occ = 1;  // blocks per CU the fast kernel is built for (grid cap)
 };
 template <int N, int DIM, int G, int WAVES, int K, int DAL>
 static size_t div_lds_bytes_of(int L) { return DivCfg<N, DIM, G, WAVES, K, DAL>::lds_bytes(L); }
@@ -1815,7 +1816,12 @@ static const DivShape kDivAlt[] = {PITA_DIV_SHAPE(13, 3, 2, 4, 2)};
 // cache writers for the block-shared tangent kernel: the first launch of a trace carries ONE direction (the tangent-only
 // launches take 16 each, so 1 + 13 + 13 + 12 beats 3 + 16 + 16 + 4 for LJ13: the primal launch is lighter and the three
 // streams are balanced)
-static const DivShape kDivWriters[] = {PITA_DIV_FAST_SHAPE(13, 3, 2, 4, 1), PITA_DIV_FAST_SHAPE(22, 3, 1, 4, 1)};
+// (measured with two blocks per CU, i.e. two waves per SIMD at 256 registers: 976 B/lane of scratch, the launch takes
+// 14 ms instead of 5 -- the primal's adjoint factors plus one tangent chain need the 492 registers it uses)
+#define PITA_DIV_WRITER_SHAPE(N, DIM, G, WAVES) \
+  DivShape { N, DIM, G, WAVES, 1, nullptr, egnn_div_fast_kernel<N, DIM, G, WAVES, 1, 0, 1>, \
+             div_lds_bytes_of<N, DIM, G, WAVES, 1, 0>, 1 }
+static const DivShape kDivWriters[] = {PITA_DIV_WRITER_SHAPE(13, 3, 2, 4), PITA_DIV_WRITER_SHAPE(22, 3, 1, 4)};
 static const DivShape* find_div_writer(int n, int dim) {
   static const bool off = getenv("PITA_DIV_NOWRITER") != nullptr;  // development aid
   if (off) return nullptr;
@@ -1991,7 +1997,7 @@ static int div_launch(const DivShape* s, void (*kernel)(DivParams), pita_egnn_t*
                                      (int)lds));
   const long long ngroups = (p.B + s->G - 1) / s->G;
   long long want = (ngroups + s->waves - 1) / s->waves;
-  const long long cap = net->n_cu;  // one 4-wave block per CU (one wave per SIMD)
+  const long long cap = (long long)net->n_cu * s->occ;  // one 4-wave block per CU (one wave per SIMD) unless built for more
   const unsigned grid = (unsigned)(want < cap ? want : cap);
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(s->waves * 64), lds, (hipStream_t)stream, p);
   PITA_LAUNCH_CHECK();
@@ -2076,10 +2082,14 @@ extern "C" int pita_egnn_jacobian_trace(pita_egnn_t* net, const float* h, const 
   if (chunk < 1024) chunk = 1024;
   if (chunk > B) chunk = B;
   // cache bytes a chunk of Bc walkers needs (grid of the fast kernel: the cache is indexed by wave and group)
+  // the launch that writes the cache: the system's fast kernel, or a one-direction writer for the block-shared stream
+  const DivShape* wr = ts->shared ? find_div_writer(n, dim) : nullptr;
+  if (wr && (wr->G != s->G || wr->waves != s->waves)) wr = nullptr;
+  const long long grid_cap = (long long)net->n_cu * (wr ? wr->occ : s->occ);
   auto cache_need = [&](long long Bc) -> size_t {
     const long long ngroups = (Bc + s->G - 1) / s->G;
     const long long want = (ngroups + s->waves - 1) / s->waves;
-    const long long grid = want < (long long)net->n_cu ? want : (long long)net->n_cu;
+    const long long grid = want < grid_cap ? want : grid_cap;
     const long long total_waves = grid * s->waves;
     const long long quota = (Bc + total_waves - 1) / total_waves;
     return sizeof(float) * ts->group_f(L) * (size_t)(total_waves * ((quota + s->G - 1) / s->G));
@@ -2121,7 +2131,7 @@ extern "C" int pita_egnn_jacobian_trace(pita_egnn_t* net, const float* h, const 
     // grid of the fast / tangent kernels (identical: the cache is indexed by wave and group)
     const long long ngroups = (Bc + s->G - 1) / s->G;
     long long want = (ngroups + s->waves - 1) / s->waves;
-    const long long grid = want < (long long)net->n_cu ? want : (long long)net->n_cu;
+    const long long grid = want < grid_cap ? want : grid_cap;
     const long long total_waves = grid * s->waves;
     const long long quota = (Bc + total_waves - 1) / total_waves;
     const long long groups_per_wave = (quota + s->G - 1) / s->G;
@@ -2150,8 +2160,6 @@ extern "C" int pita_egnn_jacobian_trace(pita_egnn_t* net, const float* h, const 
       return PITA_OK;
     };
     // first launch: primal + its own directions, cache written
-    const DivShape* wr = ts->shared ? find_div_writer(n, dim) : nullptr;
-    if (wr && (wr->G != s->G || wr->waves != s->waves)) wr = nullptr;
     const int first_k = wr ? wr->K : s->K;
     p.dir0 = 0; p.ndir = first_k < D ? first_k : D; p.out = denoiser_out ? denoiser_out + b0 * D : nullptr;
     p.bad_seq = ++net->div_seq;
