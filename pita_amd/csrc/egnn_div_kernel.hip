@@ -2145,7 +2145,8 @@ extern "C" int pita_egnn_jacobian_trace(pita_egnn_t* net, const float* h, const 
     p.bad_flag = net->d_mark + net->mark_bytes / sizeof(int);
     p.cache = net->d_divcache;
     p.cache_waves = total_waves;
-    PITA_REQUIRE(total_waves * groups_per_wave < 0x7fffffffLL, "pita_egnn_jacobian_trace: too many walker groups in one chunk");
+    PITA_REQUIRE(total_waves * groups_per_wave < 0x7fffffffLL && Bc < 0x7fffffffLL,
+                 "pita_egnn_jacobian_trace: too many walkers in one chunk");
     auto repair = [&](int dir0, int ndir, float* out) -> int {  // bf16x3 kernel for the marked walkers, its own K at a time
       DivParams r = p;
       r.repair = 1;
