@@ -247,22 +247,45 @@ __device__ __forceinline__ f32x2 silu2_scaled(f32x2 v) {
   r.y = __builtin_amdgcn_rcpf(d.y);
   return v * r;
 }
-__device__ __forceinline__ void silu16_out(f32x16& m) {
+// staged over SILU_BATCH pairs at a time: the exponentials of several pairs are issued back to back, then the adds,
+// the reciprocals, the products -- independent work between a transcendental and its consumer instead of hazard nops
+#ifndef PITA_SILU_BATCH
+#define PITA_SILU_BATCH 8
+#endif
+template <bool UNSCALE>
+__device__ __forceinline__ void silu16_staged(f32x16& m) {
+  constexpr int Q = PITA_SILU_BATCH;
+  const f32x2 c = {1.0f / F16_SX, 1.0f / F16_SX};
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const f32x2 y = silu2_scaled(f32x2{m[2 * q], m[2 * q + 1]});
-    m[2 * q] = y.x;
-    m[2 * q + 1] = y.y;
+  for (int q0 = 0; q0 < 8; q0 += Q) {
+    f32x2 v[Q], e[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      v[q] = f32x2{m[2 * (q0 + q)], m[2 * (q0 + q) + 1]};
+      if (UNSCALE) v[q] = v[q] * F16_UNSCALE;
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      e[q].x = __builtin_amdgcn_exp2f(v[q].x);
+      e[q].y = __builtin_amdgcn_exp2f(v[q].y);
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) e[q] = __builtin_elementwise_fma(e[q], c, c);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      e[q].x = __builtin_amdgcn_rcpf(e[q].x);
+      e[q].y = __builtin_amdgcn_rcpf(e[q].y);
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const f32x2 y = v[q] * e[q];
+      m[2 * (q0 + q)] = y.x;
+      m[2 * (q0 + q) + 1] = y.y;
+    }
   }
 }
-__device__ __forceinline__ void silu16_acc(f32x16& m) {
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const f32x2 y = silu2_scaled(f32x2{m[2 * q], m[2 * q + 1]} * F16_UNSCALE);
-    m[2 * q] = y.x;
-    m[2 * q + 1] = y.y;
-  }
-}
+__device__ __forceinline__ void silu16_out(f32x16& m) { silu16_staged<false>(m); }
+__device__ __forceinline__ void silu16_acc(f32x16& m) { silu16_staged<true>(m); }
 
 __device__ __forceinline__ float dot16(const f32x16& w, const f32x16& m) {
   f32x2 acc = {0.f, 0.f};
