@@ -462,14 +462,17 @@ __device__ __forceinline__ f32x16 cache_load16(const float* base, int lane) {
 //       g1 o (w_r + w_e) times the scalar dradial_d: one W2 GEMM per edge for all directions.
 //     Per edge over three layers: 6 primal + 4 adjoint + 1 + K tangent GEMMs instead of 6 + 6 K.
 __device__ __forceinline__ void silu_dsilu16(const f32x16& vin, float pre, f32x16& y, f32x16& g) {
+  // staged: all exponentials, then all reciprocals, then the products (no consumer directly behind its transcendental)
+  f32x16 v = vin * pre, e, sg;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(v[r]);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sg[r] = __builtin_amdgcn_rcpf(1.0f + e[r]);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const float v = vin[r] * pre;
-    const float e = __builtin_amdgcn_exp2f(v);
-    const float sg = __builtin_amdgcn_rcpf(1.0f + e);
-    const float yy = v * sg;
+    const float yy = v[r] * sg[r];
     y[r] = yy;
-    g[r] = fmaf(yy * (1.0f / SILU_PRESCALE), e * sg, sg);  // s (1 + z (1 - s)), z = v / kS, 1 - s = e s
+    g[r] = fmaf(yy * (1.0f / SILU_PRESCALE), e[r] * sg[r], sg[r]);  // s (1 + z (1 - s)), z = v / kS, 1 - s = e s
   }
 }
 

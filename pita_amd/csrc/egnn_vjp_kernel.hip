@@ -82,6 +82,21 @@ __device__ __forceinline__ void silu_grad(float v, float& y, float& g) {
   g = s * fmaf(v * (1.0f / SILU_PRESCALE), 1.0f - s, 1.0f);
 }
 
+// the same for a 16-element vector, staged (exponentials, reciprocals, products): same values, no transcendental with
+// its consumer directly behind it
+__device__ __forceinline__ void silu_grad16(const f32x16& v, f32x16& y, f32x16& g) {
+  f32x16 s;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(v[r]);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_rcpf(1.0f + s[r]);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    y[r] = v[r] * s[r];
+    g[r] = s[r] * fmaf(v[r] * (1.0f / SILU_PRESCALE), 1.0f - s[r], 1.0f);
+  }
+}
+
 __device__ __forceinline__ void lds_add16(float* dst, const f32x16& v) {
   f32x4* p = reinterpret_cast<f32x4*>(dst);
 #pragma unroll
@@ -368,8 +383,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
           WFrag<1> wt;
           wt.load(nullptr, mats16, M_WN2T, lane);
           f32x16 znb = wt.mul(hb[T], zero16);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) { float y, g; silu_grad(zn[r], y, g); znb[r] *= g; }
+          { f32x16 yv, gv; silu_grad16(zn, yv, gv); znb *= gv; }
           wt.load(nullptr, mats16, M_WN1BT, lane);
           aggb = wt.mul(znb, zero16);
           if (l > 0 || p.dot_h) {
@@ -399,11 +413,9 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
           f32x16 z = Ai + lds_vec16(PB + cj * PBS + hh * 16);
           z = __builtin_amdgcn_mfma_f32_32x32x2f32(a_re, hh ? ea : radial, z, 0, 0, 0);
           f32x16 g1, g2, m2, gc;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) { float y, g; silu_grad(z[r], y, g); z[r] = y; g1[r] = g; }
+          { f32x16 yv; silu_grad16(z, yv, g1); z = yv; }
           z = w2f.mul(z, lds_vec16(vl + V_B2 * EH));
-#pragma unroll
-          for (int r = 0; r < 16; ++r) { float y, g; silu_grad(z[r], y, g); m2[r] = y; g2[r] = g; }
+          silu_grad16(z, m2, g2);
           float att = 1.0f;
           f32x16 m = m2;
           if (p.attention) {
@@ -411,8 +423,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
             m *= att;
           }
           z = wc1f.mul(m, lds_vec16(vl + V_BC1 * EH));
-#pragma unroll
-          for (int r = 0; r < 16; ++r) { float y, g; silu_grad(z[r], y, g); z[r] = y; gc[r] = g; }
+          { f32x16 yv; silu_grad16(z, yv, gc); z = yv; }
           const f32x16 v_wc2 = lds_vec16(vl + V_WC2 * EH);
           float cs = xhalf_sum(dot16(v_wc2, z)), dcs_raw = 1.0f;
           if (p.tanh_on) {
