@@ -225,10 +225,23 @@ __device__ __forceinline__ f32x2 silu2(f32x2 v) {
   r.y = __builtin_amdgcn_rcpf(d.y);
   return v * r;
 }
-__device__ __forceinline__ void silu16(f32x16& m) {
+__device__ __forceinline__ void silu16(f32x16& m) {  // staged like silu16_staged below: same values
+  f32x2 e[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
-    const f32x2 y = silu2(f32x2{m[2 * q], m[2 * q + 1]});
+    e[q].x = __builtin_amdgcn_exp2f(m[2 * q]);
+    e[q].y = __builtin_amdgcn_exp2f(m[2 * q + 1]);
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) e[q] = e[q] + 1.0f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    e[q].x = __builtin_amdgcn_rcpf(e[q].x);
+    e[q].y = __builtin_amdgcn_rcpf(e[q].y);
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const f32x2 y = f32x2{m[2 * q], m[2 * q + 1]} * e[q];
     m[2 * q] = y.x;
     m[2 * q + 1] = y.y;
   }
