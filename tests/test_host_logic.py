@@ -34,3 +34,17 @@ def test_terms_from_stats_layout():
     assert terms[1].cross_term.n == 0 and np.isnan(float(terms[1].cross_term.mean()))
     nodeb = pita_amd.sde_integration._terms_from_stats(st4, None, 10, 5, [True, True], False)
     assert nodeb[0].divergence_score is None and nodeb[0].drift_A.n == 5
+
+
+def test_smooth_lj_core_coefficients_match_the_reference(golden):
+    """The four spline coefficients LennardJonesEnergy(smooth=True) hands to pita_lj_smooth_logp_force are the reference's
+    (lennardjones_energy.py:114-119: scipy CubicSpline through the float32 LJ curve, first interval), bit for bit."""
+    import numpy as np
+
+    from pita_amd.lennardjones_energy import smooth_core_coefficients
+
+    g = golden("lj13_smooth_logp_force.npz")
+    coef, r0 = smooth_core_coefficients()
+    assert coef.dtype == np.float32 and coef.shape == (4,)
+    np.testing.assert_array_equal(coef, g["spline_c0"])
+    assert np.float32(r0) == g["spline_x0"][0]
