@@ -863,6 +863,44 @@ def test_jacobian_trace_large_batches_block_shared_stream(pa, golden, n, B):
     np.testing.assert_allclose(tr.cpu().numpy(), acc.cpu().numpy(), rtol=2e-5, atol=2e-5 * scale)
 
 
+@pytest.mark.parametrize("variant", ["no_attention", "no_tanh", "layers2", "layers4", "layers5"])
+def test_jacobian_trace_network_variants(pa, golden, variant):
+    """The cached / block-shared trace path for the network options the kernels branch on (gate off, tanh off, fewer and
+    more layers than the reference configs' three): equal to the trace assembled from single-direction forward-mode
+    launches, for a batch with several walker groups per block."""
+    w = {k: T(v) for k, v in golden("egnn_weights_trainedlike.npz").items()}
+    kw = dict(hidden_nf=32, n_layers=3, recurrent=True, tanh=True, attention=True, condition_time=True,
+              condition_temperature=True, agg="sum")
+    if variant == "no_attention":
+        kw["attention"] = False
+    elif variant == "no_tanh":
+        kw["tanh"] = False
+    elif variant == "layers2":
+        kw["n_layers"] = 2
+    elif variant == "layers4":
+        kw["n_layers"] = 4
+    elif variant == "layers5":  # deeper than the block-shared kernel's LDS budget: the wave-owned tangent kernel takes over
+        kw["n_layers"] = 5
+    net = pa.EGNN_dynamics(13, 3, **kw)
+    sd = net.state_dict()
+    gen = torch.Generator().manual_seed(17)
+    for k in sd:  # reuse the trained-like tensors where the shapes agree, seeded noise elsewhere (extra layer)
+        src = w.get(k, w.get(k.replace("gcl_3", "gcl_1")))
+        sd[k] = src.clone() if src is not None and src.shape == sd[k].shape else 0.2 * torch.randn(sd[k].shape, generator=gen)
+    net.load_state_dict(sd)
+    B = 3001
+    h = torch.tensor([0.05, 0.8, 12.0])[torch.arange(B) % 3].cuda()
+    x = O.remove_mean(torch.randn(B, 39, generator=gen) * (1 + h.cpu().sqrt())[:, None], 13, 3).cuda()
+    beta = (torch.rand(B, generator=gen) + 0.7).cuda()
+    tr = net.jacobian_trace(h, x, beta)
+    acc = torch.zeros(B, device="cuda")
+    for k in range(39):
+        net.jvp(h, x, beta, direction=k, want_primal=False, want_tangent=False, diag_acc=acc)
+    scale = float(acc.abs().mean()) + 1.0
+    assert torch.isfinite(tr).all()
+    np.testing.assert_allclose(tr.cpu().numpy(), acc.cpu().numpy(), rtol=2e-5, atol=2e-5 * scale)
+
+
 def test_jacobian_trace_in_cache_chunks(golden):
     """A batch whose primal cache exceeds PITA_DIV_CACHE_GB is processed in chunks of walkers; the result does not
     depend on the chunking (the budget is read once per process, so this runs in a child process)."""
