@@ -123,6 +123,8 @@ class _Comm:
         W, r = self.world, self.rank
         if W == 1:
             return gather_rows(x, ids)
+        if Bl == 0:  # fewer walkers than ranks: every shard is empty (sde_integration.py:227)
+            return x
         if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
             return gather_rows(self.all_gather(x), ids)[r * Bl:(r + 1) * Bl].clone()  # Lightning's all_gather only
         n = W * Bl
