@@ -1295,23 +1295,6 @@ __device__ __forceinline__ void glds16s(unsigned lds_byte, const float* sbase, u
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
 }
-// at most n of this wave's vector-memory operations pending (rare path: start and end of the stream)
-__device__ __forceinline__ void wait_vmcnt_upto(int n) {
-#define PITA_VMW(k) asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory")
-  if (n >= 8) { if (n >= 12) PITA_VMW(12); else PITA_VMW(8); }
-  else if (n >= 4) { if (n >= 6) PITA_VMW(6); else if (n == 5) PITA_VMW(5); else PITA_VMW(4); }
-  else if (n >= 2) { if (n == 3) PITA_VMW(3); else PITA_VMW(2); }
-  else if (n == 1) PITA_VMW(1);
-  else PITA_VMW(0);
-#undef PITA_VMW
-}
-template <int N_>
-__device__ __forceinline__ void wait_vmcnt_const() {
-#define PITA_VMC(k) if constexpr (N_ == k) asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory")
-  PITA_VMC(1); PITA_VMC(2); PITA_VMC(3); PITA_VMC(4); PITA_VMC(5); PITA_VMC(6); PITA_VMC(7); PITA_VMC(8);
-  PITA_VMC(9); PITA_VMC(10); PITA_VMC(11); PITA_VMC(12); PITA_VMC(13); PITA_VMC(14); PITA_VMC(15); PITA_VMC(16);
-#undef PITA_VMC
-}
 __device__ __forceinline__ f32x16 slot_vec16(const float* rec, int v, int lane) {  // vector v of a record (cache_store16 layout)
   const f32x4* d = reinterpret_cast<const f32x4*>(rec + v * 1024) + lane;
   f32x16 r;
