@@ -1833,6 +1833,7 @@ struct DivTanShape {
   void (*kernel)(DivParams);
   size_t (*lds_bytes)(int);
   size_t (*group_f)(int);  // cache floats per walker group
+  bool (*fits)(int);       // block-shared kernel: the network depth fits its LDS budget and piece table
 };
 template <int N, int DIM, int G, int WAVES, int K>
 static size_t divtan_lds_of(int L) { return DivTanCfg<N, DIM, G, WAVES, K>::lds_bytes(L); }
@@ -1840,12 +1841,25 @@ template <int N, int DIM, int G>
 static size_t divcache_group_f(int L) { return DivCache<N, DIM, (G * N + 31) / 32>::group_f(L); }
 #define PITA_DIVTAN_SHAPE(N, DIM, G, WAVES, K) \
   DivTanShape { N, DIM, G, WAVES, K, 0, egnn_div_tangent_kernel<N, DIM, G, WAVES, K>, divtan_lds_of<N, DIM, G, WAVES, K>, \
-                divcache_group_f<N, DIM, G> }
+                divcache_group_f<N, DIM, G>, nullptr }
+// items of one group's sweep (as the kernel's piece table lays them out) against the table's capacity
+template <int N, int DIM, int G, int NW, int K>
+static bool divshr_fits(int L) {
+  using C = DivShrCfg<N, DIM, G, NW, K>;
+  using CA = DivCache<N, DIM, C::NT>;
+  if (L > SHR_LMAX) return false;
+  long long items = 0;
+  for (int l = 0; l < L; ++l) {
+    const int epi = SHR_S / (int)(CA::edge_f(l, L) / 256);
+    items += 1 + (long long)C::NT * ((N - 1 + epi - 1) / epi + 1);
+  }
+  return items * SHR_S <= C::MAX_P;
+}
 template <int N, int DIM, int G, int NW, int K>
 static size_t divshr_lds_of(int L) { return DivShrCfg<N, DIM, G, NW, K>::lds_bytes(L); }
 #define PITA_DIVSHR_SHAPE(N, DIM, G, NW, K) \
   DivTanShape { N, DIM, G, NW, K, 1, egnn_div_tangent_shared_kernel<N, DIM, G, NW, K>, divshr_lds_of<N, DIM, G, NW, K>, \
-                divcache_group_f<N, DIM, G> }
+                divcache_group_f<N, DIM, G>, divshr_fits<N, DIM, G, NW, K> }
 // LJ13, all 39 directions at 65 536 walkers (first launch 5.7 ms incl. the 12 GB cache write): K = 3: 34.9 ms, K = 4:
 // 32.9 ms (9 launches of 3.0 ms = 4 TB/s of cache reads), K = 5: 39.6 ms, K = 6: 44.0 ms (528 / 860 B/lane of scratch);
 // without the cache (13 fast launches): 59-62 ms.  Also measured: the four waves of a block sharing ONE walker group with
@@ -1877,11 +1891,11 @@ static const DivTanShape* find_div_tan_shape(int n, int dim, int n_layers) {
       if (kDivTanAlt[i].n == n && kDivTanAlt[i].dim == dim) return &kDivTanAlt[i];
   } else if (alt >= 2 && alt <= nalt) {
     const auto& c = kDivTanAlt[alt - 1];
-    if (c.n == n && c.dim == dim && (!c.shared || n_layers <= SHR_LMAX)) return &c;
+    if (c.n == n && c.dim == dim && (!c.shared || c.fits(n_layers))) return &c;
   }
   for (const auto& c : kDivTan)
     if (c.n == n && c.dim == dim) {
-      if (!c.shared || n_layers <= SHR_LMAX) return &c;
+      if (!c.shared || c.fits(n_layers)) return &c;
       for (int i = 0; i < 2; ++i)
         if (kDivTanAlt[i].n == n && kDivTanAlt[i].dim == dim) return &kDivTanAlt[i];
       return nullptr;

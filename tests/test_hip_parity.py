@@ -901,6 +901,30 @@ def test_jacobian_trace_network_variants(pa, golden, variant):
     np.testing.assert_allclose(tr.cpu().numpy(), acc.cpu().numpy(), rtol=2e-5, atol=2e-5 * scale)
 
 
+def test_jacobian_trace_22_atoms_four_layers(pa, golden):
+    """22 atoms x 4 layers: the sweep's piece sequence exceeds the block-shared kernel's table, so the wave-owned
+    tangent kernel must take over (a silent overflow would give garbage)."""
+    w = {k: T(v) for k, v in golden("egnn_weights_trainedlike.npz").items()}
+    net = pa.EGNN_dynamics(22, 3, hidden_nf=32, n_layers=4, recurrent=True, tanh=True, attention=True, condition_time=True,
+                           condition_temperature=True, agg="sum")
+    sd = net.state_dict()
+    gen = torch.Generator().manual_seed(23)
+    for k in sd:
+        src = w.get(k, w.get(k.replace("gcl_3", "gcl_1")))
+        sd[k] = src.clone() if src is not None and src.shape == sd[k].shape else 0.2 * torch.randn(sd[k].shape, generator=gen)
+    net.load_state_dict(sd)
+    B = 1501
+    h = torch.tensor([0.05, 0.8, 12.0])[torch.arange(B) % 3].cuda()
+    x = O.remove_mean(torch.randn(B, 66, generator=gen) * (1 + h.cpu().sqrt())[:, None], 22, 3).cuda()
+    beta = (torch.rand(B, generator=gen) + 0.7).cuda()
+    tr = net.jacobian_trace(h, x, beta)
+    acc = torch.zeros(B, device="cuda")
+    for k in range(66):
+        net.jvp(h, x, beta, direction=k, want_primal=False, want_tangent=False, diag_acc=acc)
+    scale = float(acc.abs().mean()) + 1.0
+    np.testing.assert_allclose(tr.cpu().numpy(), acc.cpu().numpy(), rtol=2e-5, atol=2e-5 * scale)
+
+
 def test_jacobian_trace_in_cache_chunks(golden):
     """A batch whose primal cache exceeds PITA_DIV_CACHE_GB is processed in chunks of walkers; the result does not
     depend on the chunking (the budget is read once per process, so this runs in a child process)."""
