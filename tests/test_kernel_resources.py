@@ -1,0 +1,57 @@
+"""Register / scratch budget of the performance-critical kernels, read from the built objects (no GPU needed).  The
+kernels are designed against fixed occupancies -- two waves per SIMD at 256 registers for the fused sampler and the
+block-shared tangent kernel -- and a change that pushes spill code into their loops costs far more than it looks
+(scratch is vector memory: in the tangent kernel every spill waits behind the LDS-DMA prefetch window)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def _kernels(obj):
+    fb, co = "/tmp/_kr_test.fb", "/tmp/_kr_test.co"
+    subprocess.run([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fb}", obj], check=True, capture_output=True)
+    subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fb}", f"--output={co}",
+                    "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], check=True, capture_output=True)
+    txt = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
+    out = {}
+    for m in re.finditer(r"\.agpr_count:\s+(\d+).*?\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?"
+                         r"\.vgpr_count:\s+(\d+)", txt, re.S):
+        ag, name, scr, vg = m.groups()
+        dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
+        out[re.sub(r"\(.*", "", dem).replace("void pita::", "")] = dict(vgpr=int(vg), agpr=int(ag), scratch=int(scr))
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(f"{LLVM}/llvm-readelf") or shutil.which("c++filt") is None,
+                    reason="needs the ROCm LLVM binutils")
+def test_register_and_scratch_budgets():
+    import pita_amd.build as build
+
+    build.build(verbose=False)
+    k = {}
+    for f in ("egnn_kernel.o", "egnn_div_kernel.o", "energy_kernels.o"):
+        k.update(_kernels(os.path.join(ROOT, "pita_amd", "csrc", f)))
+    # fused sampler, default precision, every instantiated system: two waves per SIMD (<= 256 registers in total), its
+    # spill code stays outside the edge loop (140 B/lane for LJ13 today)
+    for name in ("egnn_kernel<13, 3, 7, 4, 2, true, 2>", "egnn_kernel<4, 2, 8, 4, 2, true, 2>",
+                 "egnn_kernel<22, 3, 4, 4, 2, true, 2>", "egnn_kernel<55, 3, 1, 4, 2, true, 2>"):
+        r = k[name]
+        assert r["vgpr"] + r["agpr"] <= 256 and r["scratch"] <= 256, (name, r)
+    # block-shared tangent kernels: 256 registers, a few dwords of spill outside the item loops at most
+    for name in ("egnn_div_tangent_shared_kernel<13, 3, 2, 8, 2>", "egnn_div_tangent_shared_kernel<22, 3, 1, 8, 2>"):
+        r = k[name]
+        assert r["vgpr"] + r["agpr"] <= 256 and r["scratch"] <= 96, (name, r)
+    # the cache writer must not spill at all (one wave per SIMD, 512 registers)
+    assert k["egnn_div_fast_kernel<13, 3, 2, 4, 1, 0, 1>"]["scratch"] == 0
+    # target kernels: no scratch (the fused MALA chain carries two force sets and spills a little between its phases)
+    for name, r in k.items():
+        if name.startswith("lj13_mala"):
+            assert r["scratch"] <= 192, (name, r)
+        elif name.startswith("lj13_") or name.startswith("pair_"):
+            assert r["scratch"] == 0, (name, r)
