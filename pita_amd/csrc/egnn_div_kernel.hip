@@ -14,6 +14,8 @@
 //
 // Mapping: as egnn_jvp_kernel.hip (wave = G walkers = dense 32-column tiles, lane = column x 16 features, exact 3-way
 // bf16 split on the matrix pipe, tangents in the lane/register position of their primals); one wave per SIMD.
+#include <type_traits>
+
 #include "egnn_common.h"
 
 namespace pita {
@@ -1537,7 +1539,6 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
       end_item();
       const float a_re = vecs[VEC_EMB_F + l * VEC_LAYER_F + V_WRE * EH + lane];
       const float aggw = (l == L - 1) ? 0.0f : 1.0f;
-      const int nv = CA::nvec(l, L), erec = nv * 1024 + 512, epi = S / (nv * 4 + 2);  // floats per record, records per item
 #pragma unroll
       for (int T = 0; T < NT; ++T) {
         const bool tile_on = active && T < ntile;
@@ -1558,11 +1559,18 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
           for (int k = 0; k < DIM; ++k) dxacc[d][k] = 0.f;
         }
         const int cbase = col[T] - nodei[T];
+        // the edge sweep of one tile, specialised per layer kind (0 first, 1 middle, 2 last): record size, records per
+        // item and the tangent arithmetic are compile-time in each copy
+        auto run_edges = [&](auto kind_tag) {
+        constexpr int KIND = decltype(kind_tag)::value;
+        constexpr bool first = KIND == 0, last = KIND == 2;
+        constexpr int nv = (KIND == 1) ? 4 : 1, erec = nv * 1024 + 512, epi = S / (nv * 4 + 2);
         for (int dd0 = 1; dd0 < N; dd0 += epi) {
           begin_item();  // the barrier also orders this layer's posc / pos0 / dPB writes before their first use
-          for (int e = 0; e < epi && tile_on; ++e) {
+#pragma unroll
+          for (int e = 0; e < epi; ++e) {
             const int dd = dd0 + e;
-            if (dd >= N) break;
+            if (!tile_on || dd >= N) break;
             const float* rec = item + e * erec;
             int j = nodei[T] + dd;
             j = (j >= N) ? j - N : j;
@@ -1597,7 +1605,7 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
               dea[d] *= 2.0f;
             }
             float dcs[K];
-            if (first) {
+            if constexpr (first) {
               const f32x16 dmu = slot_vec16(rec, 0, lane);
               const float vcdmu = sc[256 + lane];
 #pragma unroll
@@ -1607,7 +1615,7 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
                 for (int r = 0; r < 16; ++r) dagg[d][r] = fmaf(dmu[r], w_, dagg[d][r]);
                 dcs[d] = dcs_f * (dradial[d] * vcdmu);
               }
-            } else if (last) {
+            } else if constexpr (last) {
               const f32x16 qv = slot_vec16(rec, 0, lane);
               const float qr = sc[256 + lane], qe = sc[320 + lane];
 #pragma unroll
@@ -1678,6 +1686,10 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
           }
           end_item();
         }
+        };
+        if (first) run_edges(std::integral_constant<int, 0>{});
+        else if (last) run_edges(std::integral_constant<int, 2>{});
+        else run_edges(std::integral_constant<int, 1>{});
         if (tile_on) {
 #pragma unroll
           for (int k = 0; k < DIM; ++k)
