@@ -48,19 +48,18 @@ __device__ __forceinline__ float fast_silu(float v) { return v * fast_sigmoid(v)
 // tanh with small-argument series: the coordinate head of a fresh EGNN outputs ~1e-4, where
 // 1 - 2/(1+e^{2v}) would lose all relative accuracy.
 __device__ __forceinline__ float accurate_tanh(float v) {
-  float a = fabsf(v);
-  if (a < 0.25f) {
-    float v2 = v * v;
-    float p = 62.0f / 2835.0f;
-    p = fmaf(p, v2, -17.0f / 315.0f);
-    p = fmaf(p, v2, 2.0f / 15.0f);
-    p = fmaf(p, v2, -1.0f / 3.0f);
-    p = fmaf(p, v2, 1.0f);
-    return v * p;
-  }
-  float e = __builtin_amdgcn_exp2f(2.88539008177792681f * a);  // e^{2a}
-  float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
-  return copysignf(t, v);
+  // both branches are evaluated and one is selected: the lanes of a wave nearly always need both anyway, and without
+  // the divergent branch the callers' loops stay one basic block (same values as the branching form)
+  const float a = fabsf(v);
+  const float v2 = v * v;
+  float p = 62.0f / 2835.0f;
+  p = fmaf(p, v2, -17.0f / 315.0f);
+  p = fmaf(p, v2, 2.0f / 15.0f);
+  p = fmaf(p, v2, -1.0f / 3.0f);
+  p = fmaf(p, v2, 1.0f);
+  const float e = __builtin_amdgcn_exp2f(2.88539008177792681f * a);  // e^{2a}
+  const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+  return a < 0.25f ? v * p : copysignf(t, v);
 }
 
 // ---- Philox4x32-10 counter RNG + Box-Muller (the generator used when the caller passes no noise)
