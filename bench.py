@@ -522,7 +522,10 @@ def main():
                 "note": "achieved/frac count the 16-bit matrix-pipe flops the kernel EXECUTES (fp32-accurate split "
                         "products included) against the dense 16-bit MFMA peak; achieved_algorithmic counts the "
                         "reference's fp32 formulation (SURVEY 8(d)) and has no frac.  The kernel is VALU-issue-bound "
-                        "(activations + operand splits): valu_issue_frac, DESIGN.md section 4.1"}
+                        "(activations + operand splits): valu_issue_frac, DESIGN.md section 4.1.  traffic (PMC) = the "
+                        "walkers in and out once per launch (algorithmic_bytes_per_launch) + register-spill scratch "
+                        "that every wave writes once per walker group outside the edge loop (~140 B/lane): no walker "
+                        "data is re-read"}
         assert 0.0 < roof["frac"] <= 1.0 and pipe_busy <= 1.0, "roofline fraction must be a fraction"
         out = {
             "metric": "walker-steps/sec (batch x T) LJ13 @ 65k walkers/GPU" if args.config == "lj13"
