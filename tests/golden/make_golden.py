@@ -110,7 +110,35 @@ def gen_lj():
         lp, f = e(x.clone(), return_force=True)
         out["logp_ef0.5"] = lp.numpy()
         out["force_ef0.5"] = f.numpy()
+        if n == 13:
+            # the reference's OWN in-tree LJ13 log-density (sampling/sample_lj13.py:15-30: torch.pdist, no eps, "2 x"
+            # unordered pairs + oscillator), executed as shipped -- no bgflow restatement involved.  fp32 and fp64.
+            e2 = _load_sample_lj13().energy2
+            for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+                xe = x.clone().to(dt).requires_grad_(True)
+                lp2 = e2(xe)
+                (f2,) = torch.autograd.grad(lp2.sum(), xe)
+                out[f"energy2_logp_{tag}"] = lp2.detach().numpy()
+                out[f"energy2_force_{tag}"] = f2.numpy()
         save(f"lj{n}_logp_force.npz", **out)
+
+
+def _load_sample_lj13():
+    """Import /root/reference/sampling/sample_lj13.py as shipped (module level only defines functions; the MCMC driver
+    sits under ``__main__``).  Its import-time dependency pyro is absent here: placeholder modules, no arithmetic."""
+    import importlib.util
+
+    _ref_shims._mod("pyro", sample=_ref_shims._Anything(), factor=_ref_shims._Anything())
+    _ref_shims._mod("pyro.distributions", Uniform=_ref_shims._Anything)
+    _ref_shims._mod("pyro.infer", MCMC=_ref_shims._Anything, NUTS=_ref_shims._Anything)
+    _ref_shims._mod("pyro.infer.mcmc")
+    _ref_shims._mod("pyro.infer.mcmc.rwkernel", RandomWalkKernel=object)
+    _ref_shims._mod("pyro.ops")
+    _ref_shims._mod("pyro.ops.integrator", potential_grad=_ref_shims._Anything())
+    spec = importlib.util.spec_from_file_location("ref_sample_lj13", _ref_shims.REF_ROOT + "/sampling/sample_lj13.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
 
 
 def gen_lj_smooth():
@@ -404,6 +432,59 @@ def gen_traj_nodebias():
          sigma_min=0.05)
 
 
+def pcg_noise(seed, N, B, D):
+    """The fixed noise of the long-trajectory fixtures: numpy's PCG64 stream, float32 ziggurat normals.  Stored as
+    the SEED only; tests regenerate the identical array."""
+    return np.random.Generator(np.random.PCG64(seed)).standard_normal((N, B, D), dtype=np.float32)
+
+
+def gen_traj_1000():
+    """The metric's own trajectory length: LJ13, N = 1000 (experiment/lj13.yaml), B = 16, not debiased, one inference
+    chunk, trained-like weights, fixed PCG64 noise.  Records the walkers entering steps 0, 100, ..., 900 (the x the
+    reference hands to VEReverseSDE.f, sde_integration.py:326-334), the final x, and drift norms at those steps."""
+    wt = dict(np.load(os.path.join(HERE, "egnn_weights_trainedlike.npz")))
+    sde, sched = build_lj13_stack(wt, debias=False)
+    N, B, seed = 1000, 16, 20261003
+    gamma = annealing_factor_schedules.ConstantAnnealingFactorSchedule(4 / 3)
+    integ = sde_integration.WeightedSDEIntegrator(
+        sde=sde, num_integration_steps=N, start_resampling_step=0, end_resampling_step=N, lightning_module=FakeLM(),
+        partial_annealing_factor_schedule=None, resampling_interval=-1, num_negative_time_steps=0, post_mcmc_steps=0,
+        batch_size=None, should_mean_free=True)
+    e = LJ(39, 13, 3, data_path="", temperature=1.0)
+    noise = pcg_noise(seed, N, B, 39)
+    scale = float((sched.h(torch.tensor(1.0)) / gamma.gamma(torch.tensor(1.0))) ** 0.5)
+    x1 = torch.from_numpy(pcg_noise(seed + 1, 1, B, 39)[0]) * scale
+    x1 = data_utils.remove_mean(x1, 13, 3)
+    calls = {"k": 0}
+    xs = []
+    real_f = sde.f
+
+    def rec_f(t, x, *a, **k):
+        if calls["k"] % 100 == 0:
+            xs.append(x.detach().clone().numpy())
+        calls["k"] += 1
+        return real_f(t, x, *a, **k)
+
+    sde.f = rec_f
+    draws = {"k": 0}
+    real_rn = torch.randn_like
+
+    def fixed_randn_like(x, *a, **k):
+        v = torch.from_numpy(noise[draws["k"]]).reshape(x.shape)
+        draws["k"] += 1
+        return v
+
+    torch.randn_like = fixed_randn_like
+    try:
+        x, logw, uniq, terms, acc = integ.integrate_sde(x1.clone(), e, gamma, inverse_temperature=1.0)
+    finally:
+        torch.randn_like = real_rn
+    assert calls["k"] == N and draws["k"] == N
+    drift = np.stack([terms[k].drift_X.reshape(B, 39).numpy() for k in range(0, N, 100)] + [terms[N - 1].drift_X.reshape(B, 39).numpy()])
+    save("em_traj_lj13_1000.npz", seed=seed, N=N, B=B, x1=x1.numpy(), x_at=np.stack(xs), at=np.arange(0, N, 100),
+         x_final=x.detach().numpy(), drift_at=drift, prior_scale=scale, gamma=4 / 3, beta=1.0, sigma_min=0.05)
+
+
 def gen_traj_debias():
     wt = dict(np.load(os.path.join(HERE, "egnn_weights_trainedlike.npz")))
     sde, sched = build_lj13_stack(wt, debias=True)
@@ -572,7 +653,7 @@ def gen_traj_gmm():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "lj", "lj_smooth", "gmm", "egnn", "mlp", "prior", "resample", "traj_nodebias",
+    which = sys.argv[1:] or ["schedules", "lj", "lj_smooth", "gmm", "egnn", "mlp", "prior", "resample", "traj_nodebias", "traj_1000",
                              "traj_debias", "traj_debias_end", "debias_variants", "post", "traj_gmm"]
     for w in which:
         globals()["gen_" + w]()

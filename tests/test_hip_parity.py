@@ -61,6 +61,25 @@ def test_lj_golden(pa, golden, n):
     assert rel(f[:nphys], g["force_ef0.5"][:nphys]) < 1e-5
 
 
+def test_lj13_against_reference_held_energy2(pa, golden):
+    """A12 against reference-held code only: ``energy2`` of sampling/sample_lj13.py:24-30 executed as shipped in
+    make_golden.py (torch.pdist, no distance eps; force by autograd).  The HIP kernel with the bgflow eps of 1e-6 is
+    within 2e-4 of it (the eps term); with dist_eps = 0 it is the same function: rel 1e-5 like the other goldens."""
+    g = golden("lj13_logp_force.npz")
+    nphys = int(g["n_cold"]) + int(g["n_warm"])
+    x = cu(g["x"])
+    lp, f = pa.LennardJonesEnergy(39, 13, 3)(x, return_force=True)
+    np.testing.assert_allclose(lp.cpu().numpy(), g["energy2_logp_f32"], rtol=2e-4)
+    assert rel(f[:nphys], g["energy2_force_f32"][:nphys]) < 2e-4
+    e0 = pa.LennardJonesEnergy(39, 13, 3)
+    e0.dist_eps = 0.0
+    lp0, f0 = e0(x, return_force=True)
+    np.testing.assert_allclose(lp0.cpu().numpy()[:nphys], g["energy2_logp_f64"][:nphys], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(lp0.cpu().numpy()[nphys:], g["energy2_logp_f64"][nphys:], rtol=2e-5)
+    assert rel(f0[:nphys], g["energy2_force_f64"][:nphys]) < 1e-5
+    assert rel(f0[nphys:], g["energy2_force_f64"][nphys:]) < 1e-4
+
+
 def test_lj_smooth_core_golden(pa, golden):
     """LennardJonesEnergy(smooth=True): cubic core below r = 0.65, against the reference's log-density and autograd force
     (walkers with and without pairs inside the core), for LJ13 and, against the oracle, LJ55 / ragged batches."""
@@ -375,6 +394,54 @@ def test_traj_golden_fused_and_stepwise(pa, golden):
     drift = torch.empty_like(x)
     net.sampler_run(x, tab[:1].cuda().contiguous(), 1, noise=noise[:1].contiguous(), drift_out=drift)
     assert rel(drift, g["drift_X"][0]) < 1e-4
+
+
+def pcg_noise(seed, N, B, D):
+    return np.random.Generator(np.random.PCG64(seed)).standard_normal((N, B, D), dtype=np.float32)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2"])
+def test_traj_1000_steps_golden(pa, golden, precision):
+    """Parity at the metric's own trajectory length: the reference's integrate_sde, LJ13, N = 1 000 (experiment/lj13.yaml),
+    fixed PCG64 noise, walkers recorded every 100 steps.  The fused HIP sampler fed the same noise must stay as close
+    to fp64 arithmetic as the fp32 reference does -- err(HIP, fp64 oracle) <= 4 x err(reference, fp64 oracle) -- at every
+    checkpoint, through the small-h end (h -> 2.5e-3) where score = (D - x)/h amplifies rounding 400x."""
+    g = golden("em_traj_lj13_1000.npz")
+    w = golden("egnn_weights_trainedlike.npz")
+    N, B = int(g["N"]), int(g["B"])
+    noise_h = pcg_noise(int(g["seed"]), N, B, 39)
+    at = [int(a) for a in g["at"]] + [N]
+    want = list(g["x_at"]) + [g["x_final"]]
+    # fp64 oracle on the same noise
+    wd = {k: T(v).double() for k, v in w.items()}
+    bb = lambda cn, xs, b: O.egnn_forward(wd, cn, xs, b, 13, 3)
+    osched, ogam = O.Elucidating(0.05, 80.0, 7), O.GammaConstant(4 / 3)
+    nz64 = T(noise_h).double()
+    out = O.integrate_sde(O.IntegratorConfig(num_integration_steps=N, end_resampling_step=N), T(g["x1"]).double(),
+                          lambda t, xc: O.f_not_debiased(bb, osched, ogam, t, xc, 1.0), osched.g, lambda i, shp: nz64[i],
+                          13, 3, record=True)
+    truth = [g["x1"].astype(np.float64)] + [out["traj"][a - 1].numpy() for a in at[1:]]
+    # HIP: ten launches of 100 steps (bitwise equal to one launch of 1 000, tested elsewhere), walkers read in between
+    net = make_net(pa, 13, 3, w, precision=precision).cuda()
+    sched, gam = pa.ElucidatingNoiseSchedule(sigma_min=0.05, sigma_max=80.0, rho=7), pa.ConstantAnnealingFactorSchedule(4 / 3)
+    tab = pa.sde_integration.build_step_table(sched, gam, torch.linspace(1.0, 0.0, N + 1)[:-1], 1.0 / N, 1.0, 1.0).cuda()
+    noise = cu(noise_h)
+    x = cu(g["x1"]).clone()
+    got = [x.cpu().numpy()]
+    for s0 in range(0, N, 100):
+        net.sampler_run(x, tab[s0:s0 + 100].contiguous(), 100, noise=noise[s0:s0 + 100].contiguous(), step0=s0,
+                        remove_mean=True, n_particles=13, n_dim=3)
+        got.append(x.cpu().numpy())
+    for k, a in enumerate(at):
+        e_ref, e_hip = rel(want[k], truth[k]), rel(got[k], truth[k])
+        print(f"[traj1000/{precision}] step {a:4d}: HIP vs fp64 {e_hip:.2e}, reference vs fp64 {e_ref:.2e}, HIP vs reference {rel(got[k], want[k]):.2e}")
+        assert e_hip <= 4 * e_ref + 1e-6, (a, e_hip, e_ref)
+    # the whole trajectory through the integrator front end in one launch gives the same walkers
+    sde = pa.VEReverseSDE(noise_schedule=sched, score_net=pa.ScoreNet(net), debias_inference=False)
+    integ = pa.WeightedSDEIntegrator(sde=sde, num_integration_steps=N, start_resampling_step=0, end_resampling_step=N,
+                                     resampling_interval=-1, num_negative_time_steps=0, post_mcmc_steps=0)
+    xi, *_ = integ.integrate_sde(cu(g["x1"]), pa.LennardJonesEnergy(39, 13, 3), gam, inverse_temperature=1.0, noise=noise)
+    assert torch.equal(xi, x)
 
 
 def test_sampler_sharding_invariance_and_determinism(pa, golden):
@@ -1382,13 +1449,15 @@ def test_forcefield_vs_oracle(pa, cutoff, gb):
     assert abs(f.reshape(B, 22, 3).sum(1)).max() < 1e-3 * f.abs().max().item()  # translation invariance
 
 
-def test_final_histograms_match_oracle_sampler(pa, golden):
+@pytest.mark.parametrize("N", [40, 1000])
+def test_final_histograms_match_oracle_sampler(pa, golden, N):
     """Distribution-level parity of the whole sampler with its OWN noise (Philox): the final interatomic-distance and
     energy histograms of the HIP run must be as close to an oracle run (torch noise, fp32 CPU) as two oracle runs with
-    different seeds are to each other (1-D Wasserstein-2; 4x margin).  LJ13, EGNN h32x3, 40 steps from the prior."""
+    different seeds are to each other (1-D Wasserstein-2; 4x margin).  LJ13, EGNN h32x3, from the prior, 40 steps and
+    the metric's own 1 000 steps (experiment/lj13.yaml; ~1 min of oracle time per seed)."""
     w = golden("egnn_weights_trainedlike.npz")
     wt = {k: T(v) for k, v in w.items()}
-    N, B = 40, 1024
+    B = 1024
     bb = lambda cn, xs, b: O.egnn_forward(wt, cn, xs, b, 13, 3)
     osched, ogam = O.Elucidating(0.05, 80.0, 7), O.GammaConstant(4 / 3)
     cfg = O.IntegratorConfig(num_integration_steps=N, start_resampling_step=0, end_resampling_step=N, resampling_interval=-1)

@@ -84,6 +84,25 @@ def test_lj_energy2_second_oracle(golden):
     np.testing.assert_allclose(e2, g["logp_T1.0"][:nphys], rtol=2e-4, atol=1e-3)
 
 
+def test_lj_against_reference_held_energy2(golden):
+    """A12 pinned by reference-held code alone: the values below were produced by EXECUTING the reference's own
+    sampling/sample_lj13.py:energy2 (torch.pdist; autograd for the force) in make_golden.py -- no bgflow restatement
+    in the loop.  With the distance eps switched off the oracle's ordered-pair formula must equal it to fp64 rounding;
+    with the bgflow eps of 1e-6 (the production setting) within 2e-4, the size of the eps term."""
+    g = golden("lj13_logp_force.npz")
+    nphys = int(g["n_cold"]) + int(g["n_warm"])
+    x = T(g["x"]).double()
+    lp0, f0 = O.lj_logp_force(x, 13, 3, dist_eps=0.0)
+    np.testing.assert_allclose(lp0.numpy(), g["energy2_logp_f64"], rtol=1e-11)
+    assert rel(f0.numpy(), g["energy2_force_f64"]) < 1e-11
+    np.testing.assert_allclose(O.lj_energy2(x, 13).numpy(), g["energy2_logp_f64"], rtol=1e-11)
+    lp, f = O.lj_logp_force(T(g["x"]), 13, 3)  # fp32, eps = 1e-6: what the product computes
+    np.testing.assert_allclose(lp.numpy(), g["energy2_logp_f32"], rtol=2e-4)
+    assert rel(f[:nphys].numpy(), g["energy2_force_f32"][:nphys]) < 2e-4
+    # and the bgflow-shimmed reference class agrees with the reference-held function to the same bound
+    np.testing.assert_allclose(g["logp_T1.0"], g["energy2_logp_f32"], rtol=2e-4)
+
+
 def test_gmm(golden):
     g = golden("gmm40.npz")
     means, scale = O.gmm_params()
@@ -193,6 +212,43 @@ def test_traj_nodebias(golden):
         assert rel(out["drift_X"][k].numpy(), g["drift_X"][k]) < 2e-3, k
     assert rel(out["x"].numpy(), g["x_final"]) < 1e-4
     assert np.all(out["logweights"].numpy() == 0)
+
+
+def pcg_noise(seed, N, B, D):
+    return np.random.Generator(np.random.PCG64(seed)).standard_normal((N, B, D), dtype=np.float32)
+
+
+def test_traj_1000_steps(golden):
+    """The metric's own trajectory length (experiment/lj13.yaml: 1 000 steps): the reference's integrate_sde on fixed
+    PCG64 noise, walkers recorded every 100 steps.  The fp32 oracle must track the reference as closely as the
+    reference tracks the fp64 oracle (both carry fp32 rounding through the small-h end where score = (D - x)/h
+    amplifies it), at every checkpoint."""
+    g = golden("em_traj_lj13_1000.npz")
+    bb = _lj13_backbone(golden)
+    N, B = int(g["N"]), int(g["B"])
+    noise = pcg_noise(int(g["seed"]), N, B, 39)
+    np.testing.assert_array_equal(O.remove_mean(T(pcg_noise(int(g["seed"]) + 1, 1, B, 39)[0]) * float(g["prior_scale"]),
+                                                13, 3).numpy(), g["x1"])
+    at = list(g["at"]) + [N]
+    want = list(g["x_at"]) + [g["x_final"]]
+    runs = {}
+    for dt in (torch.float32, torch.float64):
+        w = {k: T(v).to(dt) for k, v in golden("egnn_weights_trainedlike.npz").items()}
+        bbd = lambda cn, xs, b: O.egnn_forward(w, cn, xs, b, 13, 3)
+        sched, gam = O.Elucidating(0.05, 80.0, 7), O.GammaConstant(4 / 3)
+        cfg = O.IntegratorConfig(num_integration_steps=N, end_resampling_step=N)
+        nz = T(noise).to(dt)
+        x1 = T(g["x1"]).to(dt)
+        out = O.integrate_sde(cfg, x1, lambda t, xc: O.f_not_debiased(bbd, sched, gam, t, xc, 1.0),
+                              sched.g, lambda i, shp: nz[i], 13, 3, record=True)
+        # traj[k] = walkers after step k = walkers entering step k + 1
+        runs[dt] = [x1.numpy()] + [out["traj"][a - 1].numpy() for a in at[1:]]
+    for k, (a, ref) in enumerate(zip(at, want)):
+        e_ref = rel(ref, runs[torch.float64][k])  # the reference's own fp32 error against fp64 arithmetic
+        e_o32 = rel(runs[torch.float32][k], runs[torch.float64][k])
+        print(f"[traj1000] step {a:4d}: reference fp32 vs fp64 oracle {e_ref:.2e}, fp32 oracle vs fp64 oracle {e_o32:.2e}")
+        assert e_o32 <= 4 * e_ref + 1e-6, (a, e_o32, e_ref)
+        assert rel(runs[torch.float32][k], ref) <= 8 * e_ref + 1e-6
 
 
 def test_traj_debias(golden):
