@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PITA_ABI_VERSION 2
+#define PITA_ABI_VERSION 3
 
 enum {
   PITA_OK = 0,
@@ -87,21 +87,31 @@ int pita_dw_descent(float* x, const float* noise, int64_t B, int n_particles, in
                     float b, float c, float d0, int nsteps, float dt, float noise_scale, float sqrt_dt, uint64_t seed,
                     uint64_t walker_offset, int64_t step0, int remove_mean, void* stream);
 
-/* Fused MALA chain on the LJ13 target: all nsteps of metropolis_hastings_mala / _adaptive
- * (pita/src/models/components/sde_integration.py:28-45,362-470) in one launch, walkers resident in LDS; bit-identical to
- * pita_lj_logp_force + pita_mala_propose + pita_lj_logp_force + pita_mala_accept + pita_mala_adapt step after step.
- * x [B, 39] and logp [B] (log-density of x on entry) are updated in place; dt_dev holds the step size (adapted in place when
- * adaptive != 0, against the acceptance rate over `total` walkers -- this rank's B: with several ranks the global rate
- * needs the launch-per-kernel path); rates_out [nsteps] receives the acceptance rates.  noise [nsteps, B, 39] / uniforms
- * [nsteps, B] nullable -> Philox keyed (seed, walker key, step0 + s, particle / 0xFFFFF), walker key = walker_ids[w] or
- * walker_offset + w.  workspace: 8-byte aligned device scratch of pita_lj_mala_workspace_bytes(nsteps) bytes.  Returns PITA_EUNSUPPORTED
- * for other particle systems, and for an adaptive chain whose blocks cannot all be resident (its per-step grid barrier). */
+/* Fused MALA chain on a pair target: all nsteps of metropolis_hastings_mala / _adaptive
+ * (pita/src/models/components/sde_integration.py:28-45,362-470) in one launch, walkers resident on chip; bit-identical to
+ * pita_*_logp_force + pita_mala_propose + pita_*_logp_force + pita_mala_accept + pita_mala_adapt step after step.
+ * pita_lj_mala: LJ13 and LJ55; pita_dw_mala: DW4.  x [B, n*d] and logp [B] (log-density of x on entry) are updated in
+ * place; dt_dev holds the step size (adapted in place when adaptive != 0, against the acceptance rate over `total` walkers
+ * -- this rank's B: with several ranks the global rate needs the launch-per-kernel path); rates_out [nsteps] receives the
+ * acceptance rates.  noise [nsteps, B, n*d] / uniforms [nsteps, B] nullable -> Philox keyed (seed, walker key, step0 + s,
+ * particle / 0xFFFFF), walker key = walker_ids[w] or walker_offset + w.  workspace: 8-byte aligned device scratch of
+ * pita_lj_mala_workspace_bytes(nsteps) bytes.
+ * The adaptive chain synchronises the grid once per step (the global acceptance count decides the next step size); the
+ * grid is sized to the co-resident capacity of an idle device.  LJ55 / DW4 batches beyond it make one HBM round trip per
+ * step; the LJ13 kernel returns PITA_EUNSUPPORTED for them (launch-per-kernel path).  If the device was NOT idle and a
+ * block's bounded wait runs out, the chain is invalid: dt_dev[0] and every rates_out[s] are set to NaN (x / logp hold
+ * garbage) and the caller must rerun from its own copy of the walkers -- pita_amd.WeightedSDEIntegrator does. */
 size_t pita_lj_mala_workspace_bytes(int nsteps);
 int pita_lj_mala(float* x, float* logp, const float* noise /*nullable*/, const float* uniforms /*nullable*/, int64_t B,
                  int n_particles, int n_dim, float temperature, float energy_factor, float dist_eps, float eps, float rm,
                  float osc_scale, int nsteps, double* dt_dev, int adaptive, int64_t total, uint64_t seed,
                  uint64_t walker_offset, const int64_t* walker_ids /*nullable*/, int64_t step0, int remove_mean,
                  float* rates_out /*nullable*/, void* workspace, void* stream);
+int pita_dw_mala(float* x, float* logp, const float* noise /*nullable*/, const float* uniforms /*nullable*/, int64_t B,
+                 int n_particles, int n_dim, float temperature, float a, float b, float c, float d0, int nsteps,
+                 double* dt_dev, int adaptive, int64_t total, uint64_t seed, uint64_t walker_offset,
+                 const int64_t* walker_ids /*nullable*/, int64_t step0, int remove_mean, float* rates_out /*nullable*/,
+                 void* workspace, void* stream);
 
 /* Diagonal Gaussian mixture with equal weights.
  * replaces GMM.__call__ (pita/src/energies/gmm_energy.py:87-90) ->

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpita_hip.so")
 
 STEP_STRIDE = 16
-ABI_VERSION = 2
+ABI_VERSION = 3
 ST_CS, ST_CIN, ST_COUT, ST_CNOISE, ST_H, ST_G2, ST_GAMMA, ST_DT, ST_NOISE_SCALE, ST_SQRT_DT, ST_BETA = range(11)
 
 
@@ -61,6 +61,9 @@ _PROTOS = {
                                 c_float, c_uint64, c_uint64, c_int64, c_int, c_void_p]),
     "pita_lj_mala_workspace_bytes": (c_size_t, [c_int]),
     "pita_lj_mala": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int] + [c_float] * 6 +
+                     [c_int, c_void_p, c_int, c_int64, c_uint64, c_uint64, c_void_p, c_int64, c_int, c_void_p, c_void_p,
+                      c_void_p]),
+    "pita_dw_mala": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int] + [c_float] * 5 +
                      [c_int, c_void_p, c_int, c_int64, c_uint64, c_uint64, c_void_p, c_int64, c_int, c_void_p, c_void_p,
                       c_void_p]),
     "pita_gmm_logp_force": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_float,

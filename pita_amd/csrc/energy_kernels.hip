@@ -12,19 +12,11 @@
 // from LDS (broadcast-friendly: the n lanes of a walker read the same address).  Forces are
 // written back through LDS so the global store is again one coalesced span.  Pair energies are
 // HBM-bound for LJ13/DW4 (316 / 68 algorithmic bytes per walker-eval).
-#include "common.h"
+#include <cstdlib>
+
+#include "pair_common.h"
 
 namespace pita {
-
-enum { E_LJ = 0, E_DW = 1, E_LJS = 2 };  // E_LJS: LJ with the reference's cubic core below range_min (smooth=True)
-template <int KIND> constexpr bool is_lj() { return KIND == E_LJ || KIND == E_LJS; }
-
-struct PairParams {
-  float inv_T, energy_factor, dist_eps, eps, rm2, osc_scale;  // LJ
-  float cw, co;  // LJ13 fast path: -inv_T * 24 ef eps / rm^2 (pair force weight), -inv_T * osc_scale
-  float a, b, c, d0;                                          // DW
-  float sm_min, sc0, sc1, sc2, sc3;  // E_LJS: below r = sm_min the pair energy is sc0 u^3 + sc1 u^2 + sc2 u + sc3, u = r - sm_min
-};
 
 // pair energy and e'(r)/r of the smooth-core LJ (lennardjones_energy.py:39-54,131-133): the reference evaluates
 // `lj * ~filter + filter * spline(r)`, the spline clamped to its first interval for r < range_min -- one cubic in
@@ -430,12 +422,6 @@ __global__ void __launch_bounds__(256, 4) lj13_kernel(const float* __restrict__ 
 // in LDS for all S steps: HBM sees one read and one write of x per launch instead of per step, and the
 // per-step force array never exists.  Arithmetic and summation orders are those of pita_*_logp_force
 // followed by pita_em_step, so the fused and the per-step paths agree bit for bit.
-struct DescentParams {
-  float dt, noise_scale, sqrt_dt;
-  int nsteps, remove_mean;
-  unsigned long long seed, walker_offset;
-  long long step0;
-};
 
 template <int DIM, int KIND>
 __global__ void __launch_bounds__(256) pair_descent_kernel(float* __restrict__ x, const float* __restrict__ noise,
@@ -660,17 +646,6 @@ __global__ void __launch_bounds__(256, 2) lj13_descent_kernel(float* __restrict_
 // (all blocks co-resident: checked by the launch wrapper).  Only the counter itself crosses blocks, so the barrier is ONE
 // relaxed agent-scope atomic add of (1 << 32 | accepted) per block and a relaxed polling load -- no release / acquire
 // fences, which at agent scope write back and invalidate the XCD's L2 (measured: ~80 us per step with them); bounded spin.
-struct MalaParams {
-  const float* noise;      // nullable [nsteps, B, 39]
-  const float* uniforms;   // nullable [nsteps, B]
-  const long long* walker_ids;
-  unsigned long long seed, walker_offset;
-  long long step0, total;
-  double dt0;              // unused (dt is read from dt_dev)
-  const double* dt_dev;
-  int nsteps, adaptive, remove_mean;
-  unsigned long long* sync;  // [nsteps + 1]: per step (blocks arrived << 32 | walkers accepted), error flag; zeroed by the wrapper
-};
 
 template <bool UNIT_RM>
 __global__ void __launch_bounds__(256, 2) lj13_mala_kernel(float* __restrict__ x, float* __restrict__ logp, long long B,
@@ -808,8 +783,8 @@ __global__ void __launch_bounds__(256, 2) lj13_mala_kernel(float* __restrict__ x
           unsigned long long v = 0;
           int spins = 0;
           while (((v = __hip_atomic_load(&q.sync[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) < gridDim.x) {
+            if (++spins > q.spin_limit) { q.sync[q.nsteps] = 1; break; }  // never hang the device
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1 << 22)) { q.sync[q.nsteps] = 1; break; }  // never hang the device
           }
           total_acc = (int)(v & 0xFFFFFFFFull);
         }
@@ -831,16 +806,35 @@ __global__ void __launch_bounds__(256, 2) lj13_mala_kernel(float* __restrict__ x
   }
 }
 
-// acceptance rates of all steps and the final step size from the per-step counts (same arithmetic as mala_adapt_kernel)
+// acceptance rates of all steps and the final step size from the per-step counts (same arithmetic as mala_adapt_kernel).
+// A chain that raised its error flag (a grid-barrier spin ran out: the blocks were not all co-resident after all, e.g.
+// because another stream or process held compute units) adapted dt from different counts in different blocks: its
+// walkers are not a valid chain.  dt and every rate are then NaN, which no caller can mistake for a result
+// (WeightedSDEIntegrator._mala restores its backup and reruns the launch-per-kernel chain).
 __global__ void mala_finish_kernel(double* dt_dev, const unsigned long long* sync, int nsteps, long long total, int adaptive,
                                    float* rates_out) {
+  const bool failed = sync[nsteps] != 0;
   double dt = dt_dev[0];
   for (int s = 0; s < nsteps; ++s) {
     const float rate = (float)(int)(sync[s] & 0xFFFFFFFFull) / (float)total;
-    if (rates_out) rates_out[s] = rate;
+    if (rates_out) rates_out[s] = failed ? __builtin_nanf("") : rate;
     if (adaptive) dt = ((double)rate > 0.55) ? dt * 1.1 : dt / 1.1;
   }
-  dt_dev[0] = dt;
+  dt_dev[0] = failed ? __builtin_nan("") : dt;
+}
+
+int mala_spin_limit() {
+  const char* e = getenv("PITA_DEBUG_MALA_SPIN_LIMIT");
+  if (e && *e) return atoi(e);
+  return 1 << 22;
+}
+
+int launch_mala_finish(double* dt_dev, const unsigned long long* sync, int nsteps, long long total, int adaptive,
+                       float* rates_out, void* stream) {
+  hipLaunchKernelGGL(mala_finish_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dt_dev, sync, nsteps, total, adaptive,
+                     rates_out);
+  PITA_LAUNCH_CHECK();
+  return PITA_OK;
 }
 
 template <int KIND>
@@ -859,6 +853,10 @@ static int launch_descent(float* x, const float* noise, int64_t B, int n, int d,
     else hipLaunchKernelGGL(lj13_descent_kernel<false>, dim3(grid), dim3(256), 0, s, x, noise, (long long)B, p, q);
     PITA_LAUNCH_CHECK();
     return PITA_OK;
+  }
+  {  // compile-time particle counts (LJ55, DW4): ring_kernels.hip
+    const int rc = ring_launch_descent(KIND, x, noise, B, n, d, p, q, stream);
+    if (rc != 1) return rc;
   }
   if (n <= 64) {
     const int WB = 4 * (64 / n);
@@ -896,6 +894,10 @@ static int launch_pair(const float* x, float* logp, float* force, int64_t B, int
   PITA_REQUIRE(d >= 1 && d <= 3, "pair energy: n_dim must be 1, 2 or 3");
   if (B == 0) return PITA_OK;
   hipStream_t s = (hipStream_t)stream;
+  {  // compile-time particle counts (LJ55, DW4): ring_kernels.hip
+    const int rc = ring_launch_energy(KIND, x, logp, force, B, n, d, p, stream);
+    if (rc != 1) return rc;
+  }
   if (n <= 64) {  // whole walkers per wavefront: unordered pairs with Newton's third law
     const int WB = 4 * (64 / n);
     const long long nblk = (B + WB - 1) / WB;
@@ -1080,6 +1082,20 @@ extern "C" int pita_dw_descent(float* x, const float* noise, int64_t B, int n, i
 
 extern "C" size_t pita_lj_mala_workspace_bytes(int nsteps) { return 8 * (size_t)((nsteps > 0 ? nsteps : 0) + 1); }
 
+// shared tail of the fused-chain entry points: zero the per-step counters, run the chain, derive rates and final dt
+template <class Chain>
+static int run_mala_chain(int nsteps, double* dt_dev, int adaptive, int64_t total, float* rates_out, void* workspace,
+                          MalaParams& q, void* stream, Chain&& chain) {
+  PITA_REQUIRE(((uintptr_t)workspace & 7) == 0, "fused MALA: workspace must be 8-byte aligned");
+  unsigned long long* sync = static_cast<unsigned long long*>(workspace);
+  PITA_HIP_CHECK(hipMemsetAsync(sync, 0, pita_lj_mala_workspace_bytes(nsteps), (hipStream_t)stream));
+  q.sync = sync;
+  q.spin_limit = mala_spin_limit();
+  const int rc = chain();
+  if (rc != PITA_OK) return rc;
+  return launch_mala_finish(dt_dev, sync, nsteps, (long long)total, adaptive, rates_out, stream);
+}
+
 extern "C" int pita_lj_mala(float* x, float* logp, const float* noise, const float* uniforms, int64_t B, int n, int d,
                             float temperature, float energy_factor, float dist_eps, float eps, float rm, float osc_scale,
                             int nsteps, double* dt_dev, int adaptive, int64_t total, uint64_t seed,
@@ -1087,7 +1103,8 @@ extern "C" int pita_lj_mala(float* x, float* logp, const float* noise, const flo
                             float* rates_out, void* workspace, void* stream) {
   PITA_REQUIRE(temperature > 0.f, "pita_lj_mala: temperature must be > 0");
   PITA_REQUIRE(B >= 0 && nsteps >= 0 && total > 0, "pita_lj_mala: bad argument");
-  if (n != 13 || d != 3) return fail(PITA_EUNSUPPORTED, "pita_lj_mala: only the LJ13 kernel is fused (n = %d, d = %d)", n, d);
+  if (!((n == 13 || n == 55) && d == 3))
+    return fail(PITA_EUNSUPPORTED, "pita_lj_mala: fused chains exist for LJ13 and LJ55 (n = %d, d = %d)", n, d);
   if (nsteps == 0) return PITA_OK;
   PITA_REQUIRE(dt_dev && workspace && (B == 0 || (x && logp)), "pita_lj_mala: null argument");
   PairParams p{};
@@ -1095,34 +1112,61 @@ extern "C" int pita_lj_mala(float* x, float* logp, const float* noise, const flo
   p.rm2 = rm * rm; p.osc_scale = osc_scale;
   p.cw = -p.inv_T * (2.0f * energy_factor * eps * 12.0f / p.rm2); p.co = -p.inv_T * osc_scale;
   hipStream_t s = (hipStream_t)stream;
-  PITA_REQUIRE(((uintptr_t)workspace & 7) == 0, "pita_lj_mala: workspace must be 8-byte aligned");
-  unsigned long long* sync = static_cast<unsigned long long*>(workspace);
-  PITA_HIP_CHECK(hipMemsetAsync(sync, 0, pita_lj_mala_workspace_bytes(nsteps), s));
+  MalaParams q{};
+  q.noise = noise; q.uniforms = uniforms; q.walker_ids = (const long long*)walker_ids; q.seed = seed;
+  q.walker_offset = walker_offset; q.step0 = step0; q.total = total; q.dt_dev = dt_dev; q.nsteps = nsteps;
+  q.adaptive = adaptive; q.remove_mean = remove_mean;
+  if (n == 55) {
+    return run_mala_chain(nsteps, dt_dev, adaptive, total, rates_out, workspace, q, stream, [&]() {
+      if (B == 0) return (int)PITA_OK;
+      const int rc = ring_launch_mala(E_LJ, x, logp, B, n, d, p, q, stream);
+      return rc == 1 ? fail(PITA_EUNSUPPORTED, "pita_lj_mala: no ring kernel for n = %d", n) : rc;
+    });
+  }
   const long long nblk = (B + 127) / 128;
   const bool unit = p.rm2 == 1.0f;
-  if (nblk > 0) {
-    static int capacity = 0;  // co-resident blocks of the chain kernel on this device
-    if (capacity == 0) {
-      int per_cu = 0, dev = 0;
-      hipDeviceProp_t prop;
-      PITA_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lj13_mala_kernel<true>, 256, 0));
-      PITA_HIP_CHECK(hipGetDevice(&dev));
-      PITA_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-      capacity = per_cu * prop.multiProcessorCount;
-    }
-    if (adaptive && nblk > capacity)
-      return fail(PITA_EUNSUPPORTED, "pita_lj_mala: the adaptive chain needs all %lld blocks resident (capacity %d)", nblk,
-                  capacity);
-    MalaParams q{};
-    q.noise = noise; q.uniforms = uniforms; q.walker_ids = (const long long*)walker_ids; q.seed = seed;
-    q.walker_offset = walker_offset; q.step0 = step0; q.total = total; q.dt_dev = dt_dev; q.nsteps = nsteps;
-    q.adaptive = adaptive; q.remove_mean = remove_mean; q.sync = sync;
+  static int capacity = 0;  // co-resident blocks of the chain kernel on this device
+  if (capacity == 0) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    PITA_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lj13_mala_kernel<true>, 256, 0));
+    PITA_HIP_CHECK(hipGetDevice(&dev));
+    PITA_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    capacity = per_cu * prop.multiProcessorCount;
+  }
+  if (adaptive && nblk > capacity)
+    return fail(PITA_EUNSUPPORTED, "pita_lj_mala: the adaptive chain needs all %lld blocks resident (capacity %d)", nblk,
+                capacity);
+  return run_mala_chain(nsteps, dt_dev, adaptive, total, rates_out, workspace, q, stream, [&]() {
+    if (nblk == 0) return (int)PITA_OK;
     const unsigned grid = (unsigned)(nblk < capacity ? nblk : capacity);
     if (unit) hipLaunchKernelGGL(lj13_mala_kernel<true>, dim3(grid), dim3(256), 0, s, x, logp, (long long)B, p, q);
     else hipLaunchKernelGGL(lj13_mala_kernel<false>, dim3(grid), dim3(256), 0, s, x, logp, (long long)B, p, q);
     PITA_LAUNCH_CHECK();
-  }
-  hipLaunchKernelGGL(mala_finish_kernel, dim3(1), dim3(1), 0, s, dt_dev, sync, nsteps, (long long)total, adaptive, rates_out);
-  PITA_LAUNCH_CHECK();
-  return PITA_OK;
+    return (int)PITA_OK;
+  });
+}
+
+extern "C" int pita_dw_mala(float* x, float* logp, const float* noise, const float* uniforms, int64_t B, int n, int d,
+                            float temperature, float a, float b, float c, float d0, int nsteps, double* dt_dev,
+                            int adaptive, int64_t total, uint64_t seed, uint64_t walker_offset,
+                            const int64_t* walker_ids, int64_t step0, int remove_mean, float* rates_out, void* workspace,
+                            void* stream) {
+  PITA_REQUIRE(temperature > 0.f, "pita_dw_mala: temperature must be > 0");
+  PITA_REQUIRE(B >= 0 && nsteps >= 0 && total > 0, "pita_dw_mala: bad argument");
+  if (!(n == 4 && d == 2))
+    return fail(PITA_EUNSUPPORTED, "pita_dw_mala: the fused chain exists for DW4 (n = %d, d = %d)", n, d);
+  if (nsteps == 0) return PITA_OK;
+  PITA_REQUIRE(dt_dev && workspace && (B == 0 || (x && logp)), "pita_dw_mala: null argument");
+  PairParams p{};
+  p.inv_T = 1.0f / temperature; p.a = a; p.b = b; p.c = c; p.d0 = d0;
+  MalaParams q{};
+  q.noise = noise; q.uniforms = uniforms; q.walker_ids = (const long long*)walker_ids; q.seed = seed;
+  q.walker_offset = walker_offset; q.step0 = step0; q.total = total; q.dt_dev = dt_dev; q.nsteps = nsteps;
+  q.adaptive = adaptive; q.remove_mean = remove_mean;
+  return run_mala_chain(nsteps, dt_dev, adaptive, total, rates_out, workspace, q, stream, [&]() {
+    if (B == 0) return (int)PITA_OK;
+    const int rc = ring_launch_mala(E_DW, x, logp, B, n, d, p, q, stream);
+    return rc == 1 ? fail(PITA_EUNSUPPORTED, "pita_dw_mala: no ring kernel for n = %d", n) : rc;
+  });
 }

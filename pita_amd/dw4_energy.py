@@ -47,3 +47,20 @@ class MultiDoubleWellEnergy(BaseMoleculeEnergy):
             self.a, self.b, self.c, self.offset, int(num_steps), float(dt), float(noise_scale), float(sqrt_dt), seed,
             walker_offset, step0, int(remove_mean), _lib.stream_ptr(x.device)), "pita_dw_descent")
         return x
+
+    def fused_mala(self, x, logp, num_steps, dt_dev, adaptive, total, noise=None, uniforms=None, seed=0, walker_offset=0,
+                   walker_ids=None, step0=0, remove_mean=True, rates_out=None):
+        """See LennardJonesEnergy.fused_mala (pita_dw_mala: the DW4 ring kernel)."""
+        if self.should_normalize or self.n_particles != 4 or self.n_spatial_dim != 2:
+            return None
+        L = _lib.lib()
+        ws = torch.empty((int(L.pita_lj_mala_workspace_bytes(int(num_steps))) + 7) // 8, device=x.device, dtype=torch.int64)
+        rc = L.pita_dw_mala(x.data_ptr(), logp.data_ptr(), _lib.ptr(noise), _lib.ptr(uniforms), x.shape[0], 4, 2,
+                            float(self.temperature), self.a, self.b, self.c, self.offset, int(num_steps),
+                            dt_dev.data_ptr(), int(bool(adaptive)), int(total), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                            int(walker_offset), _lib.ptr(walker_ids), int(step0), int(bool(remove_mean)),
+                            _lib.ptr(rates_out), ws.data_ptr(), _lib.stream_ptr(x.device))
+        if rc == -2:  # PITA_EUNSUPPORTED
+            return None
+        _lib.check(rc, "pita_dw_mala")
+        return x

@@ -83,13 +83,14 @@ class LennardJonesEnergy(BaseMoleculeEnergy):
                    walker_ids=None, step0=0, remove_mean=True, rates_out=None):
         """All ``num_steps`` MALA steps in ONE launch, in place on ``x`` / ``logp`` / ``dt_dev`` (pita_lj_mala;
         metropolis_hastings_mala(_adaptive), sde_integration.py:362-470).  Returns None when the fused kernel does not
-        apply (other particle numbers, normalised coordinates, an adaptive chain too large to be co-resident): the
-        caller then runs the launch-per-kernel path, which gives the same bits."""
-        if self.should_normalize or self.smooth or self.n_particles != 13 or self.n_spatial_dim != 3:
+        apply (other particle numbers, normalised coordinates, an LJ13 adaptive chain too large to be co-resident): the
+        caller then runs the launch-per-kernel path, which gives the same bits.  LJ13 and LJ55 have fused chains."""
+        if self.should_normalize or self.smooth or self.n_particles not in (13, 55) or self.n_spatial_dim != 3:
             return None
         L = _lib.lib()
         ws = torch.empty((int(L.pita_lj_mala_workspace_bytes(int(num_steps))) + 7) // 8, device=x.device, dtype=torch.int64)
-        rc = L.pita_lj_mala(x.data_ptr(), logp.data_ptr(), _lib.ptr(noise), _lib.ptr(uniforms), x.shape[0], 13, 3,
+        rc = L.pita_lj_mala(x.data_ptr(), logp.data_ptr(), _lib.ptr(noise), _lib.ptr(uniforms), x.shape[0],
+                            self.n_particles, 3,
                             float(self.temperature), self.energy_factor, self.dist_eps, 1.0, 1.0, 1.0, int(num_steps),
                             dt_dev.data_ptr(), int(bool(adaptive)), int(total), int(seed) & 0xFFFFFFFFFFFFFFFF,
                             int(walker_offset), _lib.ptr(walker_ids), int(step0), int(bool(remove_mean)),

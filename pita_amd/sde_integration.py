@@ -524,11 +524,22 @@ class WeightedSDEIntegrator:
                     uu = torch.stack([_lib.dev_tensor(uniforms[i], "uniforms").reshape(-1) for i in range(steps)]).contiguous()
                     if tuple(uu.shape) != (steps, Bv):
                         raise ValueError(f"MALA uniforms have shape {tuple(uu.shape)}, expected {(steps, Bv)}")
+                # an adaptive chain synchronises the grid every step and assumes an idle device; if a block's bounded wait
+                # runs out (another stream or process held compute units) the launch marks the chain invalid with NaN
+                # rates: restore the walkers and run the launch-per-kernel chain, which cannot fail this way
+                backup = (x_valid.clone(), logp.clone(), dt_dev.clone()) if adaptive else None
                 if energy_function.fused_mala(x_valid, logp, steps, dt_dev, adaptive, total, noise=nz, uniforms=uu, seed=key,
                                               walker_offset=walker_offset, walker_ids=ids, step0=0, remove_mean=rm,
                                               rates_out=rates) is not None:
-                    done = steps
-                    steps = 0
+                    if adaptive and bool(torch.isnan(rates[:steps]).any()):
+                        x_valid.copy_(backup[0])
+                        logp.copy_(backup[1])
+                        dt_dev.copy_(backup[2])
+                        rates.zero_()
+                        self._fused_mala_fallbacks = getattr(self, "_fused_mala_fallbacks", 0) + 1
+                    else:
+                        done = steps
+                        steps = 0
             for i in range(steps):
                 if Bv > 0:
                     _, grad = energy_function(x_valid, return_force=True)

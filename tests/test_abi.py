@@ -113,7 +113,7 @@ def test_header_is_plain_c_and_links_from_c(built, tmp_path):
 int main(void) {
   char msg[256];
   float dummy[8] = {0};
-  if (pita_abi_version() != 2) return 10;
+  if (pita_abi_version() != PITA_ABI_VERSION) return 10;
   /* negative batch: rejected before anything touches the device */
   int rc = pita_dw_logp_force(dummy, dummy, NULL, -1, 4, 2, 1.0f, 0.9f, -4.0f, 0.0f, 4.0f, NULL);
   if (rc != PITA_EINVAL) return 11;

@@ -649,6 +649,111 @@ def test_fused_mala_equals_per_step(pa, golden, B, steps, adaptive):
         assert integ._last_mala_valid == B - 1 and torch.isinf(outs[0][0][-1, 0]) and torch.isinf(outs[1][0][-1, 0])
 
 
+def _ring_target(pa, name, B, gen):
+    """LJ55 / DW4 target with B jittered near-equilibrium walkers (chains that accept and reject)."""
+    if name == "lj55":
+        e, n, d = pa.LennardJonesEnergy(165, 55, 3), 55, 3
+        r = 3
+        grid = np.stack(np.meshgrid(*[np.arange(-r, r + 1)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float64)
+        pts = grid[np.argsort((grid**2).sum(-1), kind="stable")[:55]] * 1.09
+        base = torch.tensor(pts, dtype=torch.float32).reshape(1, 165)
+        x0 = base + 0.03 * torch.randn(B, 165, generator=gen)
+    else:
+        e, n, d = pa.MultiDoubleWellEnergy(temperature=1.0), 4, 2
+        base = torch.tensor([[2.0, 2.0], [-2.0, 2.0], [-2.0, -2.0], [2.0, -2.0]]).reshape(1, 8)
+        x0 = base + 0.3 * torch.randn(B, 8, generator=gen)
+    return e, n, d, O.remove_mean(x0, n, d).cuda()
+
+
+@pytest.mark.parametrize("adaptive", [False, True])
+@pytest.mark.parametrize("name,B,steps,dt", [("lj55", 301, 5, 2e-4), ("lj55", 3, 4, 2e-4), ("lj55", 10007, 3, 2e-4),
+                                             ("dw4", 1000, 6, 0.05), ("dw4", 37, 4, 0.05), ("dw4", 65536, 3, 0.05),
+                                             ("dw4", 700001, 3, 0.05)])
+def test_fused_ring_mala_equals_per_step(pa, name, B, steps, dt, adaptive):
+    """pita_lj_mala (LJ55) / pita_dw_mala (DW4): the ring-kernel chains == the launch-per-kernel chain, bit for bit --
+    walkers, acceptance rates; Philox and injected noise / uniforms; with and without centring; ragged wave groups; a
+    batch beyond the co-resident capacity (LJ55 10 007 walkers = 10 007 wave groups > 8 192 resident waves; DW4 700 001
+    walkers), where the adaptive chain makes one HBM round trip per step and the non-adaptive one loops over groups."""
+    gen = torch.Generator().manual_seed(B + steps)
+    e, n, d, x0 = _ring_target(pa, name, B, gen)
+    D = n * d
+    for mean_free in (True, False):
+        for inject in (False, True):
+            if inject and B * D > 2_000_000:
+                continue
+            kw = {}
+            if inject:
+                kw = dict(noise=torch.randn(steps, B, D, generator=gen).cuda(), uniforms=torch.rand(steps, B, generator=gen).cuda())
+            outs = []
+            for fused in (True, False):
+                integ = pa.WeightedSDEIntegrator(sde=None, num_integration_steps=1, start_resampling_step=0,
+                                                 end_resampling_step=1, post_mcmc_steps=steps, dt_negative_time=dt,
+                                                 adaptive_mcmc=adaptive, should_mean_free=mean_free, seed=9)
+                if adaptive:
+                    outs.append(integ.metropolis_hastings_mala_adaptive(x0.clone(), e, dt_init=dt, return_acceptance_rate=True,
+                                                                        fused=fused, **kw))
+                else:
+                    outs.append(integ.metropolis_hastings_mala(x0.clone(), e, return_acceptance_rate=True, fused=fused, **kw))
+            assert torch.equal(outs[0][0], outs[1][0]), (mean_free, inject)
+            assert outs[0][1] == outs[1][1] and len(outs[0][1]) == steps
+            assert torch.isfinite(outs[0][0]).all()
+            if B >= 100:
+                assert 0.0 < max(outs[0][1]) and min(outs[0][1]) < 1.0, outs[0][1]  # a chain that accepts and rejects
+    # the chain follows the oracle's MALA step (fp32 rounding may flip an accept decision whose log-ratio is within 1e-5)
+    if B <= 1000:
+        steps_o = 2
+        noise = torch.randn(steps_o, B, D, generator=gen)
+        us = torch.rand(steps_o, B, generator=gen)
+        integ = pa.WeightedSDEIntegrator(sde=None, num_integration_steps=1, start_resampling_step=0, end_resampling_step=1,
+                                         post_mcmc_steps=steps_o, dt_negative_time=dt, should_mean_free=True)
+        out, rates = integ.metropolis_hastings_mala(x0.clone(), e, return_acceptance_rate=True, noise=noise.cuda(),
+                                                    uniforms=us.cuda())
+        lf = (lambda xx: O.lj_logp_force(xx, 55, 3)) if name == "lj55" else (lambda xx: O.dw4_logp_force(xx))
+        xv = x0.cpu().double()
+        lp = lf(xv)[0]
+        for k in range(steps_o):
+            xv, lp, acc = O.mala_step(xv, lp, lf, dt, noise[k].double(), torch.log(us[k].double()))
+            xv = O.remove_mean(xv, n, d)
+        same = (out.cpu().double() - xv).abs().amax(dim=1) < 1e-4
+        assert same.float().mean() > 0.99, float(same.float().mean())
+
+
+@pytest.mark.parametrize("name", ["lj13", "lj55", "dw4"])
+def test_fused_adaptive_mala_barrier_timeout_falls_back(pa, golden, name, monkeypatch):
+    """The adaptive chain's per-step grid barrier assumes an idle device.  PITA_DEBUG_MALA_SPIN_LIMIT=0 makes every block
+    that is not the last to arrive give up at once: the launch must report the chain invalid (NaN rates and step size
+    through the C ABI) and WeightedSDEIntegrator must restore the walkers and produce the launch-per-kernel result."""
+    gen = torch.Generator().manual_seed(5)
+    steps = 4
+    if name == "lj13":
+        g = golden("post_lj13.npz")
+        e, n, d, dt = pa.LennardJonesEnergy(39, 13, 3), 13, 3, 3e-4
+        base = T(g["x0"])
+        x0 = O.remove_mean(base[torch.arange(2000) % base.shape[0]] + 0.02 * torch.randn(2000, 39, generator=gen), 13, 3).cuda()
+    else:
+        e, n, d, x0 = _ring_target(pa, name, 2000, gen)
+        dt = 2e-4 if name == "lj55" else 0.05
+    mk = lambda: pa.WeightedSDEIntegrator(sde=None, num_integration_steps=1, start_resampling_step=0, end_resampling_step=1,
+                                          post_mcmc_steps=steps, dt_negative_time=dt, adaptive_mcmc=True, seed=3)
+    want = mk().metropolis_hastings_mala_adaptive(x0.clone(), e, dt_init=dt, return_acceptance_rate=True, fused=False)
+    monkeypatch.setenv("PITA_DEBUG_MALA_SPIN_LIMIT", "0")
+    # through the C ABI: the invalid chain is reported, not returned as a result
+    lp = e(x0)
+    xc = x0.clone()
+    dt_dev = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    rates = torch.zeros(steps, device="cuda")
+    assert e.fused_mala(xc, lp, steps, dt_dev, True, x0.shape[0], seed=1, rates_out=rates) is not None
+    assert torch.isnan(rates).all() and torch.isnan(dt_dev).all()
+    integ = mk()
+    got = integ.metropolis_hastings_mala_adaptive(x0.clone(), e, dt_init=dt, return_acceptance_rate=True)
+    assert integ._fused_mala_fallbacks == 1
+    assert torch.equal(got[0], want[0]) and got[1] == want[1]
+    monkeypatch.delenv("PITA_DEBUG_MALA_SPIN_LIMIT")
+    integ = mk()
+    got = integ.metropolis_hastings_mala_adaptive(x0.clone(), e, dt_init=dt, return_acceptance_rate=True)
+    assert getattr(integ, "_fused_mala_fallbacks", 0) == 0 and torch.equal(got[0], want[0]) and got[1] == want[1]
+
+
 def test_mala_sets_non_finite_walkers_aside(pa, golden):
     """Quirk Q7 (sde_integration.py:366-369,400): walkers whose target log-density is not finite are taken out before
     the chain and re-appended AFTER the valid ones (order not preserved); the chain itself runs on the valid rows with
