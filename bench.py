@@ -505,28 +505,44 @@ def main():
         pm = pmc_summary()
         pk = pm.get(f"sampler_{args.config}") if pm else None
         same = pk is not None and pk.get("walkers") == B
+        alg_bytes = 2 * B * D * 4  # the walkers in and out once per launch (312 B per LJ13 walker)
+        alg_tflops = walker_steps_per_s * alg / 1e12
+        # HBM bytes per launch from the committed PMC passes: a fixed part per launch (the walkers in and out, the f16
+        # path's backup copy is a separate memcpy and not in the kernel's counters, per-walker-group register spills)
+        # + a part per walker-step, fitted from passes at two launch sizes; FETCH_SIZE corrected as the guide prescribes
+        traffic = None
+        if same and "fixed_bytes_per_launch" in pk:
+            traffic = pk["fixed_bytes_per_launch"] + pk["bytes_per_walker_step"] * B * chunk
+            assert traffic >= alg_bytes, "PMC traffic below the algorithmic bytes: the counter correction is wrong"
         roof = {"kernel": f"egnn_kernel<{n},{d},...,SAMPLER> (fused EGNN score + EDM + EM step; one launch = {chunk} steps)",
-                "bound": "mfma", "achieved": achieved, "peak": PEAK_MFMA16_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_MFMA16_TFLOPS,
-                "traffic": pk["traffic_bytes_per_walker_step"] * B * chunk if same else None,
+                "bound": "mfma",
+                # ALGORITHMIC flops per launch (4.197 MFLOP per LJ13 walker-step, counted on the reference's
+                # fp32 formulation) / average launch duration, against the dense 16-bit MFMA peak (the pipe used)
+                "achieved": alg_tflops, "peak": PEAK_MFMA16_TFLOPS, "unit": "TFLOP/s",
+                "frac": alg_tflops / PEAK_MFMA16_TFLOPS, "frac_algorithmic": alg_tflops / PEAK_MFMA16_TFLOPS,
+                "algorithmic_flop_per_walker_step": alg, "algorithmic_flop_per_launch": alg * B * chunk,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "traffic": traffic,
+                "traffic_model": {k: pk[k] for k in ("fixed_bytes_per_launch", "bytes_per_walker_step", "fit_from",
+                                                     "fetch_size_correction") if k in pk} if same else None,
+                "ms_per_launch": avg_ms, "launches": n_launch, "steps_per_launch": chunk,
+                # what the matrix pipe actually executes (fp32-accurate split products included): pipe utilisation
+                "achieved_executed": achieved, "frac_executed": achieved / PEAK_MFMA16_TFLOPS,
                 "executed_mfma_flop_per_walker_step": exec16,
                 "executed_f32_mfma_flop_per_walker_step": exec32,
                 "mfma16_per_walker_step": m16, "mfma32_per_walker_step": m32,
                 "mfma_pipe_busy_frac_at_2.4GHz": pipe_busy,
                 "valu_issue_frac": pk.get("valu_issue_frac") if same else None,
                 "pmc_source": pk.get("source") if same else None,
-                "achieved_algorithmic": walker_steps_per_s * alg / 1e12,
-                "algorithmic_flop_per_walker_step": alg, "algorithmic_bytes_per_launch": 2 * B * D * 4,
-                "ms_per_launch": avg_ms, "launches": n_launch,
                 "dense_layer_arithmetic": {0: "f32 MFMA", 1: "bf16 MFMA, 3-piece split", 2: "f16 MFMA, 2-piece split"}[net.precision],
-                "note": "achieved/frac count the 16-bit matrix-pipe flops the kernel EXECUTES (fp32-accurate split "
-                        "products included) against the dense 16-bit MFMA peak; achieved_algorithmic counts the "
-                        "reference's fp32 formulation (SURVEY 8(d)) and has no frac.  The kernel is VALU-issue-bound "
-                        "(activations + operand splits): valu_issue_frac, DESIGN.md section 4.1.  traffic (PMC) = the "
-                        "walkers in and out once per launch (algorithmic_bytes_per_launch) + register-spill scratch "
-                        "that every wave writes once per walker group outside the edge loop (~140 B/lane): no walker "
-                        "data is re-read"}
-        assert 0.0 < roof["frac"] <= 1.0 and pipe_busy <= 1.0, "roofline fraction must be a fraction"
+                "note": "achieved/frac follow SURVEY 8(d): algorithmic flops of the reference's formulation per launch / "
+                        "launch time (HIP events on the launch stream) against the dense 16-bit MFMA peak.  *_executed "
+                        "count the 16-bit matrix-pipe flops the kernel really issues (split products).  The kernel is "
+                        "VALU-issue-bound (activations + operand splits): valu_issue_frac, DESIGN.md section 4.1.  "
+                        "traffic = PMC bytes per launch (fixed part + per walker-step part, FETCH_SIZE x2 as the guide "
+                        "prescribes for gfx950): the walkers in and out once per launch + register-spill scratch; no "
+                        "walker data is re-read"}
+        assert 0.0 < roof["frac"] <= roof["frac_executed"] <= 1.0 and pipe_busy <= 1.0, "roofline fraction must be a fraction"
         out = {
             "metric": "walker-steps/sec (batch x T) LJ13 @ 65k walkers/GPU" if args.config == "lj13"
                       else f"walker-steps/sec (batch x T) {args.config} @ {B} walkers/GPU",
@@ -545,6 +561,7 @@ def main():
                                    f"init), not-debiased, resampling off, Elucidating({cfg['sigma_min']},80,7), gamma=4/3, "
                                    "beta=1",
                        "walkers_per_gpu": B, "global_walkers": world * B, "steps_per_launch": chunk,
+                       "final_allgather_bytes_per_rank": B * D * 4 if world > 1 else 0,
                        "parallelism": f"walker-sharded x{world}, final all_gather only",
                        "backend": ("gloo (one-device rehearsal)" if rehearsal else "nccl (RCCL)") if world > 1 else None},
             "roofline": roof,

@@ -2,12 +2,17 @@
 dominant kernel and per-launch HBM traffic for the target force kernel.
 
 usage: python tools/pmc_summarise.py <config> <walkers> <steps_per_launch> <out.json> <pass_dir> [<pass_dir> ...]
-Each pass_dir holds one rocprofv3 output tree (…_counter_collection.csv).  Counters used when present:
+                                     [--second <steps_per_launch_2> <pass_dir> ...]
+Each pass_dir holds one rocprofv3 output tree (…_counter_collection.csv).  With --second (FETCH_SIZE / WRITE_SIZE passes of
+the same command at another launch size) the sampler kernel's HBM bytes are fitted as
+fixed_bytes_per_launch + bytes_per_walker_step x walkers x steps, which bench.py evaluates at ITS launch size.
+Counters used when present:
   SQ_INSTS_VALU, SQ_INSTS_MFMA, SQ_INSTS_VALU_TRANS_F32, SQ_ACTIVE_INST_VALU (quad-cycles), SQ_VALU_MFMA_BUSY_CYCLES,
   SQ_WAVE_CYCLES, SQ_BUSY_CYCLES, GRBM_GUI_ACTIVE (sum over the 8 XCDs), FETCH_SIZE, WRITE_SIZE (KB).
 Units / corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE and WRITE_SIZE are in KB;
-FETCH_SIZE counts a wide coalesced streaming read at half its bytes (x2 applied to the force kernel, which streams its
-input once; NOT applied to the sampler kernel, whose fetches are scratch reloads of uncalibrated width: reported raw).
+FETCH_SIZE counts a coalesced streaming read at half its bytes (128-B requests tallied at 64 B): x2 applied to every
+kernel here -- all their reads are coalesced streams (walkers, scratch reloads; >= 256 contiguous bytes per wave
+instruction).  Check: the LJ55 sampler reads its 21.6 MB of walkers once per launch and reports FETCH_SIZE 11.3 MB.
 valu_issue_frac = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): share of SIMD cycles in which a vector
 (non-matrix) instruction holds the issue port."""
 import csv
@@ -30,7 +35,13 @@ def load(dirs):
 
 def main():
     config, walkers, chunk, out_path = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
-    acc = load(sys.argv[5:])
+    rest = sys.argv[5:]
+    second = None
+    if "--second" in rest:
+        i = rest.index("--second")
+        second = (int(rest[i + 1]), load(rest[i + 2:]))
+        rest = rest[:i]
+    acc = load(rest)
     mean = lambda k, c: (sum(acc[k][c]) / len(acc[k][c])) if acc[k].get(c) else None
     samp = [k for k in acc if "egnn_kernel" in k and "true" in k.split("(")[0]]
     # the sampler launches: the main kernel is the one with the most MFMA work
@@ -70,9 +81,20 @@ def main():
         if fe is not None and wr is not None:
             e["fetch_bytes_per_launch_raw"] = fe * 1024
             e["write_bytes_per_launch"] = wr * 1024
-            e["traffic_bytes_per_walker_step"] = (fe + wr) * 1024 / ws
+            e["fetch_size_correction"] = 2.0
+            t1 = (2.0 * fe + wr) * 1024
+            e["traffic_bytes_per_launch"] = t1
+            if second is not None and second[1].get(k, {}).get("FETCH_SIZE") and second[1][k].get("WRITE_SIZE"):
+                c2, a2 = second
+                m2 = lambda c: sum(a2[k][c]) / len(a2[k][c])
+                t2 = (2.0 * m2("FETCH_SIZE") + m2("WRITE_SIZE")) * 1024
+                per = (t1 - t2) / (walkers * (chunk - c2))
+                e["bytes_per_walker_step"] = per
+                e["fixed_bytes_per_launch"] = t1 - per * ws
+                e["fit_from"] = {f"{chunk}_steps_per_launch": t1, f"{c2}_steps_per_launch": t2}
         res[f"sampler_{config}"] = e
-    force = [k for k in acc if any(t in k for t in ("lj13_kernel", "pair_energy_kernel", "pair_energy_n3l_kernel", "ff_kernel"))]
+    force = [k for k in acc if any(t in k for t in ("lj13_kernel", "pair_energy_kernel", "pair_energy_n3l_kernel", "ring_energy_kernel",
+                                                    "ff_kernel"))]
     for k in force:
         fe, wr = mean(k, "FETCH_SIZE"), mean(k, "WRITE_SIZE")
         if fe is None or wr is None:
