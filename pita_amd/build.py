@@ -23,6 +23,7 @@ def needs_build():
 
 
 def build(force=False, verbose=True, extra_flags=()):
+    extra_flags = tuple(extra_flags) + tuple(os.environ.get("PITA_EXTRA_HIPCC_FLAGS", "").split())  # tuning aid
     if not force and not needs_build():
         return LIB
     objs = []

@@ -33,10 +33,23 @@ namespace pita {
 namespace {
 
 #ifndef RING_DD_GROUP
-#define RING_DD_GROUP 3
+#define RING_DD_GROUP 2
 #endif
 
 __device__ __forceinline__ void wfence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// one table entry as ONE ds_read_b128 (4 LDS cycles per wave instruction; left to itself the compiler narrows the
+// read to the three components in use, ds_read_b96: 8 cycles -- the pair loop is then bound by the LDS pipe)
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 read_entry(const float* p) {
+  // (volatile keeps the 16-byte read whole; the explicit LDS address space keeps it a ds_read -- address-space
+  // inference skips volatile accesses and would leave a flat load)
+  typedef const volatile f32x4_t __attribute__((address_space(3))) * lds_entry_ptr;
+  const f32x4_t v = *(lds_entry_ptr)(p);
+  float4 o;
+  o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
+  return o;
+}
 
 // v + (v moved across lanes by the DPP control); lanes without a source add 0
 template <int CTRL>
@@ -99,7 +112,9 @@ struct Ring {
 };
 
 // f = sum over the partners j of coef_ij (x_i - x_j), coef = e'(r)/r (LJ: in units of 12 eps / rm^2);
-// e = this lane's share of the pair energy: the pairs (i, i + dd), LJ in units of eps.
+// e = this lane's share of the pair energy: the pairs (i, i + dd), LJ in units of eps -- accumulated as
+// sum s^12 - 2 sum s^6 (two instructions per pair instead of three; the two sums of a lane's <= 32 pairs are O(30) near
+// equilibrium, so the subtraction costs ~1e-6 of the lane's share: inside the fp32 rounding of the 55-lane total).
 template <int N, int DIM, int KIND, bool WANT_E, bool UNIT_RM>
 __device__ __forceinline__ void ring_pairs(const Ring<N, DIM>& r, const float (&xi)[DIM], const float* te,
                                            const PairParams& p, float (&f)[DIM], float& e) {
@@ -107,6 +122,7 @@ __device__ __forceinline__ void ring_pairs(const Ring<N, DIM>& r, const float (&
 #pragma unroll
   for (int k = 0; k < DIM; ++k) f[k] = 0.f;
   e = 0.f;
+  float e12 = 0.f, e6 = 0.f;
 #pragma unroll
   for (int dd = 1; dd <= R::NH + (R::EVEN ? 1 : 0); ++dd) {
     if ((dd - 1) % RING_DD_GROUP == 0) {
@@ -114,11 +130,11 @@ __device__ __forceinline__ void ring_pairs(const Ring<N, DIM>& r, const float (&
       // (its default: every difference vector stays live to the end, > 256 registers)
 #pragma unroll
       for (int k = 0; k < DIM; ++k) asm volatile("" : "+v"(f[k]));
-      asm volatile("" : "+v"(e)::"memory");
+      asm volatile("" : "+v"(e), "+v"(e12), "+v"(e6)::"memory");
       __builtin_amdgcn_sched_barrier(0);
     }
     const bool antipodal = R::EVEN && dd == N / 2;
-    const float4 xj4 = *reinterpret_cast<const float4*>(te + dd * 4);
+    const float4 xj4 = read_entry(te + dd * 4);
     const float xj[3] = {xj4.x, xj4.y, xj4.z};
     float d[DIM], r2 = (KIND == E_LJ) ? p.dist_eps : 0.f;
 #pragma unroll
@@ -126,12 +142,16 @@ __device__ __forceinline__ void ring_pairs(const Ring<N, DIM>& r, const float (&
       d[k] = xi[k] - xj[k];
       r2 = fmaf(d[k], d[k], r2);
     }
-    float coef, ep;
+    float coef, ep = 0.f;
     if (KIND == E_LJ) {
       const float inv = __builtin_amdgcn_rcpf(r2);
       const float s2 = UNIT_RM ? inv : p.rm2 * inv;   // (rm / r)^2
       const float s6 = s2 * s2 * s2;
-      ep = s6 * (s6 - 2.0f);                          // (rm/r)^12 - 2 (rm/r)^6
+      if (WANT_E) {                                   // (rm/r)^12 and (rm/r)^6 sums
+        const float s6e = (antipodal && r.i >= N / 2) ? 0.f : s6;
+        e12 = fmaf(s6e, s6e, e12);
+        e6 += s6e;
+      }
       const float ts = s6 * s2;
       coef = fmaf(-s6, ts, ts);                       // (s^6 - s^12) s^2 = e'(r)/r * rm^2 / (12 eps)
     } else {
@@ -140,19 +160,20 @@ __device__ __forceinline__ void ring_pairs(const Ring<N, DIM>& r, const float (&
       ep = fmaf(p.a * u2, u2, fmaf(p.b, u2, p.c));
       coef = (u * fmaf(4.0f * p.a, u2, 2.0f * p.b)) / dist;
     }
-    if (WANT_E) e += (antipodal && r.i >= N / 2) ? 0.f : ep;
+    if (WANT_E && KIND != E_LJ) e += (antipodal && r.i >= N / 2) ? 0.f : ep;
 #pragma unroll
     for (int k = 0; k < DIM; ++k) f[k] = fmaf(coef, d[k], f[k]);
     if (!antipodal) {
       // the pair (i - dd, i): its coefficient comes from the lane that evaluated it, the difference is formed here
       const float cb = __builtin_bit_cast(
           float, __builtin_amdgcn_ds_bpermute(r.bp[dd - 1], __builtin_bit_cast(int, coef)));
-      const float4 xm4 = *reinterpret_cast<const float4*>(te + (N - dd) * 4);
+      const float4 xm4 = read_entry(te + (N - dd) * 4);
       const float xm[3] = {xm4.x, xm4.y, xm4.z};
 #pragma unroll
       for (int k = 0; k < DIM; ++k) f[k] = fmaf(cb, xi[k] - xm[k], f[k]);
     }
   }
+  if (WANT_E && KIND == E_LJ) e = fmaf(-2.0f, e6, e12);
 }
 
 // raw pair sums -> d logp / dx and log-density (lennardjones_energy.py:125-151: ordered pairs, i.e. every unordered
@@ -318,6 +339,12 @@ __global__ void __launch_bounds__(256) ring_mala_kernel(float* __restrict__ x, f
   extern __shared__ __attribute__((aligned(16))) float sm[];
   __shared__ int cnt[4];
   __shared__ int total_acc;
+  // non-adaptive chains only count: per block and step in LDS, flushed once at the end (a global atomic per wave and
+  // step -- 32 768 x nsteps adds on nsteps addresses for LJ55 -- serialises in the L2 and costs more than the chain)
+  constexpr int STEP_CNT = 512;
+  __shared__ int stepcnt[STEP_CNT];
+  for (int t = threadIdx.x; t < STEP_CNT; t += 256) stepcnt[t] = 0;
+  __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float* tab1 = sm + wave * 2 * R::TAB_F;  // current walkers; pad slot of an entry: this particle's |x' - fwd mean|^2
   float* tab2 = tab1 + R::TAB_F;           // proposals;       pad slot: |x - bwd mean|^2
@@ -478,10 +505,17 @@ __global__ void __launch_bounds__(256) ring_mala_kernel(float* __restrict__ x, f
         if (q.adaptive) {
           exchange(s, acc);
         } else if (lane == 0 && acc) {
-          __hip_atomic_fetch_add(&q.sync[s], (unsigned long long)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (s < STEP_CNT) atomicAdd(&stepcnt[s], acc);
+          else __hip_atomic_fetch_add(&q.sync[s], (unsigned long long)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       store(w, act);
+    }
+    if (!q.adaptive) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < STEP_CNT && t < q.nsteps; t += 256)
+        if (stepcnt[t])
+          __hip_atomic_fetch_add(&q.sync[t], (unsigned long long)stepcnt[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }

@@ -200,3 +200,70 @@ def test_resampling_exchange_moves_only_needed_parents(world):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
+def _worker_scale(rank, world, port, q, Bl, D):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+
+        from oracle import pita_oracle as O
+        from pita_amd.sde_integration import _Comm
+
+        torch.set_num_threads(1)
+        comm = _Comm(None)
+        n = world * Bl
+        gen = torch.Generator().manual_seed(1234)  # same stream on every rank: the "global" batch
+        xg = torch.randn(n, D, generator=gen)
+        x = xg[rank * Bl:(rank + 1) * Bl].clone()
+        # the event's uniform is rank 0's; the log-weights are all-gathered (4 B per walker), ids computed identically
+        u = float(comm.shared_uniform(0.1 + 0.01 * rank))
+        assert u == 0.1
+        for spread in (0.0, 0.3, 3.0):  # flat weights (nobody moves), mild, a few heavy parents
+            a_local = spread * torch.randn(n, generator=gen)[rank * Bl:(rank + 1) * Bl]
+            ag = comm.all_gather(a_local.contiguous())
+            assert ag.shape == (n,)
+            ids = torch.from_numpy(np.asarray(O.sample_cat_sys(ag, u), dtype=np.int64))
+            before = getattr(comm, "rows_received", 0)
+            got = comm.exchange_rows(x, ids, Bl)
+            assert torch.equal(got, xg[ids][rank * Bl:(rank + 1) * Bl])
+            moved = comm.rows_received - before
+            assert moved <= Bl
+            if spread == 0.0:
+                # flat weights: ids are the rotation by floor(u n) (utils.py:111-120: (u + k / n) mod 1 against bins
+                # j / n), so a rank receives exactly that many rows from its successor -- and nothing else
+                assert abs(moved - min(int(u * n), Bl)) <= 1, (moved, int(u * n))
+        # MALA's global acceptance count and the per-step moment buffers: sums over ranks
+        cnt = torch.tensor([rank + 1], dtype=torch.int32)
+        dist.all_reduce(cnt)
+        assert int(cnt) == world * (world + 1) // 2
+        st = comm.all_reduce_sum(torch.full((5, 4), 1.0 + rank, dtype=torch.float64))
+        assert torch.equal(st, torch.full((5, 4), world * (world + 1) / 2, dtype=torch.float64))
+        # X1: the final all-gather returns the global batch in rank order
+        out = comm.all_gather(x)
+        assert out.shape == (n, D) and torch.equal(out, xg)
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,Bl,D", [(4, 4096, 66), (8, 2048, 165)])
+def test_multi_gpu_host_path_at_config_shard_shapes(world, Bl, D):
+    """Configs C4 (16 384 walkers x 66 over 4 GPUs = 4 096 per rank) and C5 (262 144 x 165 over 8 GPUs = 32 768 per rank,
+    here reduced 16x to 2 048 per rank): world sizes 4 and 8 over gloo run the whole host-side protocol of a resampling
+    event (shared uniform, log-weight all-gather, identical ids, uneven all_to_all_single of the distinct parents), the
+    acceptance / moment reductions and the final all-gather.  RCCL itself needs the 8-GPU node: unmeasured here."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_scale, args=(r, world, port, q, Bl, D)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
