@@ -166,3 +166,55 @@ class ForceFieldEnergy(BaseMoleculeEnergy):
             _lib.check(_lib.lib().pita_ff_logp_force(self._native(), x.data_ptr(), logp.data_ptr(), _lib.ptr(force), B,
                                                      _lib.stream_ptr(x.device)), "pita_ff_logp_force")
         return (logp, force) if return_force else logp
+
+
+class ALPEnergy(ForceFieldEnergy):
+    """Drop-in for ``src.energies.alp_energy.ALPEnergy`` (pita/src/energies/alp_energy.py:41-149): the reference
+    constructor's argument names and defaults, the same call contract (``energy(samples, return_force=False)``, samples
+    normalised Cartesian coordinates, ``maybe_unnormalize`` = x * data_normalization_factor when ``should_normalize``;
+    log-density = -E / kT at the integrator temperature ``temperature`` in kelvin, alp_energy.py:101-105,136), so a Hydra
+    ``_target_: pita_amd.alp_energy.ALPEnergy`` can take over ``energy/aldp.yaml``.
+
+    One difference, stated: the reference builds its OpenMM ``System`` from ``pdb_filename`` + amber14-all / implicit/obc1
+    (alp_energy.py:86-100); neither OpenMM nor those parameter files exist here, so this class takes the SAME system in
+    serialized form -- ``system_xml=`` the file ``XmlSerializer.serialize(system)`` writes (what the reference itself
+    does in generate_md.py:105-106).  ``pdb_filename`` / ``atom_encoding_filename`` / ``data_path`` are accepted and
+    kept (the sampling path never reads them).  Without ``system_xml`` the constructor raises.
+
+    PARITY UNPINNED: no OpenMM, no amber14 tables and no reference energy values for this system exist in the reference
+    tree; the kernel is checked against the repository's own CPU restatement of OpenMM's functional forms only."""
+
+    def __init__(self, data_path=None, pdb_filename=None, atom_encoding_filename="atom_types_ecoding.npy",
+                 dimensionality=99, n_particles=33, spatial_dim=3, device="cuda", plot_samples_epoch_period=5,
+                 plotting_buffer_sample_size=512, data_normalization_factor=1.0, is_molecule=True, temperature=1.0,
+                 should_normalize=True, should_remove_mean=False, device_index=0, debug_train_on_test=False,
+                 energy_batch_size=10000, system_xml=None):
+        if system_xml is None:
+            raise _lib.PitaHipError(
+                "ALPEnergy: pass system_xml= (the serialized OpenMM System of the molecule, "
+                "XmlSerializer.serialize(system) as in pita/src/generate_md.py:105-106); building it from "
+                f"pdb_filename={pdb_filename!r} needs OpenMM + amber14, which are not available to this library")
+        tables, opts = tables_from_openmm_xml(system_xml)
+        if len(tables["charge"]) != int(n_particles) or int(dimensionality) != int(n_particles) * int(spatial_dim):
+            raise ValueError(f"ALPEnergy: the System has {len(tables['charge'])} particles, the configuration says "
+                             f"n_particles={n_particles}, dimensionality={dimensionality}")
+        super().__init__(tables, n_particles=int(n_particles), spatial_dim=int(spatial_dim), temperature=float(temperature),
+                         data_normalization_factor=float(data_normalization_factor) if should_normalize else 1.0,
+                         device=device, is_molecule=is_molecule, **opts)
+        self.name = "AL"
+        self.data_path, self.pdb_path, self.atom_encoding_filename = data_path, pdb_filename, atom_encoding_filename
+        self.should_normalize, self.should_remove_mean = bool(should_normalize), bool(should_remove_mean)
+        self.data_normalization_factor = float(data_normalization_factor)
+        self.debug_train_on_test, self.energy_batch_size = debug_train_on_test, int(energy_batch_size)
+        self.device_index = device_index
+        self.plot_samples_epoch_period, self.plotting_buffer_sample_size = plot_samples_epoch_period, plotting_buffer_sample_size
+
+    def __call__(self, samples: torch.Tensor, return_force=False):
+        """alp_energy.py:122-149: chunks of ``energy_batch_size`` (kept: it bounds the per-launch batch), results detached."""
+        x = _lib.dev_tensor(samples, "samples").reshape(-1, self._dimensionality)
+        if x.shape[0] <= self.energy_batch_size:
+            return super().__call__(x, return_force)
+        outs = [super(ALPEnergy, self).__call__(c.contiguous(), return_force) for c in torch.split(x, self.energy_batch_size)]
+        if return_force:
+            return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
+        return torch.cat(outs)

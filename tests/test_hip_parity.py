@@ -1554,6 +1554,37 @@ def test_forcefield_vs_oracle(pa, cutoff, gb):
     assert abs(f.reshape(B, 22, 3).sum(1)).max() < 1e-3 * f.abs().max().item()  # translation invariance
 
 
+def test_alp_energy_from_system_xml_vs_oracle(pa, golden):
+    """A14 boundary: ``ALPEnergy(..., system_xml=)`` (reference constructor names, alp_energy.py:41-59) on the committed
+    serialized-System fixture == the oracle's restatement of OpenMM's functional forms on the same tables (bonded,
+    nonbonded with reaction field, GB-OBC1), in chunks of ``energy_batch_size`` like alp_energy.py:127-145.
+    Parity with OpenMM itself stays unpinned (no OpenMM, no amber14 tables in the reference tree)."""
+    from pita_amd.alp_energy import ALPEnergy
+    from tests._synthetic import synthetic_peptide_gb
+
+    path = os.path.join(ROOT, "tests", "golden", "synthetic_peptide22_system.xml")
+    tabs, pos = synthetic_peptide_gb(22)
+    scale, B = 0.1640, 1000
+    e = ALPEnergy(data_path=None, pdb_filename="A_capped.pdb", dimensionality=66, n_particles=22, temperature=300.0,
+                  data_normalization_factor=scale, energy_batch_size=300, system_xml=path)
+    gen = torch.Generator().manual_seed(6)
+    x = (torch.tensor(pos.reshape(-1), dtype=torch.float32)[None] + 0.004 * torch.randn(B, 66, generator=gen)) / scale
+    lp, f = e(x.cuda(), return_force=True)
+    assert lp.shape == (B,) and f.shape == (B, 66) and torch.equal(lp, e(x.cuda()))
+    e1 = ALPEnergy(dimensionality=66, n_particles=22, temperature=300.0, data_normalization_factor=scale, system_xml=path)
+    assert torch.equal(e1(x.cuda()), lp)  # chunking does not change a walker's value
+    ff_t = {k: torch.as_tensor(v) for k, v in tabs.items()}
+    ff_t = {k: (v.long() if "idx" in k else v.double()) for k, v in ff_t.items()}
+    idx = torch.arange(0, B, 37)
+    lpo, fo = O.ff_logp_force(x[idx].double(), ff_t, e.kT, scale, 2.0)
+    np.testing.assert_allclose(lp[idx.cuda()].cpu().numpy(), lpo.numpy(), rtol=2e-5, atol=2e-3)
+    assert rel(f[idx.cuda()], fo) < 5e-5
+    # should_normalize=False: the samples are taken as nanometres (maybe_unnormalize is the identity)
+    e2 = ALPEnergy(dimensionality=66, n_particles=22, temperature=300.0, data_normalization_factor=scale,
+                   should_normalize=False, system_xml=path)
+    np.testing.assert_allclose(e2((x * scale).cuda()).cpu().numpy(), lp.cpu().numpy(), rtol=1e-5, atol=1e-3)
+
+
 @pytest.mark.parametrize("N", [40, 1000])
 def test_final_histograms_match_oracle_sampler(pa, golden, N):
     """Distribution-level parity of the whole sampler with its OWN noise (Philox): the final interatomic-distance and

@@ -48,3 +48,43 @@ def test_smooth_lj_core_coefficients_match_the_reference(golden):
     assert coef.dtype == np.float32 and coef.shape == (4,)
     np.testing.assert_array_equal(coef, g["spline_c0"])
     assert np.float32(r0) == g["spline_x0"][0]
+
+
+def test_alp_energy_facade_and_system_xml_fixture():
+    """ALPEnergy mirrors the reference constructor (pita/src/energies/alp_energy.py:41-59: same argument names, order and
+    defaults) + ``system_xml``; the committed serialized-System fixture (22-atom synthetic peptide: HarmonicBond/Angle,
+    PeriodicTorsion, Nonbonded + exceptions, CustomGBForce OBC1, CMMotionRemover) parses back to the tables it was
+    written from.  No GPU: only the host side (the kernel handle is created on first call)."""
+    import inspect
+    import os
+
+    from pita_amd.alp_energy import ALPEnergy, tables_from_openmm_xml
+    from tests._synthetic import openmm_system_xml, synthetic_peptide_gb
+
+    ref = [("data_path", inspect._empty), ("pdb_filename", inspect._empty), ("atom_encoding_filename", "atom_types_ecoding.npy"),
+           ("dimensionality", 99), ("n_particles", 33), ("spatial_dim", 3), ("device", "cpu"), ("plot_samples_epoch_period", 5),
+           ("plotting_buffer_sample_size", 512), ("data_normalization_factor", 1.0), ("is_molecule", True),
+           ("temperature", 1.0), ("should_normalize", True), ("should_remove_mean", False), ("device_index", 0),
+           ("debug_train_on_test", False), ("energy_batch_size", 10000)]
+    sig = list(inspect.signature(ALPEnergy.__init__).parameters.values())[1:]
+    assert [p.name for p in sig[:len(ref)]] == [r[0] for r in ref] and sig[len(ref)].name == "system_xml"
+    for p, (name, default) in zip(sig, ref):
+        if name in ("data_path", "pdb_filename", "device"):
+            continue  # optional here (the sampling path never reads the first two); the device defaults to the GPU
+        assert p.default == default, name
+    path = os.path.join(os.path.dirname(__file__), "golden", "synthetic_peptide22_system.xml")
+    t, _ = synthetic_peptide_gb(22)
+    assert open(path).read() == openmm_system_xml(t)  # the fixture is exactly what the committed writer produces
+    tt, opts = tables_from_openmm_xml(path)
+    assert opts == {"cutoff": 2.0, "rf_dielectric": 78.3, "gb_solute_dielectric": 1.0, "gb_solvent_dielectric": 78.5}
+    for k, v in t.items():
+        np.testing.assert_allclose(np.asarray(tt[k], dtype=np.float64).reshape(-1), np.asarray(v, dtype=np.float64).reshape(-1),
+                                   rtol=1e-15, atol=0)
+    e = ALPEnergy(data_path="unused", pdb_filename="A_capped.pdb", dimensionality=66, n_particles=22, temperature=300.0,
+                  data_normalization_factor=0.1640, system_xml=path)
+    assert (e.n_particles, e.n_spatial_dim, e.is_molecule, e.length_scale, e.energy_batch_size) == (22, 3, True, 0.1640, 10000)
+    assert abs(e.kT - 8.314462618e-3 * 300.0) < 1e-12 and e.cutoff == 2.0
+    with np.testing.assert_raises(pita_amd._lib.PitaHipError):
+        ALPEnergy(data_path="x", pdb_filename="A_capped.pdb", dimensionality=66, n_particles=22)  # no OpenMM here
+    with np.testing.assert_raises(ValueError):
+        ALPEnergy(data_path="x", pdb_filename="y", dimensionality=99, n_particles=33, system_xml=path)
