@@ -537,6 +537,7 @@ def main():
                 "traffic_model": {k: pk[k] for k in ("fixed_bytes_per_launch", "bytes_per_walker_step", "fit_from",
                                                      "fetch_size_correction") if k in pk} if same else None,
                 "ms_per_launch": avg_ms, "launches": n_launch, "steps_per_launch": chunk,
+                "ms_of_each_launch": [round(v, 4) for v in launch_ms[:64]],
                 # what the matrix pipe actually executes (fp32-accurate split products included): pipe utilisation
                 "achieved_executed": achieved, "frac_executed": achieved / PEAK_MFMA16_TFLOPS,
                 "executed_mfma_flop_per_walker_step": exec16,

@@ -242,11 +242,24 @@ __global__ void __launch_bounds__(256) ring_energy_kernel(const float* __restric
   float* tab = sm + wave * R::TAB_F;
   const R r(lane);
   const long long ngroups = (B + R::WPW - 1) / R::WPW, nwaves = (long long)gridDim.x * 4;
-  for (long long g = (long long)blockIdx.x * 4 + wave; g < ngroups; g += nwaves) {
+  // the next group's coordinates are fetched while the current one is being worked on (a wave owns several groups
+  // when the batch exceeds the resident waves; without the prefetch each pays the full HBM latency in sequence)
+  float xn[DIM];
+  long long g = (long long)blockIdx.x * 4 + wave;
+  if (g < ngroups) {
+    const long long w = g * R::WPW + r.wl;
+    load_x<N, DIM>(r, x, w < B ? w : B - 1, xn);
+  }
+  for (; g < ngroups; g += nwaves) {
     const long long w = g * R::WPW + r.wl;
     const bool act = r.real && w < B;
     float xi[DIM], f[DIM], e, lp = 0.f;
-    load_x<N, DIM>(r, x, w < B ? w : B - 1, xi);
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) xi[k] = xn[k];
+    if (g + nwaves < ngroups) {
+      const long long wn = (g + nwaves) * R::WPW + r.wl;
+      load_x<N, DIM>(r, x, wn < B ? wn : B - 1, xn);
+    }
     r.put(tab, xi);
     wfence();
     ring_pairs<N, DIM, KIND, true, UNIT_RM>(r, xi, r.entry(tab), p, f, e);
@@ -537,23 +550,39 @@ struct RingLaunch {
     const long long ngroups = (B + R::WPW - 1) / R::WPW, want = (ngroups + 3) / 4, cap = (long long)cus() * blocks_per_cu;
     return (unsigned)(want < cap ? want : cap);
   }
+  // resident blocks per CU of a kernel (registers and LDS decide): the persistent grids are exactly one residency
+  template <class K>
+  static int resident(K kernel, size_t lds, int& cache) {
+    if (cache == 0) {
+      int v = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kernel, 256, lds) != hipSuccess || v <= 0) v = 4;
+      cache = v;
+    }
+    return cache;
+  }
   static int energy(const float* x, float* logp, float* force, long long B, const PairParams& p, hipStream_t s) {
     const size_t lds = sizeof(float) * 4 * R::TAB_F;
-    const unsigned grid = grid_for(B, 8);
-    if (KIND == E_LJ && p.rm2 == 1.0f)
+    static int occ[2] = {0, 0};
+    if (KIND == E_LJ && p.rm2 == 1.0f) {
+      const unsigned grid = grid_for(B, resident(ring_energy_kernel<N, DIM, KIND, true>, lds, occ[1]));
       hipLaunchKernelGGL((ring_energy_kernel<N, DIM, KIND, true>), dim3(grid), dim3(256), lds, s, x, logp, force, B, p);
-    else
+    } else {
+      const unsigned grid = grid_for(B, resident(ring_energy_kernel<N, DIM, KIND, false>, lds, occ[0]));
       hipLaunchKernelGGL((ring_energy_kernel<N, DIM, KIND, false>), dim3(grid), dim3(256), lds, s, x, logp, force, B, p);
+    }
     PITA_LAUNCH_CHECK();
     return PITA_OK;
   }
   static int descent(float* x, const float* noise, long long B, const PairParams& p, const DescentParams& q, hipStream_t s) {
     const size_t lds = sizeof(float) * 4 * R::TAB_F;
-    const unsigned grid = grid_for(B, 8);
-    if (KIND == E_LJ && p.rm2 == 1.0f)
+    static int occ[2] = {0, 0};
+    if (KIND == E_LJ && p.rm2 == 1.0f) {
+      const unsigned grid = grid_for(B, resident(ring_descent_kernel<N, DIM, KIND, true>, lds, occ[1]));
       hipLaunchKernelGGL((ring_descent_kernel<N, DIM, KIND, true>), dim3(grid), dim3(256), lds, s, x, noise, B, p, q);
-    else
+    } else {
+      const unsigned grid = grid_for(B, resident(ring_descent_kernel<N, DIM, KIND, false>, lds, occ[0]));
       hipLaunchKernelGGL((ring_descent_kernel<N, DIM, KIND, false>), dim3(grid), dim3(256), lds, s, x, noise, B, p, q);
+    }
     PITA_LAUNCH_CHECK();
     return PITA_OK;
   }

@@ -292,8 +292,9 @@ class WeightedSDEIntegrator:
         # log-weights are identically zero here; a stride-0 view avoids N*B*4 bytes (reference stacks N copies)
         logweights = torch.zeros(1, Bg, device=dev).expand(N, Bg)
         if st4 is not None:
-            sde_terms_all = _terms_from_stats(comm.all_reduce_sum(st4), None, Bg * x1.shape[1], Bg,
-                                              [k >= start for k in range(N)], False)
+            # moments come from the world * Bl walkers that are integrated (Bg % world walkers are dropped, :227)
+            sde_terms_all = _terms_from_stats(comm.all_reduce_sum(st4), None, comm.world * Bl * x1.shape[1],
+                                              comm.world * Bl, [k >= start for k in range(N)], False)
 
         if self.resample_at_end and did_resampling:
             x, a_next, n_unique = self._resample_at_end(x, None, comm, times, energy_function, annealing_factor_schedule,
@@ -370,7 +371,8 @@ class WeightedSDEIntegrator:
                 sde_terms_all.append(terms)
         logweights = torch.stack(logweights)
         if st4 is not None:
-            sde_terms_all = _terms_from_stats(comm.all_reduce_sum(st4), comm.all_reduce_sum(st8), Bg * x.shape[1], Bg,
+            sde_terms_all = _terms_from_stats(comm.all_reduce_sum(st4), comm.all_reduce_sum(st8),
+                                              comm.world * Bl * x.shape[1], comm.world * Bl,
                                               [k >= self.start_resampling_step for k in range(N)], True)
         did_resampling = resampling_interval != -1 and resampling_interval < N
         if self.resample_at_end and did_resampling:

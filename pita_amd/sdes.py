@@ -71,6 +71,21 @@ class TermStats:
     def cpu(self):
         return self
 
+    def detach(self):
+        return self
+
+    def sum(self):
+        return torch.tensor(self.s, dtype=torch.float32)
+
+    def var(self):
+        return self.std() ** 2
+
+    def __getattr__(self, name):
+        # anything else a caller could ask of the reference's full tensor: say what to do instead of an AttributeError
+        # on a float (the reference's own callers take mean / std only, energytemp_module.py:938-945,1132-1143)
+        raise AttributeError(f"TermStats carries sum, sum of squares and count of an SDETerms field, not the tensor: "
+                             f"'{name}' needs WeightedSDEIntegrator(..., record_terms=True)")
+
     def __repr__(self):
         return f"TermStats(mean={float(self.mean()):.6g}, std={float(self.std()):.6g}, n={self.n})"
 
