@@ -165,9 +165,17 @@ __device__ __forceinline__ void ring_pairs(const Ring<N, DIM>& r, const float (&
     for (int k = 0; k < DIM; ++k) f[k] = fmaf(coef, d[k], f[k]);
     if (!antipodal) {
       // the pair (i - dd, i): its coefficient comes from the lane that evaluated it, the difference is formed here
+#if defined(RING_EXP) && (RING_EXP & 1)
+      const float cb = coef * 0.999f;  // TIMING EXPERIMENT ONLY (wrong results): no cross-lane permute
+#else
       const float cb = __builtin_bit_cast(
           float, __builtin_amdgcn_ds_bpermute(r.bp[dd - 1], __builtin_bit_cast(int, coef)));
+#endif
+#if defined(RING_EXP) && (RING_EXP & 2)
+      const float4 xm4 = xj4;  // TIMING EXPERIMENT ONLY: no second table read
+#else
       const float4 xm4 = read_entry(te + (N - dd) * 4);
+#endif
       const float xm[3] = {xm4.x, xm4.y, xm4.z};
 #pragma unroll
       for (int k = 0; k < DIM; ++k) f[k] = fmaf(cb, xi[k] - xm[k], f[k]);

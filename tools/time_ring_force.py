@@ -1,9 +1,10 @@
 """Only the LJ55 logp+force launches (for rocprofv3 --pmc passes): 32 768 walkers, 50 launches."""
-import sys, torch, numpy as np
-sys.path.insert(0, ".")
+import os, sys, torch, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import pita_amd as pa
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
-g = np.load("tests/golden/lj55_logp_force.npz")
+g = np.load(os.path.join(ROOT, "tests/golden/lj55_logp_force.npz"))
 base = torch.as_tensor(g["x"][: int(g["n_cold"])], dtype=torch.float32)
 x = base.repeat((B + base.shape[0] - 1) // base.shape[0], 1)[:B].contiguous().cuda()
 lp, f = torch.empty(B, device="cuda"), torch.empty_like(x)
