@@ -97,8 +97,8 @@ int pita_dw_descent(float* x, const float* noise, int64_t B, int n_particles, in
  * particle / 0xFFFFF), walker key = walker_ids[w] or walker_offset + w.  workspace: 8-byte aligned device scratch of
  * pita_lj_mala_workspace_bytes(nsteps) bytes.
  * The adaptive chain synchronises the grid once per step (the global acceptance count decides the next step size); the
- * grid is sized to the co-resident capacity of an idle device.  LJ55 / DW4 batches beyond it make one HBM round trip per
- * step; the LJ13 kernel returns PITA_EUNSUPPORTED for them (launch-per-kernel path).  If the device was NOT idle and a
+ * grid is sized to the co-resident capacity of an idle device; batches beyond it make one HBM round trip of the walkers
+ * per step (steps outside, tiles inside) instead of staying on chip.  If the device was NOT idle and a
  * block's bounded wait runs out, the chain is invalid: dt_dev[0] and every rates_out[s] are set to NaN (x / logp hold
  * garbage) and the caller must rerun from its own copy of the walkers -- pita_amd.WeightedSDEIntegrator does. */
 size_t pita_lj_mala_workspace_bytes(int nsteps);

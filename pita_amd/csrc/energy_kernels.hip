@@ -416,6 +416,69 @@ __global__ void __launch_bounds__(256, 4) lj13_kernel(const float* __restrict__ 
   }
 }
 
+// Large batches (one lane per walker, several tiles per block): the same tile routine in a persistent block that keeps
+// the NEXT tile's coordinates in flight while it works on the current one.  A tile is 256 walkers x 156 B = 39 KB; its
+// ten 16-byte loads per lane are issued before the pair loop of the tile before it starts and land in registers, so every
+// resident block (three per CU: LDS) has a full tile in flight all the time instead of only while it waits for it --
+// the plain kernel above computes and streams at 0.46 of the HBM peak because its three blocks per CU have, on
+// average, one tile in flight between them (bandwidth = bytes in flight / latency) and the vector pipe idles meanwhile.
+template <bool UNIT_RM>
+__global__ void __launch_bounds__(256, 3) lj13_stream_kernel(const float* __restrict__ x, float* __restrict__ logp,
+                                                             float* __restrict__ force, long long B, PairParams p) {
+  constexpr int D = 39, WPB = 256, NV = (WPB * D / 4 + 255) / 256;  // 16-byte pieces of a tile per lane: 10 (9.75)
+  __shared__ __attribute__((aligned(16))) float fb[WPB * D];
+  __shared__ float es[WPB];
+  const int tid = threadIdx.x;
+  const long long nblk = (B + WPB - 1) / WPB;
+  float4 nxt[NV];
+  // full tiles only take the register path (a last, ragged tile is loaded in place below)
+#define LJ13_FETCH(BLK)                                                                   \
+  {                                                                                       \
+    const float4* src4_ = reinterpret_cast<const float4*>(x + (BLK) * WPB * D);           \
+    _Pragma("unroll") for (int v = 0; v < NV; ++v) {                                      \
+      const int q_ = tid + v * 256;                                                       \
+      nxt[v] = (v < NV - 1 || q_ < WPB * D / 4) ? src4_[q_ < WPB * D / 4 ? q_ : 0] : float4{0.f, 0.f, 0.f, 0.f}; \
+    }                                                                                     \
+  }
+  long long blk = blockIdx.x;
+  bool have = false;
+  if (blk < nblk && (blk + 1) * WPB <= B) { LJ13_FETCH(blk); have = true; }
+  for (; blk < nblk; blk += gridDim.x) {
+    const long long w0 = blk * WPB;
+    const int nw = (int)((B - w0) < WPB ? (B - w0) : WPB);
+    const int nfl = nw * D;
+    if (have) {
+      float4* dst4 = reinterpret_cast<float4*>(&fb[0]);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int q = tid + v * 256;
+        if (q < WPB * D / 4) dst4[q] = nxt[v];
+      }
+    } else {
+      const float4* src4 = reinterpret_cast<const float4*>(x + w0 * D);
+      float4* dst4 = reinterpret_cast<float4*>(&fb[0]);
+      for (int q = tid; q < nfl / 4; q += 256) dst4[q] = src4[q];
+      for (int q = (nfl & ~3) + tid; q < nfl; q += 256) fb[q] = x[w0 * D + q];
+    }
+    const long long nb = blk + gridDim.x;
+    have = nb < nblk && (nb + 1) * WPB <= B;
+    if (have) LJ13_FETCH(nb);  // in flight during this tile's pair loop
+    __syncthreads();
+    const bool act = tid < nw;
+    const int row = (act ? tid : 0) * D;
+    lj13_body<1, 1, UNIT_RM>(&fb[row], &fb[row], &es[tid], p, act);
+    __syncthreads();
+    if (force) {
+      float4* dst4 = reinterpret_cast<float4*>(force + w0 * D);
+      for (int q = tid; q < nfl / 4; q += 256) dst4[q] = reinterpret_cast<const float4*>(&fb[0])[q];
+      for (int q = (nfl & ~3) + tid; q < nfl; q += 256) force[w0 * D + q] = fb[q];
+    }
+    if (tid < nw) logp[w0 + tid] = -p.inv_T * es[tid];
+    __syncthreads();
+  }
+#undef LJ13_FETCH
+}
+
 // ---------------------------------------------------------------------------- fused descent on the target
 // S steps of  x <- remove_mean(x + F(x) dt + noise_scale * sqrt_dt * xi)  in ONE launch
 // (sde_integration.py:353-360 negative_time_descent; ULA when noise_scale = 1).  The walkers of a block stay
@@ -660,11 +723,20 @@ __global__ void __launch_bounds__(256, 2) lj13_mala_kernel(float* __restrict__ x
   const int tid = threadIdx.x;
   const int half = tid / WPB, wl = tid - half * WPB;
   const long long nblk = (B + WPB - 1) / WPB;
-  // adaptive: exactly one tile per block (the wrapper launches nblk blocks); else a grid-stride loop over tiles
-  for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-    const long long w0 = blk * WPB;
-    const int nw = (int)((B - w0) < WPB ? (B - w0) : WPB);
-    const int nfl = nw * D;
+  // Tiles of 128 walkers.  Non-adaptive chains and adaptive chains with at most one tile per block keep a tile in LDS
+  // for all steps; an adaptive chain with more tiles than resident blocks runs steps outside, tiles inside, one HBM
+  // round trip of the walkers per step (the grid barrier of a step needs every tile's count first).
+  const bool roundtrip = q.adaptive && nblk > (long long)gridDim.x;
+  double dt = q.dt_dev[0];
+  long long w0 = 0, wg = 0;
+  int nw = 0, nfl = 0, row = 0;
+  bool act = false;
+  unsigned long long key = 0;
+  float lp = 0.f;
+  auto load = [&](long long blk) {
+    w0 = blk * WPB;
+    nw = (int)((B - w0) < WPB ? (B - w0) : WPB);
+    nfl = nw * D;
     {
       const float4* src4 = reinterpret_cast<const float4*>(x + w0 * D);
       float4* dst4 = reinterpret_cast<float4*>(xs);
@@ -672,13 +744,24 @@ __global__ void __launch_bounds__(256, 2) lj13_mala_kernel(float* __restrict__ x
       for (int i = (nfl & ~3) + tid; i < nfl; i += 256) xs[i] = x[w0 * D + i];
     }
     __syncthreads();
-    const bool act = wl < nw;
-    const int row = (act ? wl : 0) * D;
-    const long long wg = w0 + (act ? wl : 0);
-    const unsigned long long key = q.walker_ids ? (unsigned long long)q.walker_ids[wg] : q.walker_offset + (unsigned long long)wg;
-    float lp = (half == 0 && act) ? logp[wg] : 0.f;
-    double dt = q.dt_dev[0];
-    for (int s = 0; s < q.nsteps; ++s) {
+    act = wl < nw;
+    row = (act ? wl : 0) * D;
+    wg = w0 + (act ? wl : 0);
+    key = q.walker_ids ? (unsigned long long)q.walker_ids[wg] : q.walker_offset + (unsigned long long)wg;
+    lp = (half == 0 && act) ? logp[wg] : 0.f;
+  };
+  auto store = [&]() {
+    {
+      float4* dst4 = reinterpret_cast<float4*>(x + w0 * D);
+      const float4* src4 = reinterpret_cast<const float4*>(xs);
+      for (int i = tid; i < nfl / 4; i += 256) dst4[i] = src4[i];
+      for (int i = (nfl & ~3) + tid; i < nfl; i += 256) x[w0 * D + i] = xs[i];
+    }
+    if (half == 0 && act) logp[wg] = lp;
+    __syncthreads();
+  };
+  // one MALA step of the tile in LDS; returns the tile's accepted walkers (in every thread)
+  auto step = [&](int s) -> int {
       const float hdt = (float)(0.5 * dt), sdt = (float)sqrt(dt), tdt = (float)(2.0 * dt);
       float fr[39], e;
       // ---- A: target force at x
@@ -776,33 +859,44 @@ __global__ void __launch_bounds__(256, 2) lj13_mala_kernel(float* __restrict__ x
       const unsigned long long bal = __ballot(acc);
       if ((tid & 63) == 0) cnt[tid >> 6] = __popcll(bal);
       __syncthreads();
-      if (tid == 0) {
-        const unsigned long long c = (unsigned long long)(cnt[0] + cnt[1] + cnt[2] + cnt[3]);
-        __hip_atomic_fetch_add(&q.sync[s], (1ull << 32) | c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (q.adaptive) {  // grid-wide barrier: wait until every block has added its count
-          unsigned long long v = 0;
-          int spins = 0;
-          while (((v = __hip_atomic_load(&q.sync[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) < gridDim.x) {
-            if (++spins > q.spin_limit) { q.sync[q.nsteps] = 1; break; }  // never hang the device
-            __builtin_amdgcn_s_sleep(2);
-          }
-          total_acc = (int)(v & 0xFFFFFFFFull);
+    return cnt[0] + cnt[1] + cnt[2] + cnt[3];
+  };
+  // a step's count of this block goes to the grid; adaptive chains wait for everybody's and adapt dt
+  auto publish = [&](int s, int c) {
+    if (tid == 0) {
+      __hip_atomic_fetch_add(&q.sync[s], (1ull << 32) | (unsigned long long)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (q.adaptive) {  // grid-wide barrier: wait until every block has added its count
+        unsigned long long v = 0;
+        int spins = 0;
+        while (((v = __hip_atomic_load(&q.sync[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) < gridDim.x) {
+          if (++spins > q.spin_limit) { q.sync[q.nsteps] = 1; break; }  // never hang the device
+          __builtin_amdgcn_s_sleep(2);
         }
-      }
-      __syncthreads();
-      if (q.adaptive) {
-        const float rate = (float)total_acc / (float)q.total;
-        dt = ((double)rate > 0.55) ? dt * 1.1 : dt / 1.1;  // sde_integration.py:439-443
+        total_acc = (int)(v & 0xFFFFFFFFull);
       }
     }
-    {
-      float4* dst4 = reinterpret_cast<float4*>(x + w0 * D);
-      const float4* src4 = reinterpret_cast<const float4*>(xs);
-      for (int i = tid; i < nfl / 4; i += 256) dst4[i] = src4[i];
-      for (int i = (nfl & ~3) + tid; i < nfl; i += 256) x[w0 * D + i] = xs[i];
-    }
-    if (half == 0 && act) logp[wg] = lp;
     __syncthreads();
+    if (q.adaptive) {
+      const float rate = (float)total_acc / (float)q.total;
+      dt = ((double)rate > 0.55) ? dt * 1.1 : dt / 1.1;  // sde_integration.py:439-443
+    }
+  };
+  if (roundtrip) {
+    for (int s = 0; s < q.nsteps; ++s) {
+      int c = 0;
+      for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        load(blk);
+        c += step(s);
+        store();
+      }
+      publish(s, c);
+    }
+  } else {
+    for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+      load(blk);
+      for (int s = 0; s < q.nsteps; ++s) publish(s, step(s));
+      store();
+    }
   }
 }
 
@@ -1007,6 +1101,24 @@ extern "C" int pita_lj_logp_force(const float* x, float* logp, float* force, int
     const unsigned grid = (unsigned)(nblk < 256LL * 32 ? nblk : 256LL * 32);
     const bool unit = p.rm2 == 1.0f;
     hipStream_t s = (hipStream_t)stream;
+    if (!two && !getenv("PITA_LJ13_NO_STREAM")) {  // persistent blocks with the next tile in flight
+      static int per_cu = 0, n_cu = 0;
+      if (per_cu == 0) {
+        int dev = 0, v = 0;
+        hipDeviceProp_t prop;
+        PITA_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, lj13_stream_kernel<true>, 256, 0));
+        PITA_HIP_CHECK(hipGetDevice(&dev));
+        PITA_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        per_cu = v > 0 ? v : 1;
+        n_cu = prop.multiProcessorCount;
+      }
+      const long long cap = (long long)per_cu * n_cu;
+      const unsigned g2 = (unsigned)(nblk < cap ? nblk : cap);
+      if (unit) hipLaunchKernelGGL(lj13_stream_kernel<true>, dim3(g2), dim3(256), 0, s, x, logp, force, (long long)B, p);
+      else hipLaunchKernelGGL(lj13_stream_kernel<false>, dim3(g2), dim3(256), 0, s, x, logp, force, (long long)B, p);
+      PITA_LAUNCH_CHECK();
+      return PITA_OK;
+    }
     if (two && unit) hipLaunchKernelGGL((lj13_kernel<2, true>), dim3(grid), dim3(256), 0, s, x, logp, force, (long long)B, p);
     else if (two) hipLaunchKernelGGL((lj13_kernel<2, false>), dim3(grid), dim3(256), 0, s, x, logp, force, (long long)B, p);
     else if (unit) hipLaunchKernelGGL((lj13_kernel<1, true>), dim3(grid), dim3(256), 0, s, x, logp, force, (long long)B, p);
@@ -1134,9 +1246,6 @@ extern "C" int pita_lj_mala(float* x, float* logp, const float* noise, const flo
     PITA_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
     capacity = per_cu * prop.multiProcessorCount;
   }
-  if (adaptive && nblk > capacity)
-    return fail(PITA_EUNSUPPORTED, "pita_lj_mala: the adaptive chain needs all %lld blocks resident (capacity %d)", nblk,
-                capacity);
   return run_mala_chain(nsteps, dt_dev, adaptive, total, rates_out, workspace, q, stream, [&]() {
     if (nblk == 0) return (int)PITA_OK;
     const unsigned grid = (unsigned)(nblk < capacity ? nblk : capacity);

@@ -21,7 +21,13 @@
 //     exactly as with an explicit hand-over;
 //   * for even N the antipodal distance N/2 pairs every particle with one partner: both lanes evaluate it (identical
 //     bits), the energy is counted by the lower half.
-// Per pair and lane: 2 LDS reads, 1 permute, ~21 vector instructions + v_rcp_f32 (LJ).  Sums over a walker's particles
+// Per pair and lane: 2 LDS reads, 1 permute, ~23 vector instructions + v_rcp_f32 (LJ) -- 684 vector instructions per LJ55
+// walker-evaluation, and that count is the bound: PMC on the final kernel gives 3 300 SIMD cycles per walker with the
+// vector pipe busy 0.86 of them (one fp32 wave instruction per ~4.2 cycles); without the permutes and second reads
+// (wrong results, timing only) 41 us instead of 46 at 32 768 walkers.  A packed-fp32 pair loop (two distances per
+// v_pk_fma_f32 on a structure-of-arrays table, 281 packed + 87 plain instructions) measured 54 us: the packed operations
+// issue at half rate on this chip, as tools/ubench/isa_rates.hip says, so the 157 TFLOP/s vector peak -- which counts
+// them at full rate -- is not reachable by this arithmetic; against the plain-FMA rate the kernel sits at 0.38.  Sums over a walker's particles
 // that belong to THIS file's arithmetic only (oscillator centre, energy) are DPP tree reductions; sums whose order is
 // shared with the per-step kernels (remove_mean of pita_em_step, the proposal densities and centring of
 // pita_mala_accept: sequential over the particles from 0.f) keep that order, carried by a few lanes that walk the LDS
@@ -165,17 +171,9 @@ __device__ __forceinline__ void ring_pairs(const Ring<N, DIM>& r, const float (&
     for (int k = 0; k < DIM; ++k) f[k] = fmaf(coef, d[k], f[k]);
     if (!antipodal) {
       // the pair (i - dd, i): its coefficient comes from the lane that evaluated it, the difference is formed here
-#if defined(RING_EXP) && (RING_EXP & 1)
-      const float cb = coef * 0.999f;  // TIMING EXPERIMENT ONLY (wrong results): no cross-lane permute
-#else
       const float cb = __builtin_bit_cast(
           float, __builtin_amdgcn_ds_bpermute(r.bp[dd - 1], __builtin_bit_cast(int, coef)));
-#endif
-#if defined(RING_EXP) && (RING_EXP & 2)
-      const float4 xm4 = xj4;  // TIMING EXPERIMENT ONLY: no second table read
-#else
       const float4 xm4 = read_entry(te + (N - dd) * 4);
-#endif
       const float xm[3] = {xm4.x, xm4.y, xm4.z};
 #pragma unroll
       for (int k = 0; k < DIM; ++k) f[k] = fmaf(cb, xi[k] - xm[k], f[k]);

@@ -122,6 +122,26 @@ def test_lj_vs_oracle_random_and_edges(pa):
         e(torch.zeros(4, 39))  # CPU tensor: no fallback, must fail loudly
 
 
+def test_lj13_large_batch_streaming_kernel(pa, monkeypatch):
+    """Beyond 262 144 walkers pita_lj_logp_force runs persistent blocks that keep the next tile's coordinates in flight
+    (lj13_stream_kernel): same tile arithmetic as the plain one-lane-per-walker kernel -> bit-identical to it
+    (PITA_LJ13_NO_STREAM=1 selects the plain kernel), ragged last tile included, and equal to the oracle."""
+    gen = torch.Generator().manual_seed(8)
+    B = 262144 + 300 + 77
+    x = (torch.randn(B, 39, generator=gen) * 0.6 + torch.linspace(-2, 2, 39)[None]).cuda()
+    e = pa.LennardJonesEnergy(39, 13, 3, temperature=1.5)
+    lp, f = e(x, return_force=True)
+    monkeypatch.setenv("PITA_LJ13_NO_STREAM", "1")
+    lp0, f0 = e(x, return_force=True)
+    monkeypatch.delenv("PITA_LJ13_NO_STREAM")
+    assert torch.equal(lp, lp0) and torch.equal(f, f0)
+    assert torch.equal(e(x), lp)  # force == NULL path
+    idx = torch.cat([torch.arange(0, B, 4099), torch.arange(B - 400, B, 7)])
+    lp_o, f_o = O.lj_logp_force(x[idx.cuda()].cpu().double(), 13, 3, temperature=1.5)
+    np.testing.assert_allclose(lp[idx.cuda()].cpu().numpy(), lp_o.numpy(), rtol=2e-5)
+    assert rel(f[idx.cuda()], f_o) < 2e-5
+
+
 def test_dw4_vs_oracle(pa):
     gen = torch.Generator().manual_seed(4)
     x = torch.randn(513, 8, generator=gen) * 2.5
@@ -601,11 +621,12 @@ def test_post_processing_golden(pa, golden):
 
 
 @pytest.mark.parametrize("adaptive", [False, True])
-@pytest.mark.parametrize("B,steps", [(777, 6), (128, 3), (5, 4), (65536, 5)])
+@pytest.mark.parametrize("B,steps", [(777, 6), (128, 3), (5, 4), (65536, 5), (70001, 3)])
 def test_fused_mala_equals_per_step(pa, golden, B, steps, adaptive):
     """pita_lj_mala (all steps, both target evaluations per step, accept / reject and step-size adaptation in one launch)
     == the launch-per-kernel chain, bit for bit: walkers, acceptance rates, with Philox and with injected noise /
-    uniforms, with and without centring, ragged and full blocks, and with a walker that is set aside (quirk Q7)."""
+    uniforms, with and without centring, ragged and full blocks, with a walker that is set aside (quirk Q7), and with more
+    tiles than co-resident blocks (70 001 walkers: the adaptive chain then makes one HBM round trip per step)."""
     g = golden("post_lj13.npz")
     e = pa.LennardJonesEnergy(39, 13, 3)
     gen = torch.Generator().manual_seed(B + steps)
