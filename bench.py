@@ -259,9 +259,19 @@ def force_roofline(pita_amd, cfg, energy, x, dev, reps):
     n, d, B = cfg["n"], cfg["d"], x.shape[0]
 
     def timed(fn, k):
+        """us per call over >= k back-to-back calls, after ~40 ms of the same calls: short launches measured from a cold
+        start run at the clock the chip is still ramping through (the 2^21-walker LJ13 launch: 183 us cold, 150 us after
+        40 ms of work), which says nothing about the kernel."""
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         for _ in range(3):
             fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e1.record()
+        torch.cuda.synchronize()
+        per_call_ms = max(e0.elapsed_time(e1) / 3, 1e-3)
+        for _ in range(min(4000, int(40.0 / per_call_ms) + 1)):
+            fn()
+        k = max(k, min(4000, int(20.0 / per_call_ms) + 1))
         e0.record()
         for _ in range(k):
             fn()

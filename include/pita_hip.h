@@ -15,7 +15,12 @@
  *   - walker-major row-major layout [B, D] with D = n_particles * n_dim, fp32, exactly the
  *     reference's tensor layout (no transposes at the boundary);
  *   - every function returns 0 on success or a negative PITA_E* code; pita_last_error()
- *     gives the message.  Nothing throws, nothing aborts.
+ *     gives the message.  Nothing throws, nothing aborts;
+ *   - handles (pita_egnn_t, pita_mlp_t, pita_ff_t) live on the device that was current when they were
+ *     created; calls that take an EGNN handle make that device current for their duration (its scratch
+ *     buffers -- reverse-mode checkpoints, the f16 path's walker backup, divergence marks, the primal
+ *     cache -- grow on demand on THAT device) and restore the caller's.  A handle's scratch is shared by
+ *     its launches: use one handle from ONE stream at a time (one handle per stream for concurrency).
  */
 #ifndef PITA_HIP_H
 #define PITA_HIP_H

@@ -320,6 +320,20 @@ __device__ __forceinline__ float xhalf_sum(float v) {
 
 }  // namespace pita
 
+// makes `device` current for the lifetime of the guard (no-op when it already is)
+struct PitaDeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit PitaDeviceGuard(int device) {
+    if (device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != device) switched = hipSetDevice(device) == hipSuccess;
+  }
+  ~PitaDeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  PitaDeviceGuard(const PitaDeviceGuard&) = delete;
+  PitaDeviceGuard& operator=(const PitaDeviceGuard&) = delete;
+};
+
 struct pita_egnn {
   pita_egnn_config cfg;
   unsigned* d_mats16 = nullptr;  // [L][M_COUNT][3][2][64][4]  bf16-split fragments
@@ -331,6 +345,10 @@ struct pita_egnn {
   const void* shape = nullptr;   // pita::EgnnShape of egnn_kernel.hip
   const void* shape_small = nullptr;  // optional mapping with fewer walkers per wave, for batches that underfill the GPU
   int n_cu = 256;
+  int device = -1;               // the device the handle's memory lives on: every entry point runs under it (a handle
+                                 // may be called while another device is current; its lazily grown scratch buffers --
+                                 // ws, divcache, mark, bk -- must land on ITS device).  One handle serves ONE stream at a
+                                 // time: those buffers are shared by its launches (include/pita_hip.h, threading)
   float* d_ws = nullptr;         // reverse-mode checkpoint scratch (egnn_vjp_kernel.hip), grown on demand
   size_t ws_bytes = 0;
   float* d_divcache = nullptr;   // precision 2: per-edge primal factors of one trace (egnn_div_kernel.hip, DivCache)

@@ -2020,6 +2020,7 @@ extern "C" int pita_egnn_div_accumulate(pita_egnn_t* net, const float* h, const 
                                         int ndir, float* diag_acc, float* out, int64_t B, void* stream) {
   PITA_REQUIRE(net && B >= 0, "pita_egnn_div_accumulate: bad argument");
   if (B == 0) return PITA_OK;
+  PitaDeviceGuard guard(net->device);
   PITA_REQUIRE(h && x && diag_acc, "pita_egnn_div_accumulate: null argument");
   PITA_REQUIRE(beta || net->cfg.in_node_nf == 1, "pita_egnn_div_accumulate: beta required for in_node_nf=2");
   const int D = net->cfg.n_particles * net->cfg.n_dim;
@@ -2069,6 +2070,7 @@ extern "C" int pita_egnn_jacobian_trace(pita_egnn_t* net, const float* h, const 
                                         float* denoiser_out, int64_t B, void* stream) {
   PITA_REQUIRE(net && B >= 0, "pita_egnn_jacobian_trace: bad argument");
   if (B == 0) return PITA_OK;
+  PitaDeviceGuard guard(net->device);
   PITA_REQUIRE(h && x && trace, "pita_egnn_jacobian_trace: null argument");
   PITA_REQUIRE(beta || net->cfg.in_node_nf == 1, "pita_egnn_jacobian_trace: beta required for in_node_nf=2");
   const int n = net->cfg.n_particles, dim = net->cfg.n_dim, D = n * dim, L = net->cfg.n_layers;

@@ -377,6 +377,7 @@ extern "C" int pita_egnn_jvp(pita_egnn_t* net, const float* h, const float* x, c
                              int64_t dot_off, float* diag_acc, int64_t B, void* stream) {
   PITA_REQUIRE(net && B >= 0, "pita_egnn_jvp: bad argument");
   if (B == 0) return PITA_OK;
+  PitaDeviceGuard guard(net->device);
   PITA_REQUIRE(h && x && (dout || dot_out || diag_acc || out), "pita_egnn_jvp: null argument");
   PITA_REQUIRE(beta || net->cfg.in_node_nf == 1, "pita_egnn_jvp: beta required for in_node_nf=2");
   const int D = net->cfg.n_particles * net->cfg.n_dim;

@@ -423,6 +423,24 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) egnn_kernel(EgnnParams p) {
           } else {
             philox_normal4(p.seed, p.walker_offset + (unsigned long long)wid[T], p.step0 + step, (uint32_t)nodei[T], xi);
           }
+          // whose launch owns this column's moments of this step: decided per COLUMN (all DIM components together), so the
+          // f16 launch and the repair launch partition the moments exactly even when the components of one particle
+          // differ in finiteness at the step where an overflow first shows
+          bool take_col = true;
+          if (p.stats_out && valid[T] && hh == 0) {
+            if (PREC == 2) {  // leave non-finite values to the repair launch and remember from which step on
+#pragma unroll
+              for (int k = 0; k < DIM; ++k) {
+                const float xc = xbuf[col[T] * DIM + k];
+                const float Dth = c_s[T] * xc + c_out[T] * F[T][k];
+                take_col = take_col && __builtin_isfinite(gamma * (((Dth - xc) / hval[T]) * g2));
+              }
+              take_col = take_col && bad_from[T] == 0x7fffffff;  // once owed, always owed (the walker is recomputed)
+              if (!take_col && bad_from[T] == 0x7fffffff) bad_from[T] = step;
+            } else if (p.repair) {
+              take_col = step >= bad_from[T];
+            }
+          }
 #pragma unroll
           for (int k = 0; k < DIM; ++k) {
             const float xc = xbuf[col[T] * DIM + k];
@@ -433,13 +451,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) egnn_kernel(EgnnParams p) {
               p.drift_out[(walker0 * N + col[T]) * DIM + k] = drift;
             const float dif = noise_scale * xi[k];  // sdes.py:250
             if (p.stats_out && valid[T] && hh == 0) {
-              bool take = true;
-              if (PREC == 2) {  // leave non-finite values to the repair launch and remember from which step on
-                take = __builtin_isfinite(drift);
-                if (!take && bad_from[T] == 0x7fffffff) bad_from[T] = step;
-              } else if (p.repair) {
-                take = step >= bad_from[T];
-              }
+              const bool take = take_col;
               if (take) {
                 st_d += drift; st_d2 = fmaf(drift, drift, st_d2);
                 st_n += dif; st_n2 = fmaf(dif, dif, st_n2);
@@ -765,8 +777,10 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
   }
   int dev = 0;
   hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-    net->n_cu = prop.multiProcessorCount;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    net->device = dev;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) net->n_cu = prop.multiProcessorCount;
+  }
   // opt in to the LDS the kernel needs (static limit is 64 KiB)
   size_t lds = shape->lds_bytes(L);
   hipError_t e3 = hipSuccess;
@@ -788,6 +802,7 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
 
 extern "C" int pita_egnn_destroy(pita_egnn_t* net) {
   if (!net) return PITA_OK;
+  PitaDeviceGuard guard(net->device);
   (void)hipFree(net->d_mats);
   (void)hipFree(net->d_vecs);
   (void)hipFree(net->d_mats16);
@@ -813,6 +828,7 @@ static const EgnnShape* shape_for(const pita_egnn_t* net, long long B) {
 }
 
 static int egnn_launch(pita_egnn_t* net, EgnnParams& p, void* stream) {
+  PitaDeviceGuard guard(net->device);
   const EgnnShape* s = shape_for(net, p.B);
   const int prec = net->cfg.precision;
   p.mats = net->d_mats;

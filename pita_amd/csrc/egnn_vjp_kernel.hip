@@ -565,6 +565,7 @@ extern "C" int pita_egnn_vjp(pita_egnn_t* net, const float* h, const float* x, c
                              float* out, float* vjp, float* dot_h, int64_t B, void* stream) {
   PITA_REQUIRE(net && B >= 0, "pita_egnn_vjp: bad argument");
   if (B == 0) return PITA_OK;
+  PitaDeviceGuard guard(net->device);
   PITA_REQUIRE(h && x && vjp, "pita_egnn_vjp: null argument");
   PITA_REQUIRE(beta || net->cfg.in_node_nf == 1, "pita_egnn_vjp: beta required for in_node_nf=2");
   const VjpShape* s = nullptr;
