@@ -296,7 +296,7 @@ def force_roofline(pita_amd, cfg, energy, x, dev, reps):
     # kernel of this config is the one launched most often under that name in the profiled bench run
     pm = pmc_summary()
     ks = (pm or {}).get(f"force_{cfg['name']}_kernels", {})
-    pat = {"lj": "lj13_kernel<2" if n == 13 else "pair", "dw": "pair", "ff": "ff_"}[cfg["target"]]
+    pat = {"lj": "lj13_kernel<2" if n == 13 else "ring_energy", "dw": "ring_energy", "ff": "ff_"}[cfg["target"]]
     ks = {k: v for k, v in ks.items() if pat in k}
     out["traffic"] = None
     if ks and B == cfg["walkers"]:

@@ -66,6 +66,10 @@ struct EgnnParams {
   int* bad_from;          // mode 3 with stats_out: [B*N] first step whose moments the f16 launch left out (INT_MAX: none)
 };
 
+#ifndef PITA_EGNN_RECOMPUTE_COLS
+#define PITA_EGNN_RECOMPUTE_COLS 1
+#endif
+
 template <int N, int DIM, int G, int WAVES>
 struct EgnnCfg {
   static constexpr int NCOL = G * N;
@@ -185,6 +189,27 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) egnn_kernel(EgnnParams p) {
 
     const int nsteps = (mode == 3) ? p.n_steps : 1;
     for (int step = 0; step < nsteps; ++step) {
+#if PITA_EGNN_RECOMPUTE_COLS
+      // the per-column bookkeeping is recomputed from the (opaque) lane id at every step instead of being carried
+      // across the step loop: carried, the register allocator spills it once per walker group (~25 dwords per lane,
+      // the bulk of the kernel's HBM writes); recomputed it costs ~30 instructions per wave and step
+      int col[NT], nodei[NT];
+      bool valid[NT];
+      long long wid[NT];
+      {
+        int cl_o = cl;
+        asm volatile("" : "+v"(cl_o));
+#pragma unroll
+        for (int T = 0; T < NT; ++T) {
+          col[T] = T * 32 + cl_o;
+          const int w = col[T] / N;
+          nodei[T] = col[T] - w * N;
+          wid[T] = walker0 + w;
+          valid[T] = (col[T] < ncol);
+          if (!valid[T]) wid[T] = p.B - 1;
+        }
+      }
+#endif
       // ---- per-column scalars of this evaluation
       float c_s[NT], c_in[NT], c_out[NT], tfeat[NT], hval[NT], bfeat[NT];
       float g2 = 0.f, gamma = 0.f, dt = 0.f, noise_scale = 0.f, sqrt_dt = 0.f;

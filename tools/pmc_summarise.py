@@ -29,7 +29,8 @@ def load(dirs):
         for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             with open(path) as f:
                 for row in csv.DictReader(f):
-                    acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+                    name = row["Kernel_Name"].replace("(anonymous namespace)::", "")
+                    acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
     return acc
 
 
