@@ -309,16 +309,32 @@ def force_roofline(pita_amd, cfg, energy, x, dev, reps):
                     "frac": tf / PEAK_F32_VALU_TFLOPS, "hbm_GBs_for_information": gbs,
                     "algorithmic_flop_per_walker_eval": flop})
         out.pop("frac_of_measured_achievable_6300")
-    if cfg["target"] == "lj" and n == 13:
+    if cfg["target"] in ("lj", "dw"):  # the kernel itself: C-ABI calls on preallocated outputs
         L = pita_amd._lib.lib()
         sp = pita_amd._lib.stream_ptr(dev)
         lp, fo = torch.empty(B, device=dev), torch.empty_like(x)
-        us_raw = timed(lambda: L.pita_lj_logp_force(x.data_ptr(), lp.data_ptr(), fo.data_ptr(), B, 13, 3, 1.0, 1.0, 1e-6,
-                                                    1.0, 1.0, 1.0, sp), reps)
+        if cfg["target"] == "lj":
+            raw = lambda: L.pita_lj_logp_force(x.data_ptr(), lp.data_ptr(), fo.data_ptr(), B, n, d, 1.0, 1.0, 1e-6, 1.0, 1.0, 1.0, sp)
+        else:
+            raw = lambda: L.pita_dw_logp_force(x.data_ptr(), lp.data_ptr(), fo.data_ptr(), B, n, d, 1.0, energy.a, energy.b,
+                                               energy.c, energy.offset, sp)
+        us_raw = timed(raw, reps)
         gbs_raw = B * nbytes / (us_raw * 1e-6) / 1e9
-        out.update({"us_per_launch": us_raw, "achieved": gbs_raw, "frac": gbs_raw / PEAK_HBM_GBS,
-                    "frac_of_measured_achievable_6300": gbs_raw / ACHIEVABLE_HBM_GBS,
-                    "walker_evals_per_s": B / (us_raw * 1e-6), "note": "C-ABI calls on preallocated outputs"})
+        out.update({"us_per_launch": us_raw, "walker_evals_per_s": B / (us_raw * 1e-6), "hbm_GBs_for_information": gbs_raw,
+                    "us_per_launch_through_plugin_class": us, "note": "C-ABI calls on preallocated outputs"})
+        if out["bound"] == "hbm":
+            out.update({"achieved": gbs_raw, "frac": gbs_raw / PEAK_HBM_GBS,
+                        "frac_of_measured_achievable_6300": gbs_raw / ACHIEVABLE_HBM_GBS})
+        else:
+            tf = B * out["algorithmic_flop_per_walker_eval"] / (us_raw * 1e-6) / 1e12
+            out.update({"achieved": tf, "frac": tf / PEAK_F32_VALU_TFLOPS,
+                        "frac_of_plain_fma_rate_78.6": tf / (PEAK_F32_VALU_TFLOPS / 2),
+                        "note": "C-ABI calls on preallocated outputs.  peak = 157.3 TFLOP/s counts packed FMAs at full "
+                                "rate; they issue at half rate on this chip (tools/ubench/isa_rates.hip; a packed pair loop "
+                                "measured slower, DESIGN.md 4.2), so the plain-FMA rate is given beside it"})
+    if cfg["target"] == "lj" and n == 13:
+        L = pita_amd._lib.lib()
+        sp = pita_amd._lib.stream_ptr(dev)
         BIG = 1 << 21
         xbig = x.repeat(BIG // B + 1, 1)[:BIG].contiguous()
         lpb, fob = torch.empty(BIG, device=dev), torch.empty_like(xbig)
