@@ -1892,7 +1892,7 @@ static const DivTanShape kDivTan[] = {
 // wave-owned kernels for the systems above that default to the block-shared one (networks deeper than its LDS budget
 // is sized for; PITA_DIV_TAN_ALT=1 selects them for A/B runs), then experiments (PITA_DIV_TAN_ALT=<index + 1>)
 static const DivTanShape kDivTanAlt[] = {PITA_DIVTAN_SHAPE(13, 3, 2, 4, 4), PITA_DIVTAN_SHAPE(22, 3, 1, 4, 4),
-                                         PITA_DIVSHR_SHAPE(13, 3, 2, 12, 1), PITA_DIVSHR_SHAPE(55, 3, 1, 4, 2)};
+                                         PITA_DIVSHR_SHAPE(13, 3, 2, 12, 1)};
 static const DivTanShape* find_div_tan_shape(int n, int dim, int n_layers) {
   static const bool off = getenv("PITA_DIV_NOCACHE") != nullptr;  // development aid: A/B against the cache-free path
   if (off) return nullptr;

@@ -8,10 +8,11 @@
 * Debiased Feynman-Kac regime (sdes.py:151-239): drift_X = -gamma grad_x E_theta g^2/2 + gamma s_theta g^2/2 and the
   log-weight drift  gamma^2 <-grad E, b> + gamma div b + gamma dE/dt + gamma'(t) E, clamped at its 0.9 quantile.
   The reference obtains grad_x E (autograd), div s (vmap(jacrev)) and dE/dt (autograd through h(t)); here they are
-  assembled from derivatives of the two denoisers computed by HIP kernels: one reverse-mode launch (pita_egnn_vjp,
-  csrc/egnn_vjp_kernel.hip) + one forward-mode launch in the h direction (pita_egnn_jvp, csrc/egnn_jvp_kernel.hip)
-  for the energy net, and dim / K launches of the K-direction divergence kernel (pita_egnn_div_accumulate,
-  csrc/egnn_div_kernel.hip) for the exact divergence of the score net, per step.
+  assembled (pita_fk_assemble, csrc/fk_kernels.hip) from derivatives of the two denoisers computed by HIP kernels:
+  ONE reverse-mode launch on the energy net (pita_egnn_vjp, csrc/egnn_vjp_kernel.hip) that returns J_x D^T x and
+  <x, dD/dh> from the same sweep, and the exact trace of the score net's Jacobian (pita_egnn_jacobian_trace,
+  csrc/egnn_div_kernel.hip: one launch with the primal that writes the primal cache, tangent-only launches that stream
+  it), per step; the clamp is pita_quantile_clamp per inference chunk.
 """
 from dataclasses import dataclass
 from typing import Optional
