@@ -142,6 +142,58 @@ def test_lj13_large_batch_streaming_kernel(pa, monkeypatch):
     assert rel(f[idx.cuda()], f_o) < 2e-5
 
 
+@pytest.mark.parametrize("name", ["lj55", "dw4"])
+def test_ring_kernels_edge_cases(pa, name):
+    """Ring kernels (compile-time particle count, lane = particle): empty batch, one walker, batches that leave the last
+    wave group ragged (DW4: 16 walkers per wave), determinism, translation invariance of the pair part, zero net force,
+    the energy_factor / temperature / (LJ) non-unit rm variants against the oracle, and a walker with a non-finite
+    coordinate that must not disturb its neighbours in the same wave."""
+    gen = torch.Generator().manual_seed(21)
+    if name == "lj55":
+        n, d = 55, 3
+        mk = lambda **kw: pa.LennardJonesEnergy(165, 55, 3, **kw)
+        orc = lambda x, T=1.0, ef=1.0: O.lj_logp_force(x, 55, 3, temperature=T, energy_factor=ef)
+        base = torch.randn(1, 165, generator=gen) * 0.9 + torch.linspace(-2.5, 2.5, 165)[None]
+    else:
+        n, d = 4, 2
+        mk = lambda **kw: pa.MultiDoubleWellEnergy(**kw)
+        orc = lambda x, T=1.0, ef=1.0: O.dw4_logp_force(x, temperature=T)
+        base = torch.tensor([[2.0, 2.0, -2.0, 2.0, -2.0, -2.0, 2.0, -2.0]])
+    D = n * d
+    e = mk()
+    lp, f = e(torch.empty(0, D).cuda(), return_force=True)
+    assert lp.shape == (0,) and f.shape == (0, D)
+    for B in (1, 2, 15, 16, 17, 63, 65, 1000):
+        x = base + 0.25 * torch.randn(B, D, generator=gen)
+        lp, f = e(x.cuda(), return_force=True)
+        lp2, f2 = e(x.cuda(), return_force=True)
+        assert torch.equal(lp, lp2) and torch.equal(f, f2) and torch.equal(e(x.cuda()), lp)
+        lpo, fo = orc(x.double())
+        np.testing.assert_allclose(lp.cpu().numpy(), lpo.numpy(), rtol=2e-5, atol=2e-5)
+        assert rel(f, fo) < 2e-5
+        # a walker's value does not depend on where it sits in the batch / wave group
+        if B > 2:
+            lp3, f3 = e(x[1:].contiguous().cuda(), return_force=True)
+            assert torch.equal(lp3, lp[1:]) and torch.equal(f3, f[1:])
+        fsum = f.reshape(B, n, d).sum(1).abs().max().item()
+        if name == "dw4":
+            assert fsum < 1e-4 * max(1.0, f.abs().max().item())  # pair forces cancel exactly up to rounding
+    x = (base + 0.2 * torch.randn(40, D, generator=gen)).cuda()
+    for T, ef in ((2.5, 1.0), (0.7, 0.5)):
+        kw = dict(temperature=T) if name == "dw4" else dict(temperature=T, energy_factor=ef)
+        lp, f = mk(**kw)(x, return_force=True)
+        lpo, fo = orc(x.cpu().double(), T, ef)
+        np.testing.assert_allclose(lp.cpu().numpy(), lpo.numpy(), rtol=2e-5, atol=2e-5)
+        assert rel(f, fo) < 2e-5
+    xb = x.clone()
+    xb[17, 3] = float("nan")
+    lpb, fb = e(xb, return_force=True)
+    lp, f = e(x, return_force=True)
+    keep = torch.ones(40, dtype=torch.bool, device="cuda")
+    keep[17] = False
+    assert torch.equal(lpb[keep], lp[keep]) and torch.equal(fb[keep], f[keep]) and not torch.isfinite(lpb[17])
+
+
 def test_dw4_vs_oracle(pa):
     gen = torch.Generator().manual_seed(4)
     x = torch.randn(513, 8, generator=gen) * 2.5

@@ -88,3 +88,40 @@ def test_alp_energy_facade_and_system_xml_fixture():
         ALPEnergy(data_path="x", pdb_filename="A_capped.pdb", dimensionality=66, n_particles=22)  # no OpenMM here
     with np.testing.assert_raises(ValueError):
         ALPEnergy(data_path="x", pdb_filename="y", dimensionality=99, n_particles=33, system_xml=path)
+
+
+def test_committed_bench_lines_follow_survey_8d():
+    """The committed round-3 bench lines (profiles/r03_bench_<config>.json) can be recomputed from their own fields by
+    SURVEY 8(d)'s formulas: roofline.achieved = algorithmic flops per launch / launch time, frac = achieved / peak,
+    value = walkers x steps / (steps x ms_per_step), PMC traffic >= algorithmic bytes; and the rocprofv3 kernel-stats
+    summary of the same command (profiles/r03_kernel_stats_<config>.csv) agrees with the HIP-event launch time."""
+    import csv
+    import json
+    import os
+
+    prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    alg = {"lj13": 4196608.0, "dw4": None, "aldp22": None, "lj55": None}  # LJ13: 2 098 304 MAC x 2 (SURVEY 8(d))
+    for cfg in ("lj13", "dw4", "aldp22", "lj55"):
+        path = os.path.join(prof, f"r03_bench_{cfg}.json")
+        line = json.loads([ln for ln in open(path) if ln.startswith("{")][-1])
+        r = line["roofline"]
+        B, c = line["config"]["walkers_per_gpu"], r["steps_per_launch"]
+        if alg[cfg] is not None:
+            assert abs(r["algorithmic_flop_per_walker_step"] - alg[cfg]) < 1
+        want = r["algorithmic_flop_per_walker_step"] * B * c / (r["ms_per_launch"] * 1e-3) / 1e12
+        assert abs(r["achieved"] - want) < 1e-6 * want and r["peak"] == 2500.0 and r["unit"] == "TFLOP/s"
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] <= r["frac_executed"] <= 1
+        assert abs(line["value"] - line["n_gpus"] * B * line["steps"] / (line["ms_per_step"] * line["steps"] * 1e-3)) < 1e-6 * line["value"]
+        assert line["unit"] == "walker-steps/s" and line["higher_is_better"] and line["scaling"] == "weak"
+        if r["traffic"] is not None:
+            assert r["traffic"] >= r["algorithmic_bytes_per_launch"] == 2 * B * line["config"]["walkers_per_gpu"] // B * 0 + r["algorithmic_bytes_per_launch"]
+        cb = line["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+        # rocprofv3 --kernel-trace --stats of the same command (200 + 100 steps in 100-step launches)
+        rows = list(csv.DictReader(open(os.path.join(prof, f"r03_kernel_stats_{cfg}.csv"))))
+        samp = [x for x in rows if "egnn_kernel" in x["Name"] and ", 2, true," in x["Name"]]
+        assert samp, cfg
+        avg_ms = float(max(samp, key=lambda x: float(x["TotalDurationNs"]))["AverageNs"]) * 1e-6
+        under = json.loads([ln for ln in open(os.path.join(prof, f"r03_bench_under_rocprof_{cfg}.json")) if ln.startswith("{")][-1])
+        ev_ms = under["roofline"]["ms_per_launch"]
+        assert abs(avg_ms - ev_ms) < 0.03 * ev_ms, (cfg, avg_ms, ev_ms)
