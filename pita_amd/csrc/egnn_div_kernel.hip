@@ -2089,7 +2089,20 @@ extern "C" int pita_egnn_jacobian_trace(pita_egnn_t* net, const float* h, const 
     return PITA_OK;
   }
   // walkers per chunk: the cache of a chunk must fit the budget
-  static const double budget_gb = getenv("PITA_DIV_CACHE_GB") ? atof(getenv("PITA_DIV_CACHE_GB")) : 24.0;
+  // budget of the primal cache: PITA_DIV_CACHE_GB, else 24 GB but never more than 60 % of what the device has free
+  // right now plus what this handle already holds (other handles, the caller's tensors and a second process keep theirs)
+  double budget_gb = 24.0;
+  if (getenv("PITA_DIV_CACHE_GB")) {
+    budget_gb = atof(getenv("PITA_DIV_CACHE_GB"));
+  } else {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      const double avail = 0.6 * ((double)free_b + (double)net->divcache_bytes) / 1e9;
+      if (avail < budget_gb) budget_gb = avail;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
   const double per_walker = 4.0 * (double)ts->group_f(L) / s->G;
   long long chunk = (long long)(budget_gb * 1e9 / per_walker);
   chunk = chunk / 1024 * 1024;
