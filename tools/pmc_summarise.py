@@ -90,8 +90,10 @@ def main():
                 m2 = lambda c: sum(a2[k][c]) / len(a2[k][c])
                 t2 = (2.0 * m2("FETCH_SIZE") + m2("WRITE_SIZE")) * 1024
                 per = (t1 - t2) / (walkers * (chunk - c2))
+                if per < 0.0:  # no growth with the launch length within the counters' noise: all of it is per launch
+                    per = 0.0
                 e["bytes_per_walker_step"] = per
-                e["fixed_bytes_per_launch"] = t1 - per * ws
+                e["fixed_bytes_per_launch"] = max(t1, t2) if per == 0.0 else t1 - per * ws
                 e["fit_from"] = {f"{chunk}_steps_per_launch": t1, f"{c2}_steps_per_launch": t2}
         res[f"sampler_{config}"] = e
     force = [k for k in acc if any(t in k for t in ("lj13_kernel", "pair_energy_kernel", "pair_energy_n3l_kernel", "ring_energy_kernel",
