@@ -772,6 +772,19 @@ def test_fused_ring_mala_equals_per_step(pa, name, B, steps, dt, adaptive):
             assert torch.isfinite(outs[0][0]).all()
             if B >= 100:
                 assert 0.0 < max(outs[0][1]) and min(outs[0][1]) < 1.0, outs[0][1]  # a chain that accepts and rejects
+    if B in (301, 1000):  # a non-finite walker in the middle is set aside: Philox keys follow the ORIGINAL indices
+        xb = x0.clone()
+        xb[B // 3, 1] = float("inf")
+        outs = []
+        for fused in (True, False):
+            integ = pa.WeightedSDEIntegrator(sde=None, num_integration_steps=1, start_resampling_step=0,
+                                             end_resampling_step=1, post_mcmc_steps=steps, dt_negative_time=dt,
+                                             adaptive_mcmc=adaptive, seed=9)
+            fn = integ.metropolis_hastings_mala_adaptive if adaptive else integ.metropolis_hastings_mala
+            akw = dict(dt_init=dt) if adaptive else {}
+            outs.append(fn(xb.clone(), e, return_acceptance_rate=True, fused=fused, **akw))
+        assert torch.equal(outs[0][0][:-1], outs[1][0][:-1]) and outs[0][1] == outs[1][1]
+        assert integ._last_mala_valid == B - 1 and torch.isinf(outs[0][0][-1, 1]) and torch.isinf(outs[1][0][-1, 1])
     # the chain follows the oracle's MALA step (fp32 rounding may flip an accept decision whose log-ratio is within 1e-5)
     if B <= 1000:
         steps_o = 2
