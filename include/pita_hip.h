@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PITA_ABI_VERSION 3
+#define PITA_ABI_VERSION 4
 
 enum {
   PITA_OK = 0,
@@ -117,6 +117,29 @@ int pita_dw_mala(float* x, float* logp, const float* noise /*nullable*/, const f
                  double* dt_dev, int adaptive, int64_t total, uint64_t seed, uint64_t walker_offset,
                  const int64_t* walker_ids /*nullable*/, int64_t step0, int remove_mean, float* rates_out /*nullable*/,
                  void* workspace, void* stream);
+
+/* ---------------------------------------------------------------- wide EGNN backbone (hidden_nf <= 64, static node features)
+ * replaces EGNN_dynamics_AD2_cat.forward (pita/src/models/components/egnn_dynamics_ad2_cat.py:157-203; the
+ * alanine-dipeptide backbone of configs/model/net/egnn_dynamics_ad2_cat.yaml: hidden 64 x 5 layers, one-hot atom-type
+ * node features concatenated with t and beta) over EGNN / E_GCL of egnn.py:108-346, and ScoreNet's EDM preconditioning
+ * (score_net.py:13-43).  Vector-pipe kernel (lane = hidden feature), fp32 FMA chains: csrc/egnn_wide_kernel.hip.
+ * weights: the module's state_dict flattened in registration order (embedding, embedding_out, gcl_0 .. gcl_{L-1}, like
+ * pita_egnn_create); h_initial: host [n_particles, n_static] static node features (the reference's get_h_initial()). */
+typedef struct pita_egnn_wide pita_egnn_wide_t;
+typedef struct {
+  int n_particles, n_dim, hidden_nf, n_layers;
+  int n_static;       /* static features per node; in_node_nf = n_static + 1 (t) + condition_beta */
+  int condition_beta;
+  int attention, tanh;
+  float coords_range; /* 15.0 in the reference; per-layer range = coords_range / n_layers */
+} pita_egnn_wide_config;
+int64_t pita_egnn_wide_num_weights(const pita_egnn_wide_config* cfg);
+int pita_egnn_wide_create(pita_egnn_wide_t** out, const pita_egnn_wide_config* cfg, const float* weights,
+                          int64_t n_weights, const float* h_initial /* host; nullable when n_static == 0 */);
+int pita_egnn_wide_destroy(pita_egnn_wide_t* net);
+/* what = 0: vel[B, n*d] = backbone(t[B], x[B, n*d], beta[B]) (mean-free); 1: denoiser D_theta(h = t, x); 2: score */
+int pita_egnn_wide_eval(pita_egnn_wide_t* net, int what, const float* t, const float* x, const float* beta /*nullable*/,
+                        float* out, int64_t B, void* stream);
 
 /* Diagonal Gaussian mixture with equal weights.
  * replaces GMM.__call__ (pita/src/energies/gmm_energy.py:87-90) ->

@@ -376,7 +376,7 @@ def _silu(v: Tensor) -> Tensor:
 
 def egnn_forward(p: Dict[str, Tensor], t: Tensor, x: Tensor, beta: Optional[Tensor], n: int, d: int,
                  n_layers: int = 3, coords_range: float = 15.0, tanh: bool = True, attention: bool = True,
-                 return_h0: bool = False, feature_layout: str = "pita"):
+                 return_h0: bool = False, feature_layout: str = "pita", h0: Optional[Tensor] = None):
     """EGNN_dynamics.forward: velocity ``x_final - x`` made mean-free.
 
     ``p`` is the reference ``state_dict`` (keys ``egnn.embedding.weight`` ...).  Materialises
@@ -393,7 +393,8 @@ def egnn_forward(p: Dict[str, Tensor], t: Tensor, x: Tensor, beta: Optional[Tens
     col = (col1[None] + off).reshape(-1)
     pos = x.reshape(B * n, d).clone()
     pos0 = pos
-    h = egnn_node_features(t, beta, n, feature_layout)
+    # h0: node features given by the caller (EGNN_dynamics_AD2_cat: [static one-hot rows, t, beta], see egnn_ad2_cat_features)
+    h = egnn_node_features(t, beta, n, feature_layout) if h0 is None else h0.to(dt)
     h0 = h
     edge_attr = ((pos[row] - pos[col]) ** 2).sum(dim=1, keepdim=True)  # :79 (frozen, quirk Q10)
     h = h @ P["egnn.embedding.weight"].T + P["egnn.embedding.bias"]  # :179
@@ -425,6 +426,34 @@ def egnn_forward(p: Dict[str, Tensor], t: Tensor, x: Tensor, beta: Optional[Tens
     if return_h0:
         return vel, h0
     return vel
+
+
+def egnn_ad2_cat_h_initial(n: int) -> Tensor:
+    """Static node features of EGNN_dynamics_AD2_cat.get_h_initial (egnn_dynamics_ad2_cat.py:66-92) for the particle
+    counts that need no topology file: one-hot atom types with the methyl hydrogens merged."""
+    groups = {22: [([0, 2, 3], 2), ([19, 20, 21], 20), ([11, 12, 13], 12)],
+              33: [([1, 2, 3], 2), ([9, 10, 11], 10), ([19, 20, 21], 18), ([29, 30, 31], 31)],
+              42: [([1, 2, 3], 2), ([11, 12, 13], 12), ([21, 22, 23], 22), ([31, 32, 33], 32), ([39, 40, 41], 40)]}
+    if n in (13, 55):
+        return torch.zeros(n, 1)
+    at = np.arange(n)
+    for idx, v in groups[n]:
+        at[idx] = v
+    return torch.nn.functional.one_hot(torch.tensor(at)).to(torch.float32)
+
+
+def egnn_ad2_cat_forward(p: Dict[str, Tensor], t: Tensor, x: Tensor, beta: Optional[Tensor], n: int, d: int,
+                         n_layers: int = 5, tanh: bool = True, attention: bool = True,
+                         h_initial: Optional[Tensor] = None) -> Tensor:
+    """EGNN_dynamics_AD2_cat.forward (egnn_dynamics_ad2_cat.py:157-203): node features [h_initial, t(, beta)] per node,
+    then the same EGNN / E_GCL stack as ``egnn_forward`` (egnn.py and egnn_temp_conditioned.py share the layer)."""
+    B = x.shape[0]
+    hi = (egnn_ad2_cat_h_initial(n) if h_initial is None else h_initial).to(x.dtype)
+    cols = [hi[None].expand(B, n, hi.shape[1]), t.to(x.dtype)[:, None, None].expand(B, n, 1)]
+    if beta is not None:
+        cols.append(beta.to(x.dtype)[:, None, None].expand(B, n, 1))
+    h0 = torch.cat(cols, dim=-1).reshape(B * n, -1)
+    return egnn_forward(p, t, x, beta, n, d, n_layers=n_layers, tanh=tanh, attention=attention, h0=h0)
 
 
 # --------------------------------------------------------------------------------------

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpita_hip.so")
 
 STEP_STRIDE = 16
-ABI_VERSION = 3
+ABI_VERSION = 4
 ST_CS, ST_CIN, ST_COUT, ST_CNOISE, ST_H, ST_G2, ST_GAMMA, ST_DT, ST_NOISE_SCALE, ST_SQRT_DT, ST_BETA = range(11)
 
 
@@ -25,6 +25,12 @@ class EgnnConfig(ctypes.Structure):
     _fields_ = [("n_particles", c_int), ("n_dim", c_int), ("hidden_nf", c_int), ("n_layers", c_int),
                 ("in_node_nf", c_int), ("attention", c_int), ("tanh", c_int), ("coords_range", c_float),
                 ("feature_layout", c_int), ("precision", c_int)]
+
+
+class EgnnWideConfig(ctypes.Structure):
+    _fields_ = [("n_particles", c_int), ("n_dim", c_int), ("hidden_nf", c_int), ("n_layers", c_int),
+                ("n_static", c_int), ("condition_beta", c_int), ("attention", c_int), ("tanh", c_int),
+                ("coords_range", c_float)]
 
 
 class FfConfig(ctypes.Structure):
@@ -74,6 +80,10 @@ _PROTOS = {
     "pita_egnn_create": (c_int, [POINTER(c_void_p), POINTER(EgnnConfig), c_void_p, c_int64]),
     "pita_egnn_destroy": (c_int, [c_void_p]),
     "pita_egnn_num_weights": (c_int64, [POINTER(EgnnConfig)]),
+    "pita_egnn_wide_num_weights": (c_int64, [POINTER(EgnnWideConfig)]),
+    "pita_egnn_wide_create": (c_int, [POINTER(c_void_p), POINTER(EgnnWideConfig), c_void_p, c_int64, c_void_p]),
+    "pita_egnn_wide_destroy": (c_int, [c_void_p]),
+    "pita_egnn_wide_eval": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "pita_egnn_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "pita_egnn_edm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "pita_egnn_jvp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

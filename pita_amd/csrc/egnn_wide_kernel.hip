@@ -1,0 +1,360 @@
+// EGNN backbone with hidden_nf up to 64 and static per-node input features, for gfx950 (MI355X).
+//
+// Replaces (paths relative to /root/reference/pita/src/models/components/):
+//   egnn_dynamics_ad2_cat.py:11-203   EGNN_dynamics_AD2_cat (the alanine-dipeptide backbone of
+//                                     configs/model/net/egnn_dynamics_ad2_cat.yaml: hidden 64 x 5 layers, one-hot atom-type
+//                                     node features concatenated with t and beta)
+//   egnn.py:108-184, 187-346          EGNN.forward, E_GCL (edge_model, coord_model, node_model, coord2radial; the same
+//                                     layer as egnn_temp_conditioned.py)
+//   score_net.py:13-43                EDM preconditioning (modes 1, 2)
+//
+// Why a second EGNN kernel: egnn_kernel.hip ties the hidden width to the 32 x 32 MFMA tile (lane = column x 16 of 32
+// features).  This one trades speed for generality -- any hidden_nf <= 64, any number of static node features -- with
+// the plainest possible mapping: ONE wavefront = one walker, LANE = hidden feature.  A dense layer y = W v is
+//     y_f = b_f + sum_k W[f][k] v_k      lane f, k = 0 .. H-1:  v_k by v_readlane_b32 (lane k holds v_k), W[f][.] in registers
+// i.e. 2 vector instructions per k; an edge costs two such layers (W2, coord head) + three SiLUs + two wave reductions
+// (attention gate, coordinate scalar: DPP trees), ~300 instructions; the per-node layers (Wa, Wb, node MLP) read their
+// transposed weight rows from the L2.  fp32 FMA chains throughout (no reduced-precision operands).  Edges are swept
+// i-major, j ascending: the reference's index_add order, so per-node sums accumulate in the same order.
+// Throughput is that of the vector pipe (~8e5 walker-forwards/s for 22 atoms, 64 x 5): the LJ / DW4 configurations
+// stay on the MFMA kernel.
+#include "common.h"
+
+struct pita_egnn_wide {
+  pita_egnn_wide_config cfg;
+  float* d_w = nullptr;        // packed weights, see WideLayer
+  float* d_estatic = nullptr;  // [n][64] embedding of the static node features + embedding bias
+  int device = -1;
+  int n_cu = 256;
+};
+
+namespace pita {
+
+constexpr int WIDE_HP = 64;  // lanes of a wave = padded hidden width
+
+// per-layer block of the packed weights (floats); matrices are stored TRANSPOSED, [k][64]: lane f reads W[f][k] at k*64+f
+struct WideLayer {
+  static constexpr int MAT = WIDE_HP * WIDE_HP;
+  static constexpr int WA = 0, WB = MAT, W2 = 2 * MAT, WC1 = 3 * MAT, WN1A = 4 * MAT, WN1B = 5 * MAT, WN2 = 6 * MAT;
+  static constexpr int VEC = 7 * MAT;  // then vectors of 64: wr, we, b1, b2, watt, batt (lane 0), bc1, wc2, bn1, bn2
+  static constexpr int WR = VEC, WE = VEC + 64, B1 = VEC + 128, B2 = VEC + 192, WATT = VEC + 256, BATT = VEC + 320,
+                       BC1 = VEC + 384, WC2 = VEC + 448, BN1 = VEC + 512, BN2 = VEC + 576;
+  static constexpr int SIZE = VEC + 640;
+};
+constexpr int WIDE_HEAD = 128;  // emb_t[64], emb_beta[64] in front of the layers
+
+struct WideParams {
+  const float* w;
+  const float* estatic;
+  int n, dim, H, L, attention, tanh_on, has_beta;
+  float coord_scale;
+  long long B;
+  int mode;  // 0 backbone forward (t = its time input), 1 denoiser, 2 score (t = h = sigma^2)
+  const float* x;
+  const float* t;
+  const float* beta;
+  float* out;
+};
+
+namespace {
+
+template <int CTRL>
+__device__ __forceinline__ float wdpp_add(float v) {
+  const int m = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false);
+  return v + __builtin_bit_cast(float, m);
+}
+// sum over the 64 lanes, fixed tree order, returned to every lane
+__device__ __forceinline__ float wwave_sum(float v) {
+  v = wdpp_add<0xb1>(v);
+  v = wdpp_add<0x4e>(v);
+  v = wdpp_add<0x124>(v);
+  v = wdpp_add<0x128>(v);
+  v = wdpp_add<0x142>(v);
+  v = wdpp_add<0x143>(v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wlane(float v, int k) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
+}
+__device__ __forceinline__ float wsilu(float z) { return z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * z)); }
+__device__ __forceinline__ void wfence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// y_f = acc_f + sum_k row[k] v_k  with the weight row of this lane in registers
+template <int HK>
+__device__ __forceinline__ float dense_reg(const float (&row)[WIDE_HP], float v, float acc) {
+#pragma unroll
+  for (int k = 0; k < HK; ++k) acc = fmaf(row[k], wlane(v, k), acc);
+  return acc;
+}
+// the same with the transposed matrix in memory ([k][64] floats)
+template <int HK>
+__device__ __forceinline__ float dense_mem(const float* __restrict__ wt, int lane, float v, float acc) {
+#pragma unroll 8
+  for (int k = 0; k < HK; ++k) acc = fmaf(wt[k * WIDE_HP + lane], wlane(v, k), acc);
+  return acc;
+}
+
+// HK = hidden width rounded up to 32 (the k extent of every dense layer)
+template <int HK>
+__global__ void __launch_bounds__(256) egnn_wide_kernel(WideParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = p.n, DIM = p.dim;
+  const int per_wave = 3 * n * WIDE_HP + 3 * n * 4;
+  float* hf = lds + wave * per_wave;     // [n][64] node features
+  float* At = hf + n * WIDE_HP;          // [n][64] Wa h_i + b1
+  float* Bt = At + n * WIDE_HP;          // [n][64] Wb h_j
+  float* pos = Bt + n * WIDE_HP;         // [n][4] positions entering the layer
+  float* pos0 = pos + n * 4;             // [n][4] input geometry (frozen edge attribute)
+  float* posn = pos0 + n * 4;            // [n][4] positions leaving the layer
+  const long long nw = (long long)gridDim.x * waves;
+  for (long long w = (long long)blockIdx.x * waves + wave; w < p.B; w += nw) {
+    const float tv = p.t[w];
+    const float bet = p.has_beta ? p.beta[w] : 0.f;
+    float c_s = 0.f, c_in = 1.f, c_out = 1.f, tfeat = tv, hval = 1.f;
+    if (p.mode != 0) {  // score_net.py:26-29
+      hval = tv;
+      c_s = 1.0f / (1.0f + tv);
+      c_in = 1.0f / sqrtf(1.0f + tv);
+      c_out = sqrtf(tv) * c_in;
+      tfeat = 0.125f * logf(tv);
+    }
+    // scaled input coordinates
+    for (int q = lane; q < n * DIM; q += 64) {
+      const int i = q / DIM, k = q - i * DIM;
+      const float v = c_in * p.x[w * n * DIM + q];
+      pos[i * 4 + k] = v;
+      pos0[i * 4 + k] = v;
+    }
+    // node features: embedding of [static one-hot features, t, beta] (egnn_dynamics_ad2_cat.py:157-184, egnn.py:179)
+    {
+      const float et = p.w[lane], eb = p.w[64 + lane];
+      for (int i = 0; i < n; ++i) hf[i * WIDE_HP + lane] = fmaf(et, tfeat, fmaf(eb, bet, p.estatic[i * WIDE_HP + lane]));
+    }
+    wfence();
+    for (int l = 0; l < p.L; ++l) {
+      const float* wl = p.w + WIDE_HEAD + (size_t)l * WideLayer::SIZE;
+      // per-node first-layer terms of the edge MLP: W1 [h_i, h_j, r, e] = Wa h_i + Wb h_j + w_r r + w_e e
+      for (int i = 0; i < n; ++i) {
+        const float hv = hf[i * WIDE_HP + lane];
+        At[i * WIDE_HP + lane] = dense_mem<HK>(wl + WideLayer::WA, lane, hv, wl[WideLayer::B1 + lane]);
+        Bt[i * WIDE_HP + lane] = dense_mem<HK>(wl + WideLayer::WB, lane, hv, 0.f);
+      }
+      wfence();
+      float w2[WIDE_HP], wc1[WIDE_HP];
+#pragma unroll
+      for (int k = 0; k < HK; ++k) {
+        w2[k] = wl[WideLayer::W2 + k * WIDE_HP + lane];
+        wc1[k] = wl[WideLayer::WC1 + k * WIDE_HP + lane];
+      }
+      const float wr = wl[WideLayer::WR + lane], we = wl[WideLayer::WE + lane], b2 = wl[WideLayer::B2 + lane];
+      const float watt = wl[WideLayer::WATT + lane], batt = wl[WideLayer::BATT], bc1 = wl[WideLayer::BC1 + lane];
+      const float wc2 = wl[WideLayer::WC2 + lane];
+      const bool last = (l == p.L - 1);
+      for (int i = 0; i < n; ++i) {
+        const float Ai = At[i * WIDE_HP + lane];
+        float pi[3] = {0.f, 0.f, 0.f}, p0i[3] = {0.f, 0.f, 0.f}, xacc[3] = {0.f, 0.f, 0.f};
+        for (int k = 0; k < DIM; ++k) { pi[k] = pos[i * 4 + k]; p0i[k] = pos0[i * 4 + k]; }
+        float agg = 0.f;
+        for (int j = 0; j < n; ++j) {
+          if (j == i) continue;
+          float df[3] = {0.f, 0.f, 0.f}, radial = 0.f, ea = 0.f;
+          for (int k = 0; k < DIM; ++k) {  // coord2radial (egnn.py E_GCL), frozen edge attribute (ad2_cat.py:186)
+            df[k] = pi[k] - pos[j * 4 + k];
+            radial = fmaf(df[k], df[k], radial);
+            const float e0 = p0i[k] - pos0[j * 4 + k];
+            ea = fmaf(e0, e0, ea);
+          }
+          float m = wsilu(fmaf(we, ea, fmaf(wr, radial, Ai + Bt[j * WIDE_HP + lane])));
+          m = wsilu(dense_reg<HK>(w2, m, b2));
+          if (p.attention) m *= fast_sigmoid(wwave_sum(watt * m) + batt);
+          agg += m;
+          const float c1 = wsilu(dense_reg<HK>(wc1, m, bc1));
+          float cs = wwave_sum(wc2 * c1);
+          if (p.tanh_on) cs = accurate_tanh(cs) * p.coord_scale;
+          const float inv = 1.0f / (sqrtf(radial + 1e-8f) + 1.0f);
+          for (int k = 0; k < DIM; ++k) xacc[k] = fmaf(df[k] * inv, cs, xacc[k]);
+        }
+        if (lane < DIM) posn[i * 4 + lane] = pi[lane < 3 ? lane : 0] + xacc[lane < 3 ? lane : 0];
+        if (!last) {  // node model, recurrent (the last layer's node update is dead: h_final is discarded)
+          const float hv = hf[i * WIDE_HP + lane];
+          float z = dense_mem<HK>(wl + WideLayer::WN1A, lane, hv, wl[WideLayer::BN1 + lane]);
+          z = dense_mem<HK>(wl + WideLayer::WN1B, lane, agg, z);
+          const float o = dense_mem<HK>(wl + WideLayer::WN2, lane, wsilu(z), wl[WideLayer::BN2 + lane]);
+          hf[i * WIDE_HP + lane] = hv + o;  // A / B tables of this layer were built from the old features
+        }
+      }
+      wfence();
+      for (int q = lane; q < n * 4; q += 64) pos[q] = posn[q];
+      wfence();
+    }
+    // vel = x_final - x, mean-free over the particles; EDM combination for modes 1, 2
+    float mean[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < DIM; ++k) {
+      float s = 0.f;
+      for (int i = 0; i < n; ++i) s += pos[i * 4 + k] - pos0[i * 4 + k];
+      mean[k] = s / (float)n;
+    }
+    for (int q = lane; q < n * DIM; q += 64) {
+      const int i = q / DIM, k = q - i * DIM;
+      const float F = (pos[i * 4 + k] - pos0[i * 4 + k]) - mean[k];
+      float o = F;
+      if (p.mode != 0) {
+        const float xc = p.x[w * n * DIM + q];
+        o = c_s * xc + c_out * F;
+        if (p.mode == 2) o = (o - xc) / hval;
+      }
+      p.out[w * n * DIM + q] = o;
+    }
+    wfence();
+  }
+}
+
+}  // namespace
+}  // namespace pita
+
+using namespace pita;
+
+extern "C" int64_t pita_egnn_wide_num_weights(const pita_egnn_wide_config* c) {
+  if (!c) return PITA_EINVAL;
+  const int64_t H = c->hidden_nf, nf = c->n_static + 1 + (c->condition_beta ? 1 : 0);
+  int64_t per_layer = (H * (2 * H + 2) + H) + (H * H + H) + (H * 2 * H + H) + (H * H + H) + (H * H + H) + H;
+  if (c->attention) per_layer += H + 1;
+  return (H * nf + H) + (nf * H + nf) + c->n_layers * per_layer;
+}
+
+extern "C" int pita_egnn_wide_create(pita_egnn_wide_t** out, const pita_egnn_wide_config* cfg, const float* w,
+                                     int64_t n_weights, const float* h_initial) {
+  PITA_REQUIRE(out && cfg && w, "pita_egnn_wide_create: null argument");
+  PITA_REQUIRE(cfg->hidden_nf >= 1 && cfg->hidden_nf <= WIDE_HP, "pita_egnn_wide_create: hidden_nf must be in [1, 64]");
+  PITA_REQUIRE(cfg->n_particles >= 2 && cfg->n_particles <= 64 && cfg->n_dim >= 1 && cfg->n_dim <= 3,
+               "pita_egnn_wide_create: n_particles in [2, 64], n_dim in [1, 3]");
+  PITA_REQUIRE(cfg->n_layers >= 1 && cfg->n_layers <= 16 && cfg->n_static >= 0, "pita_egnn_wide_create: bad layer / feature count");
+  PITA_REQUIRE(cfg->n_static == 0 || h_initial, "pita_egnn_wide_create: h_initial missing");
+  PITA_REQUIRE(n_weights == pita_egnn_wide_num_weights(cfg), "pita_egnn_wide_create: got %lld weights, expected %lld",
+               (long long)n_weights, (long long)pita_egnn_wide_num_weights(cfg));
+  const int H = cfg->hidden_nf, L = cfg->n_layers, ns = cfg->n_static, n = cfg->n_particles;
+  const int nf = ns + 1 + (cfg->condition_beta ? 1 : 0);
+  const size_t n_w = WIDE_HEAD + (size_t)L * WideLayer::SIZE;
+  float* hw = new float[n_w]();
+  float* he = new float[(size_t)n * WIDE_HP]();
+  const float* q = w;
+  const float* emb_w = q; q += H * nf;
+  const float* emb_b = q; q += H;
+  q += nf * H + nf;  // embedding_out: dead (h_final is discarded, egnn_dynamics_ad2_cat.py:187)
+  for (int f = 0; f < H; ++f) {
+    hw[f] = emb_w[f * nf + ns];
+    hw[64 + f] = cfg->condition_beta ? emb_w[f * nf + ns + 1] : 0.f;
+    for (int i = 0; i < n; ++i) {
+      double s = emb_b[f];
+      for (int k = 0; k < ns; ++k) s += (double)emb_w[f * nf + k] * (double)h_initial[i * ns + k];
+      he[i * WIDE_HP + f] = (float)s;
+    }
+  }
+  auto put_t = [&](float* dst, const float* M, int ld, int col0) {  // dst[k][f] = M[f][col0 + k]
+    for (int k = 0; k < H; ++k)
+      for (int f = 0; f < H; ++f) dst[k * WIDE_HP + f] = M[f * ld + col0 + k];
+  };
+  for (int l = 0; l < L; ++l) {
+    float* wl = hw + WIDE_HEAD + (size_t)l * WideLayer::SIZE;
+    const float* e0w = q; q += H * (2 * H + 2);
+    const float* e0b = q; q += H;
+    const float* e2w = q; q += H * H;
+    const float* e2b = q; q += H;
+    const float* n0w = q; q += H * 2 * H;
+    const float* n0b = q; q += H;
+    const float* n2w = q; q += H * H;
+    const float* n2b = q; q += H;
+    const float* c0w = q; q += H * H;
+    const float* c0b = q; q += H;
+    const float* c2w = q; q += H;
+    const float* aw = nullptr; const float* ab = nullptr;
+    if (cfg->attention) { aw = q; q += H; ab = q; q += 1; }
+    put_t(wl + WideLayer::WA, e0w, 2 * H + 2, 0);
+    put_t(wl + WideLayer::WB, e0w, 2 * H + 2, H);
+    put_t(wl + WideLayer::W2, e2w, H, 0);
+    put_t(wl + WideLayer::WC1, c0w, H, 0);
+    put_t(wl + WideLayer::WN1A, n0w, 2 * H, 0);
+    put_t(wl + WideLayer::WN1B, n0w, 2 * H, H);
+    put_t(wl + WideLayer::WN2, n2w, H, 0);
+    for (int f = 0; f < H; ++f) {
+      wl[WideLayer::WR + f] = e0w[f * (2 * H + 2) + 2 * H];
+      wl[WideLayer::WE + f] = e0w[f * (2 * H + 2) + 2 * H + 1];
+      wl[WideLayer::B1 + f] = e0b[f];
+      wl[WideLayer::B2 + f] = e2b[f];
+      wl[WideLayer::WATT + f] = aw ? aw[f] : 0.f;
+      wl[WideLayer::BC1 + f] = c0b[f];
+      wl[WideLayer::WC2 + f] = c2w[f];
+      wl[WideLayer::BN1 + f] = n0b[f];
+      wl[WideLayer::BN2 + f] = n2b[f];
+    }
+    wl[WideLayer::BATT] = ab ? ab[0] : 0.f;
+  }
+  pita_egnn_wide* net = new pita_egnn_wide();
+  net->cfg = *cfg;
+  hipError_t e = hipMalloc(&net->d_w, n_w * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&net->d_estatic, (size_t)n * WIDE_HP * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(net->d_w, hw, n_w * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(net->d_estatic, he, (size_t)n * WIDE_HP * sizeof(float), hipMemcpyHostToDevice);
+  delete[] hw;
+  delete[] he;
+  if (e != hipSuccess) {
+    (void)hipFree(net->d_w);
+    (void)hipFree(net->d_estatic);
+    delete net;
+    return fail(PITA_EHIP, "pita_egnn_wide_create: device upload failed: %s", hipGetErrorString(e));
+  }
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    net->device = dev;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) net->n_cu = prop.multiProcessorCount;
+  }
+  *out = net;
+  return PITA_OK;
+}
+
+extern "C" int pita_egnn_wide_destroy(pita_egnn_wide_t* net) {
+  if (!net) return PITA_OK;
+  (void)hipFree(net->d_w);
+  (void)hipFree(net->d_estatic);
+  delete net;
+  return PITA_OK;
+}
+
+// what: 0 backbone forward (t = its time input), 1 denoiser D_theta, 2 score (t = h = sigma^2)
+extern "C" int pita_egnn_wide_eval(pita_egnn_wide_t* net, int what, const float* t, const float* x, const float* beta,
+                                   float* out, int64_t B, void* stream) {
+  PITA_REQUIRE(net && B >= 0 && what >= 0 && what <= 2, "pita_egnn_wide_eval: bad argument");
+  if (B == 0) return PITA_OK;
+  PITA_REQUIRE(t && x && out, "pita_egnn_wide_eval: null argument");
+  PITA_REQUIRE(beta || !net->cfg.condition_beta, "pita_egnn_wide_eval: beta required (condition_beta)");
+  int prev = -1;
+  bool switched = false;
+  if (net->device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != net->device)
+    switched = hipSetDevice(net->device) == hipSuccess;
+  WideParams p{};
+  p.w = net->d_w; p.estatic = net->d_estatic;
+  p.n = net->cfg.n_particles; p.dim = net->cfg.n_dim; p.H = net->cfg.hidden_nf; p.L = net->cfg.n_layers;
+  p.attention = net->cfg.attention; p.tanh_on = net->cfg.tanh; p.has_beta = net->cfg.condition_beta;
+  p.coord_scale = net->cfg.coords_range / (float)net->cfg.n_layers;
+  p.B = B; p.mode = what; p.x = x; p.t = t; p.beta = beta; p.out = out;
+  const size_t per_wave = sizeof(float) * (size_t)(3 * p.n * WIDE_HP + 3 * p.n * 4);
+  int waves = 4;
+  while (waves > 1 && per_wave * waves > 72 * 1024) waves >>= 1;  // two blocks per CU inside the 160 KB
+  int rc = PITA_OK;
+  auto kernel = p.H <= 32 ? egnn_wide_kernel<32> : egnn_wide_kernel<64>;
+  if (per_wave * waves > 150 * 1024) {
+    rc = fail(PITA_EUNSUPPORTED, "pita_egnn_wide_eval: %d particles need %zu B of LDS per wave", p.n, per_wave);
+  } else if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(per_wave * waves)) != hipSuccess) {
+    rc = fail(PITA_EHIP, "pita_egnn_wide_eval: cannot reserve %zu B of LDS", per_wave * waves);
+  } else {
+    const long long want = (B + waves - 1) / waves, cap = (long long)net->n_cu * 8;
+    const unsigned grid = (unsigned)(want < cap ? want : cap);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(waves * 64), per_wave * waves, (hipStream_t)stream, p);
+    if (hipGetLastError() != hipSuccess) rc = fail(PITA_EHIP, "pita_egnn_wide_eval: launch failed");
+  }
+  if (switched) (void)hipSetDevice(prev);
+  return rc;
+}

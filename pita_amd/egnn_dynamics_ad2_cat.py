@@ -1,0 +1,121 @@
+"""EGNN backbone of the alanine-dipeptide class (hidden 64 x 5 layers, one-hot atom-type node features) on the HIP
+vector-pipe kernel.
+
+Mirror of ``EGNN_dynamics_AD2_cat`` (pita/src/models/components/egnn_dynamics_ad2_cat.py:11-203; the ``_target_`` of
+``configs/model/net/egnn_dynamics_ad2_cat.yaml``): same constructor arguments and defaults, same parameter names and
+creation order (``egnn.embedding``, ``egnn.embedding_out``, ``egnn.gcl_<l>.{edge_mlp,node_mlp,coord_mlp,att_mlp}``: a
+seeded construction gives the reference's weights and its ``state_dict`` loads unchanged), same
+``forward(t, xs, beta) -> vel`` contract.  Node features are ``[h_initial (static one-hot rows), t, beta]`` (:157-184);
+the arithmetic of ``EGNN.forward`` / ``E_GCL`` (egnn.py:108-346) lives in pita_amd/csrc/egnn_wide_kernel.hip
+(``pita_egnn_wide_eval``).  ``edm`` lets ``ScoreNet`` evaluate the EDM preconditioning in the same launch.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .egnn_temp_conditioned import EGNN, _as_batch
+
+
+class EGNN_dynamics_AD2_cat(nn.Module):
+    def __init__(self, n_particles, n_dimensions, hidden_nf=64, act_fn=torch.nn.SiLU(), n_layers=5, recurrent=True,
+                 attention=True, tanh=True, atom_encoding_filename="atom_types_ecoding.npy", data_dir="data/alanine",
+                 pdb_filename="", agg="sum", M=128, condition_beta=False, h_initial=None):
+        super().__init__()
+        self._n_particles, self._n_dimensions = n_particles, n_dimensions
+        if h_initial is None:
+            h_initial = self.get_h_initial()
+        self.h_initial = torch.as_tensor(h_initial)
+        self.condition_beta = condition_beta
+        h_size = self.h_initial.size(1) + 1 + (1 if condition_beta else 0)  # :44-49
+        self.egnn = EGNN(in_node_nf=h_size, in_edge_nf=1, hidden_nf=hidden_nf, act_fn=act_fn, n_layers=n_layers,
+                         recurrent=recurrent, attention=attention, tanh=tanh, agg=agg)
+        self.counter = 0
+        self.M = M
+        self._handle = None
+        self._handle_key = None
+
+    def get_h_initial(self):
+        """The static node features of :66-92 for the particle counts that need no topology file."""
+        n = self._n_particles
+        groups = {22: [([0, 2, 3], 2), ([19, 20, 21], 20), ([11, 12, 13], 12)],
+                  33: [([1, 2, 3], 2), ([9, 10, 11], 10), ([19, 20, 21], 18), ([29, 30, 31], 31)],
+                  42: [([1, 2, 3], 2), ([11, 12, 13], 12), ([21, 22, 23], 22), ([31, 32, 33], 32), ([39, 40, 41], 40)]}
+        if n in groups:
+            atom_types = np.arange(n)
+            for idx, v in groups[n]:
+                atom_types[idx] = v
+            return torch.nn.functional.one_hot(torch.tensor(atom_types))
+        if n in (13, 55):
+            return torch.zeros(n, 1)
+        raise NotImplementedError(
+            f"EGNN_dynamics_AD2_cat: the node features of {n} particles come from a topology file (mdtraj, :94-155); "
+            "pass h_initial=[n_particles, n_features] instead")
+
+    # ------------------------------------------------------------------ native handle
+    def _config(self):
+        e = self.egnn
+        return _lib.EgnnWideConfig(self._n_particles, self._n_dimensions, e.hidden_nf, e.n_layers,
+                                   int(self.h_initial.size(1)), int(bool(self.condition_beta)), int(e.attention),
+                                   int(e.tanh), e.coords_range)
+
+    def _native(self, device):
+        tensors = self.__dict__.get("_tensor_list")
+        if tensors is None:
+            tensors = self.__dict__["_tensor_list"] = list(self.parameters()) + list(self.buffers())
+        key = (device.index,) + tuple((p.data_ptr(), p._version) for p in tensors)
+        if self._handle is None or key != self._handle_key:
+            self._release()
+            flat = torch.cat([p.detach().to("cpu", torch.float32).reshape(-1) for p in self.state_dict().values()]).contiguous().numpy()
+            h0 = np.ascontiguousarray(self.h_initial.detach().to("cpu", torch.float32).numpy())
+            cfg = self._config()
+            h = ctypes.c_void_p()
+            with torch.cuda.device(device):
+                _lib.check(_lib.lib().pita_egnn_wide_create(ctypes.byref(h), ctypes.byref(cfg),
+                                                            flat.ctypes.data_as(ctypes.c_void_p), flat.size,
+                                                            h0.ctypes.data_as(ctypes.c_void_p)), "pita_egnn_wide_create")
+            self._handle, self._handle_key = h, key
+        return self._handle
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_handle"], state["_handle_key"] = None, None
+        state.pop("_tensor_list", None)
+        return state
+
+    def _release(self):
+        if self._handle is not None:
+            _lib.lib().pita_egnn_wide_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ reference interface
+    def _eval(self, what, t, xs, beta):
+        xs = _lib.dev_tensor(xs, "xs")
+        B = xs.shape[0]
+        t = _lib.dev_tensor(t, "t").reshape(-1).expand(B).contiguous()
+        b = None
+        if self.condition_beta:
+            if beta is None:
+                raise ValueError("EGNN_dynamics_AD2_cat(condition_beta=True) needs beta")
+            b = _as_batch(beta, B, xs.device)
+        out = torch.empty_like(xs)
+        _lib.check(_lib.lib().pita_egnn_wide_eval(self._native(xs.device), int(what), t.data_ptr(), xs.data_ptr(), _lib.ptr(b),
+                                                  out.data_ptr(), B, _lib.stream_ptr(xs.device)), "pita_egnn_wide_eval")
+        return out
+
+    def forward(self, t, xs, beta=None):
+        """vel[B, n*d] = backbone(t[B], xs[B, n*d], beta[B]); mean-free (:157-203)."""
+        self.counter += 1
+        return self._eval(0, t, xs, beta)
+
+    def edm(self, what, h_t, x_t, beta):
+        """what=1: denoiser D_theta, what=2: score (D_theta - x)/h, EDM preconditioning fused (score_net.py:13-43)."""
+        return self._eval(what, h_t, x_t, beta)

@@ -255,6 +255,39 @@ def gen_egnn():
     save("egnn_notemp_lj13_fwd.npz", x=x.numpy(), t=t.numpy(), out=y.numpy(), **{"w." + k: v for k, v in sd_np(net1).items()})
 
 
+def gen_egnn_ad2cat():
+    """EGNN_dynamics_AD2_cat (egnn_dynamics_ad2_cat.py; configs/model/net/egnn_dynamics_ad2_cat.yaml: hidden 64 x 5 layers,
+    condition_beta) for 22 atoms: the reference module's output on seeded inputs, its weights and its static node
+    features.  mdtraj is only touched for >= 53 particles: a placeholder module satisfies the import."""
+    _ref_shims._mod("mdtraj")
+    from src.models.components import egnn_dynamics_ad2_cat as ad2
+
+    for tag, kw in (("h64", dict(hidden_nf=64, n_layers=5)), ("h48", dict(hidden_nf=48, n_layers=2, attention=False, tanh=False))):
+        torch.manual_seed(2468)
+        net = ad2.EGNN_dynamics_AD2_cat(n_particles=22, n_dimensions=3, condition_beta=True, **kw)
+        with torch.no_grad():  # the fresh coordinate heads (xavier gain 1e-3) make velocities ~1e-4: scale them up
+            for l in range(kw["n_layers"]):
+                getattr(net.egnn, f"gcl_{l}").coord_mlp[2].weight.mul_(300.0)
+            for p in net.parameters():
+                p.add_(0.02 * torch.randn_like(p))
+        gen = torch.Generator().manual_seed(97)
+        B = 12
+        base = lattice_cluster(22, 3, B, gen, spacing=1.1, jitter=0.1)
+        hs = torch.tensor([1e-3, 0.1, 1.0, 10.0, 400.0, 3.0])[torch.arange(B) % 6]
+        x = base + hs.sqrt()[:, None] * torch.randn(B, 66, generator=gen)
+        betas = torch.tensor([1.0, 1.33, 4.0])[torch.arange(B) % 3]
+        sn = score_net.ScoreNet(net)
+        with torch.no_grad():
+            c_noise = (1 / 8) * torch.log(hs)
+            c_in = 1 / (1 + hs) ** 0.5
+            F = net(c_noise, c_in[:, None] * x, betas)
+            Dth = sn.denoiser(hs, x, betas)
+            sc = sn(hs, x, betas)
+        save(f"egnn_ad2cat_{tag}_fwd.npz", x=x.numpy(), h=hs.numpy(), beta=betas.numpy(), F=F.numpy(), D=Dth.numpy(),
+             score=sc.numpy(), h_initial=net.h_initial.numpy().astype(np.float32),
+             **{"w." + k: v for k, v in sd_np(net).items()})
+
+
 # ----------------------------------------------------------------------------- MLP
 def gen_mlp():
     torch.manual_seed(12345)
@@ -653,7 +686,7 @@ def gen_traj_gmm():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "lj", "lj_smooth", "gmm", "egnn", "mlp", "prior", "resample", "traj_nodebias", "traj_1000",
+    which = sys.argv[1:] or ["schedules", "lj", "lj_smooth", "gmm", "egnn", "egnn_ad2cat", "mlp", "prior", "resample", "traj_nodebias", "traj_1000",
                              "traj_debias", "traj_debias_end", "debias_variants", "post", "traj_gmm"]
     for w in which:
         globals()["gen_" + w]()

@@ -260,6 +260,67 @@ def test_egnn_golden(pa, golden, name, tag, wfile, precision):
         assert rel(sc[m], g[f"score_{tag}"][m]) < tol, hv
 
 
+@pytest.mark.parametrize("tag,L,tanh,att", [("h64", 5, True, True), ("h48", 2, False, False)])
+def test_egnn_ad2cat_golden(pa, golden, tag, L, tanh, att):
+    """EGNN_dynamics_AD2_cat on the vector-pipe kernel (pita_egnn_wide_eval; hidden 64 x 5 layers and a hidden-48 net
+    that exercises the padding): backbone output within 4x the reference's own fp32-vs-fp64 error, denoiser and score
+    through ScoreNet's fused EDM path, batch edges, and the per-step sampler path of the integrator against the oracle."""
+    from pita_amd.egnn_dynamics_ad2_cat import EGNN_dynamics_AD2_cat
+
+    g = golden(f"egnn_ad2cat_{tag}_fwd.npz")
+    w = {k[2:]: T(v) for k, v in g.items() if k.startswith("w.")}
+    H = w["egnn.embedding.weight"].shape[0]
+    net = EGNN_dynamics_AD2_cat(22, 3, hidden_nf=H, n_layers=L, tanh=tanh, attention=att, condition_beta=True)
+    net.load_state_dict(w)
+    x, h, beta = cu(g["x"]), cu(g["h"]), cu(g["beta"])
+    c_s, c_in, c_out, c_noise = O.edm_coeffs(T(g["h"]))
+    F = net(c_noise.cuda(), (c_in[:, None] * T(g["x"])).cuda(), beta)
+    wd = {k: v.double() for k, v in w.items()}
+    F64 = O.egnn_ad2_cat_forward(wd, c_noise.double(), (c_in[:, None] * T(g["x"])).double(), T(g["beta"]).double(), 22, 3,
+                                 n_layers=L, tanh=tanh, attention=att)
+    err_ref, err_hip = rel(g["F"], F64), rel(F, F64)
+    print(f"[ad2cat/{tag}] err_hip_vs_fp64={err_hip:.3e} err_ref_vs_fp64={err_ref:.3e}")
+    assert err_hip < max(4 * err_ref, 2e-6), (err_hip, err_ref)
+    assert rel(F, g["F"]) < max(2e-5, 6 * err_ref)
+    sn = pa.ScoreNet(net)
+    assert rel(sn.denoiser(h, x, beta), g["D"]) < 2e-6
+    sc = sn(h, x, beta).cpu().numpy()
+    for hv in np.unique(g["h"]):
+        m = g["h"] == hv
+        assert rel(sc[m], g["score"][m]) < (1e-4 if hv > 0.05 else 5e-3), hv
+    # batch edges: empty, one walker, more walkers than resident waves; a walker's value does not depend on the batch
+    assert net(c_noise[:0].cuda(), x[:0], beta[:0]).shape == (0, 66)
+    one = net(c_noise[:1].cuda(), (c_in[:1, None] * T(g["x"][:1])).cuda(), beta[:1])
+    assert torch.equal(one, F[:1])
+    reps = 700
+    big = net(c_noise.repeat(reps).cuda(), (c_in[:, None] * T(g["x"])).repeat(reps, 1).cuda(), beta.repeat(reps))
+    assert torch.equal(big[-12:], F) and torch.equal(big[:12], F)
+    with pytest.raises(pa._lib.PitaHipError):
+        net(c_noise, T(g["x"]), T(g["beta"]))  # CPU tensors: no fallback
+    if not tanh:
+        return  # without the tanh bound these scaled-up coordinate heads diverge from the prior's scale (in the oracle too)
+    # the integrator's per-step path (ScoreNet's fused EDM evaluation + pita_em_step) against the oracle, 6 steps
+    N, B = 6, 12
+    sched, gam = pa.ElucidatingNoiseSchedule(sigma_min=0.01, sigma_max=80.0, rho=7), pa.ConstantAnnealingFactorSchedule(1.0)
+    sde = pa.VEReverseSDE(noise_schedule=sched, score_net=sn, debias_inference=False)
+    integ = pa.WeightedSDEIntegrator(sde=sde, num_integration_steps=N, start_resampling_step=0, end_resampling_step=N,
+                                     resampling_interval=-1, num_negative_time_steps=0, post_mcmc_steps=0)
+    gen = torch.Generator().manual_seed(4)
+    x1 = O.remove_mean(torch.randn(B, 66, generator=gen) * 60.0, 22, 3)
+    noise = torch.randn(N, B, 66, generator=gen)
+
+    class Geo:  # what the integrator reads off an energy function
+        n_particles, n_spatial_dim, is_molecule = 22, 3, True
+
+    xh, *_ = integ.integrate_sde(x1.cuda(), Geo(), gam, inverse_temperature=1.3, noise=noise.cuda())
+    bb = lambda cn, xs, b: O.egnn_ad2_cat_forward(w, cn, xs, b, 22, 3, n_layers=L, tanh=tanh, attention=att)
+    osched, ogam = O.Elucidating(0.01, 80.0, 7), O.GammaConstant(1.0)
+    ref = O.integrate_sde(O.IntegratorConfig(num_integration_steps=N, end_resampling_step=N), x1,
+                          lambda t, xc: O.f_not_debiased(bb, osched, ogam, t, xc, 1.3), osched.g, lambda i, shp: noise[i],
+                          22, 3)["x"]
+    assert torch.isfinite(ref).all() and rel(xh, ref) < 1e-4
+
+
 def test_f16x2_out_of_range_walkers_are_recomputed_on_the_bf16_path(pa, golden):
     """precision="f16x2" has a range limit (SiLU outputs beyond 65504 overflow f16).  The launch wrapper follows the f16
     kernel with a repair launch of the bf16x3 kernel that recomputes exactly the walker groups whose results are

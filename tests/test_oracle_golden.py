@@ -139,6 +139,29 @@ def test_egnn(golden, name, tag, wfile):
     np.testing.assert_allclose(E, g[f"E_{tag}"], rtol=2e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("tag,L,tanh,att", [("h64", 5, True, True), ("h48", 2, False, False)])
+def test_egnn_ad2cat(golden, tag, L, tanh, att):
+    """EGNN_dynamics_AD2_cat (the alanine-dipeptide backbone: one-hot atom types + t + beta, hidden 64 x 5 layers; a
+    second net with hidden 48, no attention, no tanh): backbone output, denoiser and score of the reference module."""
+    g = golden(f"egnn_ad2cat_{tag}_fwd.npz")
+    w = {k[2:]: T(v) for k, v in g.items() if k.startswith("w.")}
+    np.testing.assert_array_equal(O.egnn_ad2_cat_h_initial(22).numpy(), g["h_initial"])
+    x, hs, beta = T(g["x"]), T(g["h"]), T(g["beta"])
+    c_s, c_in, c_out, c_noise = O.edm_coeffs(hs)
+    F = O.egnn_ad2_cat_forward(w, c_noise, c_in[:, None] * x, beta, 22, 3, n_layers=L, tanh=tanh, attention=att)
+    assert rel(F.numpy(), g["F"]) < 2e-6
+    bb = lambda cn, xs, b: O.egnn_ad2_cat_forward(w, cn, xs, b, 22, 3, n_layers=L, tanh=tanh, attention=att)
+    assert rel(O.denoiser(bb, hs, x, beta).numpy(), g["D"]) < 2e-6
+    # the pita_amd module owns parameters with the reference's names and shapes (checkpoints load unchanged)
+    from pita_amd.egnn_dynamics_ad2_cat import EGNN_dynamics_AD2_cat
+
+    m = EGNN_dynamics_AD2_cat(22, 3, hidden_nf=w["egnn.embedding.weight"].shape[0], n_layers=L, tanh=tanh, attention=att,
+                              condition_beta=True)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(w.keys()) and all(sd[k].shape == w[k].shape for k in w)
+    assert torch.equal(m.h_initial.float(), T(g["h_initial"]))
+
+
 def test_egnn_quirk_layout():
     h0 = O.egnn_node_features(T([0.5]), T([2.0]), 13).numpy()
     assert (h0[:6] == [0.5, 0.5]).all() and (h0[6] == [0.5, 2.0]).all() and (h0[7:] == [2.0, 2.0]).all()
