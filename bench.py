@@ -511,6 +511,41 @@ def main():
     if rank == 0 and world == 1 and not args.no_debiased and not args.force_last:
         Bd = B if n <= 22 else min(B, 4096)
         debiased = debiased_leg(pita_amd, net, cfg, dev, Bd, with_cpu=not args.no_cpu_baseline and n <= 13)
+    ad2cat = None
+    if rank == 0 and world == 1 and args.config == "aldp22" and not args.force_last:
+        # the reference's alanine-dipeptide EGNN (egnn_dynamics_ad2_cat.yaml: hidden 64 x 5 layers, one-hot atom types) on
+        # the vector-pipe kernel, through the integrator's per-step path (fused EDM evaluation + pita_em_step)
+        from pita_amd.egnn_dynamics_ad2_cat import EGNN_dynamics_AD2_cat
+
+        torch.manual_seed(12345)
+        net64 = EGNN_dynamics_AD2_cat(n, d, hidden_nf=64, n_layers=5, condition_beta=True)
+        sn64 = pita_amd.ScoreNet(net64)
+        xa = x.clone()
+        L_ = pita_amd._lib.lib()
+
+        def step64(k):
+            row = tab_h[k]
+            ht = torch.full((B,), float(row[pita_amd._lib.ST_H]), device=dev)
+            score = sn64(ht, xa, 1.0)
+            drift = (float(row[pita_amd._lib.ST_GAMMA]) * (score * float(row[pita_amd._lib.ST_G2]))).contiguous()
+            L_.pita_em_step(xa.data_ptr(), drift.data_ptr(), 0, B, n, d, float(row[pita_amd._lib.ST_DT]),
+                            float(row[pita_amd._lib.ST_NOISE_SCALE]), float(row[pita_amd._lib.ST_SQRT_DT]), seed, rank * B, k, 1,
+                            0, pita_amd._lib.stream_ptr(dev))
+
+        for k in range(2):
+            step64(k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(2, 10):
+            step64(k)
+        torch.cuda.synchronize()
+        dt64 = (time.perf_counter() - t0) / 8
+        mac = 5 * (n * (n - 1) * ((2 * 64 + 2) * 64 + 2 * 64 * 64 + 2 * 64) + n * 3 * 64 * 64)
+        ad2cat = {"backbone": "EGNN_dynamics_AD2_cat hidden 64 x 5 layers (pita_egnn_wide_eval, fp32 vector pipe)",
+                  "walkers": B, "ms_per_step": dt64 * 1e3, "value": B / dt64, "unit": "walker-steps/s",
+                  "algorithmic_TFLOPs": 2 * mac * B / dt64 / 1e12, "frac_of_plain_fma_rate_78.6": 2 * mac * B / dt64 / 78.65e12,
+                  "finite": bool(torch.isfinite(xa).all())}
+        del xa
     run(0, W)  # warm-up (also builds the native handle)
     gathered = torch.empty(world * B, D, device=dev) if world > 1 else None
     torch.cuda.synchronize()
@@ -617,6 +652,8 @@ def main():
             "roofline": roof,
             "roofline_force": force_rl,
         }
+        if ad2cat is not None:
+            out["ad2cat_backbone"] = ad2cat
         if world == 1 and not args.no_cpu_baseline:
             # ~10-20 s of CPU work: the cost per walker-step grows with the number of edges
             steps = args.cpu_steps or max(4, int(300 * 156 / (n * (n - 1))))
