@@ -518,6 +518,51 @@ def gen_traj_1000():
          x_final=x.detach().numpy(), drift_at=drift, prior_scale=scale, gamma=4 / 3, beta=1.0, sigma_min=0.05)
 
 
+def gen_traj_1000_lj55():
+    """Config C5's system at the metric's trajectory length: LJ55, EGNN h32x3 (trained-like weights of the LJ13 fixture:
+    the parameter shapes do not depend on the particle count), N = 1000, 4 walkers, fixed PCG64 noise."""
+    wt = dict(np.load(os.path.join(HERE, "egnn_weights_trainedlike.npz")))
+    net = make_egnn(55, 3)
+    net.load_state_dict({k: torch.tensor(v) for k, v in wt.items()})
+    sn = score_net.ScoreNet(net)
+    sched = noise_schedules.ElucidatingNoiseSchedule(sigma_min=0.05, sigma_max=80.0, rho=7)
+    sde = sdes.VEReverseSDE(noise_schedule=sched, energy_net=None, score_net=sn, cdf=lambda *a: None, debias_inference=False)
+    sde.trainer = FakeTrainer()
+    N, B, seed = 1000, 4, 20261055
+    gamma = annealing_factor_schedules.ConstantAnnealingFactorSchedule(4 / 3)
+    integ = sde_integration.WeightedSDEIntegrator(
+        sde=sde, num_integration_steps=N, start_resampling_step=0, end_resampling_step=N, lightning_module=FakeLM(),
+        partial_annealing_factor_schedule=None, resampling_interval=-1, num_negative_time_steps=0, post_mcmc_steps=0,
+        batch_size=None, should_mean_free=True)
+    e = LJ(165, 55, 3, data_path="", temperature=1.0)
+    noise = pcg_noise(seed, N, B, 165)
+    scale = float((sched.h(torch.tensor(1.0)) / gamma.gamma(torch.tensor(1.0))) ** 0.5)
+    x1 = data_utils.remove_mean(torch.from_numpy(pcg_noise(seed + 1, 1, B, 165)[0]) * scale, 55, 3)
+    calls, draws, xs = {"k": 0}, {"k": 0}, []
+    real_f, real_rn = sde.f, torch.randn_like
+
+    def rec_f(t, x, *a, **k):
+        if calls["k"] % 250 == 0:
+            xs.append(x.detach().clone().numpy())
+        calls["k"] += 1
+        return real_f(t, x, *a, **k)
+
+    def fixed_randn_like(x, *a, **k):
+        v = torch.from_numpy(noise[draws["k"]]).reshape(x.shape)
+        draws["k"] += 1
+        return v
+
+    sde.f = rec_f
+    torch.randn_like = fixed_randn_like
+    try:
+        x, logw, uniq, terms, acc = integ.integrate_sde(x1.clone(), e, gamma, inverse_temperature=1.0)
+    finally:
+        torch.randn_like = real_rn
+    assert calls["k"] == N and draws["k"] == N
+    save("em_traj_lj55_1000.npz", seed=seed, N=N, B=B, x1=x1.numpy(), x_at=np.stack(xs), at=np.arange(0, N, 250),
+         x_final=x.detach().numpy(), prior_scale=scale, gamma=4 / 3, beta=1.0, sigma_min=0.05)
+
+
 def gen_traj_debias():
     wt = dict(np.load(os.path.join(HERE, "egnn_weights_trainedlike.npz")))
     sde, sched = build_lj13_stack(wt, debias=True)
@@ -606,9 +651,9 @@ def gen_debias_variants():
     save("debias_variants_lj13.npz", **out)
 
 
-def gen_post():
-    """negative-time descent + MALA on the LJ13 target (sde_integration.py:353-470)."""
-    e_raw = LJ(39, 13, 3, data_path="", temperature=1.0)
+def gen_post(n=13, B=16, dt_mala=4e-4):
+    """negative-time descent + MALA on the LJ13 / LJ55 target (sde_integration.py:353-470)."""
+    e_raw = LJ(3 * n, n, 3, data_path="", temperature=1.0)
 
     class Detached:
         """torch>=2.10 refuses ``requires_grad = True`` on the non-leaf views the reference's MALA
@@ -616,14 +661,14 @@ def gen_post():
         swallows the exception (sde_integration.py:401) and MALA silently does nothing.  Hand the
         energy a detached alias of the same storage so the reference arithmetic runs unchanged."""
 
-        is_molecule, n_particles, n_spatial_dim = True, 13, 3
+        is_molecule, n_particles, n_spatial_dim = True, n, 3
 
         def __call__(self, x, return_force=False):
             return e_raw(x.detach(), return_force=return_force)
 
     e = Detached()
-    gen = torch.Generator().manual_seed(5150)
-    x0 = lattice_cluster(13, 3, 16, gen, spacing=1.12, jitter=0.1)
+    gen = torch.Generator().manual_seed(5150 if n == 13 else 5150 + n)
+    x0 = lattice_cluster(n, 3, B, gen, spacing=1.12, jitter=0.1 if n == 13 else 0.04)
 
     def mk(**kw):
         d = dict(sde=None, num_integration_steps=1, start_resampling_step=0, end_resampling_step=1,
@@ -640,7 +685,7 @@ def gen_post():
         out["x_langevin"] = integ.negative_time_descent(x0.clone(), e).detach().numpy()
     out["langevin_noise"] = np.stack([r.numpy() for r in rec.randn])
     # plain MALA, 6 steps, dt chosen so acceptance is mixed
-    integ = mk(post_mcmc_steps=6, dt_negative_time=4e-4, adaptive_mcmc=False)
+    integ = mk(post_mcmc_steps=6, dt_negative_time=dt_mala, adaptive_mcmc=False)
     torch.manual_seed(4)
     with Recorder() as rec:
         xm, accs = integ.metropolis_hastings_mala(x0.clone(), e, return_acceptance_rate=True)
@@ -649,15 +694,20 @@ def gen_post():
     out["mala_noise"] = np.stack([r.numpy() for r in rec.randn])
     out["mala_u"] = np.stack([r.numpy() for r in rec.rand_like])
     # adaptive MALA
-    integ = mk(post_mcmc_steps=6, dt_negative_time=4e-4, adaptive_mcmc=True)
+    integ = mk(post_mcmc_steps=6, dt_negative_time=dt_mala, adaptive_mcmc=True)
     torch.manual_seed(5)
     with Recorder() as rec:
-        xa, accs = integ.metropolis_hastings_mala_adaptive(x0.clone(), e, dt_init=4e-4, return_acceptance_rate=True)
+        xa, accs = integ.metropolis_hastings_mala_adaptive(x0.clone(), e, dt_init=dt_mala, return_acceptance_rate=True)
     out["x_mala_adaptive"] = xa.detach().numpy()
     out["mala_adaptive_acc"] = np.asarray(accs)
     out["mala_adaptive_noise"] = np.stack([r.numpy() for r in rec.randn])
     out["mala_adaptive_u"] = np.stack([r.numpy() for r in rec.rand_like])
-    save("post_lj13.npz", **out)
+    out["dt_mala"] = dt_mala
+    save(f"post_lj{n}.npz", **out)
+
+
+def gen_post55():
+    gen_post(n=55, B=8, dt_mala=1.2e-3)
 
 
 def gen_traj_gmm():
@@ -687,6 +737,6 @@ def gen_traj_gmm():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["schedules", "lj", "lj_smooth", "gmm", "egnn", "egnn_ad2cat", "mlp", "prior", "resample", "traj_nodebias", "traj_1000",
-                             "traj_debias", "traj_debias_end", "debias_variants", "post", "traj_gmm"]
+                             "traj_debias", "traj_debias_end", "debias_variants", "post", "post55", "traj_1000_lj55", "traj_gmm"]
     for w in which:
         globals()["gen_" + w]()

@@ -534,46 +534,49 @@ def pcg_noise(seed, N, B, D):
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2"])
-def test_traj_1000_steps_golden(pa, golden, precision):
+@pytest.mark.parametrize("n", [13, 55])
+def test_traj_1000_steps_golden(pa, golden, precision, n):
     """Parity at the metric's own trajectory length: the reference's integrate_sde, LJ13, N = 1 000 (experiment/lj13.yaml),
     fixed PCG64 noise, walkers recorded every 100 steps.  The fused HIP sampler fed the same noise must stay as close
     to fp64 arithmetic as the fp32 reference does -- err(HIP, fp64 oracle) <= 4 x err(reference, fp64 oracle) -- at every
     checkpoint, through the small-h end (h -> 2.5e-3) where score = (D - x)/h amplifies rounding 400x."""
-    g = golden("em_traj_lj13_1000.npz")
+    g = golden(f"em_traj_lj{n}_1000.npz")  # LJ55: config C5's system, 4 walkers, checkpoints every 250 steps
+    D = 3 * n
     w = golden("egnn_weights_trainedlike.npz")
     N, B = int(g["N"]), int(g["B"])
-    noise_h = pcg_noise(int(g["seed"]), N, B, 39)
+    noise_h = pcg_noise(int(g["seed"]), N, B, D)
     at = [int(a) for a in g["at"]] + [N]
     want = list(g["x_at"]) + [g["x_final"]]
     # fp64 oracle on the same noise
     wd = {k: T(v).double() for k, v in w.items()}
-    bb = lambda cn, xs, b: O.egnn_forward(wd, cn, xs, b, 13, 3)
+    bb = lambda cn, xs, b: O.egnn_forward(wd, cn, xs, b, n, 3)
     osched, ogam = O.Elucidating(0.05, 80.0, 7), O.GammaConstant(4 / 3)
     nz64 = T(noise_h).double()
     out = O.integrate_sde(O.IntegratorConfig(num_integration_steps=N, end_resampling_step=N), T(g["x1"]).double(),
                           lambda t, xc: O.f_not_debiased(bb, osched, ogam, t, xc, 1.0), osched.g, lambda i, shp: nz64[i],
-                          13, 3, record=True)
+                          n, 3, record=True)
     truth = [g["x1"].astype(np.float64)] + [out["traj"][a - 1].numpy() for a in at[1:]]
     # HIP: ten launches of 100 steps (bitwise equal to one launch of 1 000, tested elsewhere), walkers read in between
-    net = make_net(pa, 13, 3, w, precision=precision).cuda()
+    net = make_net(pa, n, 3, w, precision=precision).cuda()
     sched, gam = pa.ElucidatingNoiseSchedule(sigma_min=0.05, sigma_max=80.0, rho=7), pa.ConstantAnnealingFactorSchedule(4 / 3)
     tab = pa.sde_integration.build_step_table(sched, gam, torch.linspace(1.0, 0.0, N + 1)[:-1], 1.0 / N, 1.0, 1.0).cuda()
     noise = cu(noise_h)
     x = cu(g["x1"]).clone()
     got = [x.cpu().numpy()]
-    for s0 in range(0, N, 100):
-        net.sampler_run(x, tab[s0:s0 + 100].contiguous(), 100, noise=noise[s0:s0 + 100].contiguous(), step0=s0,
-                        remove_mean=True, n_particles=13, n_dim=3)
+    every = at[1] - at[0]
+    for s0 in range(0, N, every):
+        net.sampler_run(x, tab[s0:s0 + every].contiguous(), every, noise=noise[s0:s0 + every].contiguous(), step0=s0,
+                        remove_mean=True, n_particles=n, n_dim=3)
         got.append(x.cpu().numpy())
     for k, a in enumerate(at):
         e_ref, e_hip = rel(want[k], truth[k]), rel(got[k], truth[k])
-        print(f"[traj1000/{precision}] step {a:4d}: HIP vs fp64 {e_hip:.2e}, reference vs fp64 {e_ref:.2e}, HIP vs reference {rel(got[k], want[k]):.2e}")
+        print(f"[traj1000/lj{n}/{precision}] step {a:4d}: HIP vs fp64 {e_hip:.2e}, reference vs fp64 {e_ref:.2e}, HIP vs reference {rel(got[k], want[k]):.2e}")
         assert e_hip <= 4 * e_ref + 1e-6, (a, e_hip, e_ref)
     # the whole trajectory through the integrator front end in one launch gives the same walkers
     sde = pa.VEReverseSDE(noise_schedule=sched, score_net=pa.ScoreNet(net), debias_inference=False)
     integ = pa.WeightedSDEIntegrator(sde=sde, num_integration_steps=N, start_resampling_step=0, end_resampling_step=N,
                                      resampling_interval=-1, num_negative_time_steps=0, post_mcmc_steps=0)
-    xi, *_ = integ.integrate_sde(cu(g["x1"]), pa.LennardJonesEnergy(39, 13, 3), gam, inverse_temperature=1.0, noise=noise)
+    xi, *_ = integ.integrate_sde(cu(g["x1"]), pa.LennardJonesEnergy(D, n, 3), gam, inverse_temperature=1.0, noise=noise)
     assert torch.equal(xi, x)
 
 
@@ -711,9 +714,13 @@ def test_resample_global_batch_of_config_c5(pa):
     print(f"[resample/C5] {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per global resampling event at {B} walkers")
 
 
-def test_post_processing_golden(pa, golden):
-    g = golden("post_lj13.npz")
-    e = pa.LennardJonesEnergy(39, 13, 3)
+@pytest.mark.parametrize("n", [13, 55])
+def test_post_processing_golden(pa, golden, n):
+    """The reference's negative-time descent, Langevin descent, MALA and adaptive MALA (recorded noise and uniforms) on the
+    LJ13 and LJ55 targets: the fused chains (lj13 kernels / ring kernels) reproduce walkers and acceptance rates."""
+    g = golden(f"post_lj{n}.npz")
+    dtm = float(g["dt_mala"])
+    e = pa.LennardJonesEnergy(3 * n, n, 3)
     mk = lambda **kw: pa.WeightedSDEIntegrator(sde=None, num_integration_steps=1, start_resampling_step=0,
                                                end_resampling_step=1, **kw)
     x0 = cu(g["x0"])
@@ -722,12 +729,12 @@ def test_post_processing_golden(pa, golden):
     xl = mk(num_negative_time_steps=10, dt_negative_time=1e-4, do_langevin=True).negative_time_descent(
         x0, e, noise=cu(g["langevin_noise"]))
     assert rel(xl, g["x_langevin"]) < 1e-5
-    xm, acc = mk(post_mcmc_steps=6, dt_negative_time=4e-4).metropolis_hastings_mala(
+    xm, acc = mk(post_mcmc_steps=6, dt_negative_time=dtm).metropolis_hastings_mala(
         x0, e, return_acceptance_rate=True, noise=cu(g["mala_noise"]), uniforms=cu(g["mala_u"]))
     np.testing.assert_allclose(acc, g["mala_acc"], atol=1e-7)
     assert rel(xm, g["x_mala"]) < 1e-5
-    xa, acc = mk(post_mcmc_steps=6, dt_negative_time=4e-4, adaptive_mcmc=True).metropolis_hastings_mala_adaptive(
-        x0, e, dt_init=4e-4, return_acceptance_rate=True, noise=cu(g["mala_adaptive_noise"]),
+    xa, acc = mk(post_mcmc_steps=6, dt_negative_time=dtm, adaptive_mcmc=True).metropolis_hastings_mala_adaptive(
+        x0, e, dt_init=dtm, return_acceptance_rate=True, noise=cu(g["mala_adaptive_noise"]),
         uniforms=cu(g["mala_adaptive_u"]))
     np.testing.assert_allclose(acc, g["mala_adaptive_acc"], atol=1e-7)
     assert rel(xa, g["x_mala_adaptive"]) < 1e-5

@@ -241,35 +241,36 @@ def pcg_noise(seed, N, B, D):
     return np.random.Generator(np.random.PCG64(seed)).standard_normal((N, B, D), dtype=np.float32)
 
 
-def test_traj_1000_steps(golden):
+@pytest.mark.parametrize("n", [13, 55])
+def test_traj_1000_steps(golden, n):
     """The metric's own trajectory length (experiment/lj13.yaml: 1 000 steps): the reference's integrate_sde on fixed
     PCG64 noise, walkers recorded every 100 steps.  The fp32 oracle must track the reference as closely as the
     reference tracks the fp64 oracle (both carry fp32 rounding through the small-h end where score = (D - x)/h
     amplifies it), at every checkpoint."""
-    g = golden("em_traj_lj13_1000.npz")
-    bb = _lj13_backbone(golden)
+    g = golden(f"em_traj_lj{n}_1000.npz")  # LJ55: config C5's system, 4 walkers, checkpoints every 250 steps
+    D = 3 * n
     N, B = int(g["N"]), int(g["B"])
-    noise = pcg_noise(int(g["seed"]), N, B, 39)
-    np.testing.assert_array_equal(O.remove_mean(T(pcg_noise(int(g["seed"]) + 1, 1, B, 39)[0]) * float(g["prior_scale"]),
-                                                13, 3).numpy(), g["x1"])
+    noise = pcg_noise(int(g["seed"]), N, B, D)
+    np.testing.assert_array_equal(O.remove_mean(T(pcg_noise(int(g["seed"]) + 1, 1, B, D)[0]) * float(g["prior_scale"]),
+                                                n, 3).numpy(), g["x1"])
     at = list(g["at"]) + [N]
     want = list(g["x_at"]) + [g["x_final"]]
     runs = {}
     for dt in (torch.float32, torch.float64):
         w = {k: T(v).to(dt) for k, v in golden("egnn_weights_trainedlike.npz").items()}
-        bbd = lambda cn, xs, b: O.egnn_forward(w, cn, xs, b, 13, 3)
+        bbd = lambda cn, xs, b: O.egnn_forward(w, cn, xs, b, n, 3)
         sched, gam = O.Elucidating(0.05, 80.0, 7), O.GammaConstant(4 / 3)
         cfg = O.IntegratorConfig(num_integration_steps=N, end_resampling_step=N)
         nz = T(noise).to(dt)
         x1 = T(g["x1"]).to(dt)
         out = O.integrate_sde(cfg, x1, lambda t, xc: O.f_not_debiased(bbd, sched, gam, t, xc, 1.0),
-                              sched.g, lambda i, shp: nz[i], 13, 3, record=True)
+                              sched.g, lambda i, shp: nz[i], n, 3, record=True)
         # traj[k] = walkers after step k = walkers entering step k + 1
         runs[dt] = [x1.numpy()] + [out["traj"][a - 1].numpy() for a in at[1:]]
     for k, (a, ref) in enumerate(zip(at, want)):
         e_ref = rel(ref, runs[torch.float64][k])  # the reference's own fp32 error against fp64 arithmetic
         e_o32 = rel(runs[torch.float32][k], runs[torch.float64][k])
-        print(f"[traj1000] step {a:4d}: reference fp32 vs fp64 oracle {e_ref:.2e}, fp32 oracle vs fp64 oracle {e_o32:.2e}")
+        print(f"[traj1000/lj{n}] step {a:4d}: reference fp32 vs fp64 oracle {e_ref:.2e}, fp32 oracle vs fp64 oracle {e_o32:.2e}")
         assert e_o32 <= 4 * e_ref + 1e-6, (a, e_o32, e_ref)
         assert rel(runs[torch.float32][k], ref) <= 8 * e_ref + 1e-6
 
@@ -346,29 +347,32 @@ def test_traj_debias_resample_at_end(golden):
     assert rel(x.numpy(), g["x_final"]) < 2e-3
 
 
-def test_post(golden):
-    g = golden("post_lj13.npz")
-    lf = lambda x: O.lj_logp_force(x, 13, 3)
+@pytest.mark.parametrize("n", [13, 55])
+def test_post(golden, n):
+    """negative-time descent, Langevin descent, MALA and adaptive MALA of the reference on the LJ13 and LJ55 targets."""
+    g = golden(f"post_lj{n}.npz")
+    dtm = float(g["dt_mala"])
+    lf = lambda x: O.lj_logp_force(x, n, 3)
     x0 = T(g["x0"])
-    xd = O.negative_time_descent(x0, lf, 25, 1e-4, 13, 3)
+    xd = O.negative_time_descent(x0, lf, 25, 1e-4, n, 3)
     assert rel(xd.numpy(), g["x_descent"]) < 1e-6
     ln = T(g["langevin_noise"])
-    xl = O.negative_time_descent(x0, lf, 10, 1e-4, 13, 3, do_langevin=True, noise_fn=lambda k, s: ln[k])
+    xl = O.negative_time_descent(x0, lf, 10, 1e-4, n, 3, do_langevin=True, noise_fn=lambda k, s: ln[k])
     assert rel(xl.numpy(), g["x_langevin"]) < 1e-6
     # MALA: the reference draws 1 proposal-noise tensor and 1 uniform tensor per step
-    x, lp = x0.clone(), O.lj_logp(x0, 13, 3)
+    x, lp = x0.clone(), O.lj_logp(x0, n, 3)
     accs = []
     for k in range(6):
-        x, lp, acc = O.mala_step(x, lp, lf, 4e-4, T(g["mala_noise"][k]), torch.log(T(g["mala_u"][k])))
-        x = O.remove_mean(x, 13, 3)
+        x, lp, acc = O.mala_step(x, lp, lf, dtm, T(g["mala_noise"][k]), torch.log(T(g["mala_u"][k])))
+        x = O.remove_mean(x, n, 3)
         accs.append(acc.float().mean().item())
     np.testing.assert_allclose(accs, g["mala_acc"], atol=1e-7)
     assert rel(x.numpy(), g["x_mala"]) < 1e-6
     # adaptive
-    x, lp, dt = x0.clone(), O.lj_logp(x0, 13, 3), 4e-4
+    x, lp, dt = x0.clone(), O.lj_logp(x0, n, 3), dtm
     for k in range(6):
         x, lp, acc = O.mala_step(x, lp, lf, dt, T(g["mala_adaptive_noise"][k]), torch.log(T(g["mala_adaptive_u"][k])))
-        x = O.remove_mean(x, 13, 3)
+        x = O.remove_mean(x, n, 3)
         a = acc.float().mean().item()
         dt = dt * 1.1 if a > 0.55 else dt / 1.1
         assert abs(a - g["mala_adaptive_acc"][k]) < 1e-7
