@@ -160,8 +160,34 @@ __global__ void __launch_bounds__(QT) quantile_clamp_kernel(float* __restrict__ 
   const long long klo = (long long)floorf(rank);
   const long long khi = (klo + 1 < n) ? (long long)ceilf(rank) : klo;
   const float w = rank - (float)klo;
-  const float vlo = radix_select(ac, n, klo, hist, sh);
-  const float vhi = (khi == klo) ? vlo : radix_select(ac, n, khi, hist, sh);
+  float vlo, vhi;
+  if (n <= QT) {
+    // chunks of up to 1 024 walkers (the reference's inference chunks: 512 for LJ13): both order statistics by rank
+    // counting -- thread i counts the elements that sort before its own (ties broken by index, so ranks are a
+    // permutation), all threads reading the same key from LDS at a time (broadcast reads).  ~2 n instructions per
+    // thread instead of the radix select's eight serial 256-bin scans (216 -> 12 us at 128 chunks of 512).
+    __shared__ unsigned keys[QT];
+    __shared__ float picked[2];
+    const int t = threadIdx.x;
+    const unsigned mine = t < n ? f2key(ac[t]) : 0xFFFFFFFFu;
+    keys[t] = mine;
+    __syncthreads();
+    if (t < n) {
+      int rank = 0;
+      for (int j = 0; j < (int)n; ++j) {
+        const unsigned kj = keys[j];
+        rank += (kj < mine || (kj == mine && j < t)) ? 1 : 0;
+      }
+      if (rank == (int)klo) picked[0] = key2f(mine);
+      if (rank == (int)khi) picked[1] = key2f(mine);
+    }
+    __syncthreads();
+    vlo = picked[0];
+    vhi = picked[1];
+  } else {
+    vlo = radix_select(ac, n, klo, hist, sh);
+    vhi = (khi == klo) ? vlo : radix_select(ac, n, khi, hist, sh);
+  }
   const float diff = vhi - vlo;
   const float quant = (w < 0.5f) ? fmaf(w, diff, vlo) : vhi - diff * (1.0f - w);  // at::lerp
   for (long long i = threadIdx.x; i < n; i += QT) ac[i] = fminf(ac[i], quant);

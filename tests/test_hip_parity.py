@@ -1675,7 +1675,7 @@ def test_debiased_resample_at_end_golden(pa, golden):
     assert rel(x, g["x_final"]) < 3e-3
 
 
-@pytest.mark.parametrize("n,chunk", [(12, 12), (1000, 1000), (65536, 512), (65536, 65536), (777, 100), (5, 1)])
+@pytest.mark.parametrize("n,chunk", [(12, 12), (1000, 1000), (65536, 512), (65536, 65536), (777, 100), (5, 1), (4096, 1024), (4100, 1025)])
 def test_quantile_clamp_kernel(pa, n, chunk):
     """K11 against torch.quantile (CPU) per chunk: exact order statistics, torch's lerp."""
     gen = torch.Generator().manual_seed(n + chunk)
