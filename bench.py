@@ -501,16 +501,18 @@ def main():
     # With the debiased leg (0.2 s of back-to-back MFMA launches) immediately before, the W warm-up steps and the K
     # timed steps run at the sustained clock, which is what a 1 000-step trajectory sees.  The timed region itself is
     # unchanged: W untimed steps, barrier + synchronize, exactly K steps, synchronize + barrier.
+    # EVERY rank runs them (rank 0 reports): with several ranks the time is the slowest rank's, and a rank that skipped
+    # the legs would enter the timed region cold.
     force_rl = debiased = None
-    if rank == 0 and args.force_evals > 0 and not args.force_last:
+    if args.force_evals > 0 and not args.force_last:
         energy = make_target(pita_amd, cfg, dev)
         xf = x.clone() if cfg["target"] != "ff" else pita_amd.Prior(scale=1.0, n_particles=n, spatial_dim=d, device=dev,
                                                                     seed=3).sample(B)
         force_rl = force_roofline(pita_amd, cfg, energy, xf, dev, args.force_evals)
         del xf
-    if rank == 0 and world == 1 and not args.no_debiased and not args.force_last:
+    if not args.no_debiased and not args.force_last:
         Bd = B if n <= 22 else min(B, 4096)
-        debiased = debiased_leg(pita_amd, net, cfg, dev, Bd, with_cpu=not args.no_cpu_baseline and n <= 13)
+        debiased = debiased_leg(pita_amd, net, cfg, dev, Bd, with_cpu=world == 1 and not args.no_cpu_baseline and n <= 13)
     ad2cat = None
     if rank == 0 and world == 1 and args.config == "aldp22" and not args.force_last:
         # the reference's alanine-dipeptide EGNN (egnn_dynamics_ad2_cat.yaml: hidden 64 x 5 layers, one-hot atom types) on
@@ -660,10 +662,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_walkers, steps)
         else:
             out["cpu_baseline"] = None
-        if world == 1 and not args.no_debiased:
+        if not args.no_debiased:
             if debiased is None:
                 Bd = B if n <= 22 else min(B, 4096)
-                debiased = debiased_leg(pita_amd, net, cfg, dev, Bd, with_cpu=not args.no_cpu_baseline and n <= 13)
+                debiased = debiased_leg(pita_amd, net, cfg, dev, Bd,
+                                        with_cpu=world == 1 and not args.no_cpu_baseline and n <= 13)
             xc = debiased.pop("_x48", None)
             if xc is not None:
                 debiased["cpu_baseline"] = debiased_cpu_baseline(net, cfg, xc)
