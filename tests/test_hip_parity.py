@@ -185,6 +185,14 @@ def test_ring_kernels_edge_cases(pa, name):
         lpo, fo = orc(x.cpu().double(), T, ef)
         np.testing.assert_allclose(lp.cpu().numpy(), lpo.numpy(), rtol=2e-5, atol=2e-5)
         assert rel(f, fo) < 2e-5
+    if name == "lj55":  # non-unit rm / eps / oscillator scale through the C ABI (the plug-in class always passes 1)
+        lp = torch.empty(40, device="cuda")
+        f = torch.empty_like(x)
+        pa._lib.check(pa._lib.lib().pita_lj_logp_force(x.data_ptr(), lp.data_ptr(), f.data_ptr(), 40, 55, 3, 1.7, 0.8, 1e-6, 0.7, 1.1,
+                                                       0.5, pa._lib.stream_ptr()), "pita_lj_logp_force")
+        lpo, fo = O.lj_logp_force(x.cpu().double(), 55, 3, temperature=1.7, energy_factor=0.8, eps=0.7, rm=1.1, osc_scale=0.5)
+        np.testing.assert_allclose(lp.cpu().numpy(), lpo.numpy(), rtol=2e-5, atol=2e-5)
+        assert rel(f, fo) < 2e-5
     xb = x.clone()
     xb[17, 3] = float("nan")
     lpb, fb = e(xb, return_force=True)
