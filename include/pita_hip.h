@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PITA_ABI_VERSION 4
+#define PITA_ABI_VERSION 5
 
 enum {
   PITA_OK = 0,
@@ -122,7 +122,11 @@ int pita_dw_mala(float* x, float* logp, const float* noise /*nullable*/, const f
  * replaces EGNN_dynamics_AD2_cat.forward (pita/src/models/components/egnn_dynamics_ad2_cat.py:157-203; the
  * alanine-dipeptide backbone of configs/model/net/egnn_dynamics_ad2_cat.yaml: hidden 64 x 5 layers, one-hot atom-type
  * node features concatenated with t and beta) over EGNN / E_GCL of egnn.py:108-346, and ScoreNet's EDM preconditioning
- * (score_net.py:13-43).  Vector-pipe kernel (lane = hidden feature), fp32 FMA chains: csrc/egnn_wide_kernel.hip.
+ * (score_net.py:13-43).  Two kernels serve the handle: a matrix-pipe kernel (csrc/egnn_wide_mfma_kernel.hip: 64 x 64 dense
+ * layers as 2 x 2 blocks of 32 x 32 x 16 f16 MFMAs on the fp32-equivalent two-piece split) for the particle systems it is
+ * instantiated for (22 atoms x 3), and a vector-pipe kernel (csrc/egnn_wide_kernel.hip: lane = hidden feature, fp32 FMA
+ * chains) for every other shape -- which also recomputes, behind the matrix-pipe launch, exactly those walkers whose
+ * result came out non-finite (an activation beyond the f16 range).
  * weights: the module's state_dict flattened in registration order (embedding, embedding_out, gcl_0 .. gcl_{L-1}, like
  * pita_egnn_create); h_initial: host [n_particles, n_static] static node features (the reference's get_h_initial()). */
 typedef struct pita_egnn_wide pita_egnn_wide_t;
@@ -137,6 +141,8 @@ int64_t pita_egnn_wide_num_weights(const pita_egnn_wide_config* cfg);
 int pita_egnn_wide_create(pita_egnn_wide_t** out, const pita_egnn_wide_config* cfg, const float* weights,
                           int64_t n_weights, const float* h_initial /* host; nullable when n_static == 0 */);
 int pita_egnn_wide_destroy(pita_egnn_wide_t* net);
+/* 1 when pita_egnn_wide_eval runs this handle on the matrix-pipe kernel, 0 when on the vector-pipe kernel alone */
+int pita_egnn_wide_uses_matrix_pipe(const pita_egnn_wide_t* net);
 /* what = 0: vel[B, n*d] = backbone(t[B], x[B, n*d], beta[B]) (mean-free); 1: denoiser D_theta(h = t, x); 2: score */
 int pita_egnn_wide_eval(pita_egnn_wide_t* net, int what, const float* t, const float* x, const float* beta /*nullable*/,
                         float* out, int64_t B, void* stream);

@@ -1,0 +1,27 @@
+// Native handle behind pita_egnn_wide_t, shared by the two kernels that serve it: the vector-pipe kernel
+// (egnn_wide_kernel.hip: any hidden_nf <= 64, any particle count <= 64) and the matrix-pipe kernel
+// (egnn_wide_mfma_kernel.hip: the particle systems it is instantiated for).
+#pragma once
+#include "common.h"
+
+struct pita_egnn_wide {
+  pita_egnn_wide_config cfg;
+  float* d_w = nullptr;        // vector-pipe kernel: packed weights, see WideLayer
+  float* d_estatic = nullptr;  // [n][64] embedding of the static node features + embedding bias, natural feature order
+  int device = -1;
+  int n_cu = 256;
+  // matrix-pipe kernel (null / 0 when the particle system has no instantiation)
+  unsigned* d_m16h = nullptr;  // [L][7 matrices][2 x 2 blocks] f16 two-piece fragments
+  float* d_vecs64 = nullptr;   // embedding vectors + per-layer vectors, fragment order, f16-path scales folded in
+  float* d_est64 = nullptr;    // [n][64] as d_estatic, fragment order
+  const void* shape64 = nullptr;
+};
+
+namespace pita {
+// packs and uploads the matrix-pipe kernel's weights when the particle system has an instantiation (leaves
+// net->shape64 null otherwise); w: the flattened state_dict (pita_egnn_wide_create), he: host [n][64] static embedding
+int wide64_prepare(pita_egnn_wide* net, const float* w, const float* he);
+int wide64_launch(pita_egnn_wide* net, int what, const float* t, const float* x, const float* beta, float* out,
+                  long long B, hipStream_t stream);
+void wide64_release(pita_egnn_wide* net);
+}  // namespace pita

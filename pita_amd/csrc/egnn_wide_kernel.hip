@@ -18,15 +18,9 @@
 // i-major, j ascending: the reference's index_add order, so per-node sums accumulate in the same order.
 // Throughput is that of the vector pipe (~8e5 walker-forwards/s for 22 atoms, 64 x 5): the LJ / DW4 configurations
 // stay on the MFMA kernel.
-#include "common.h"
+#include <cstdlib>
 
-struct pita_egnn_wide {
-  pita_egnn_wide_config cfg;
-  float* d_w = nullptr;        // packed weights, see WideLayer
-  float* d_estatic = nullptr;  // [n][64] embedding of the static node features + embedding bias
-  int device = -1;
-  int n_cu = 256;
-};
+#include "egnn_wide_common.h"
 
 namespace pita {
 
@@ -54,6 +48,7 @@ struct WideParams {
   const float* t;
   const float* beta;
   float* out;
+  int only_bad;  // recompute only the walkers whose `out` holds a non-finite value (repair pass behind the matrix-pipe kernel)
 };
 
 namespace {
@@ -109,6 +104,11 @@ __global__ void __launch_bounds__(256) egnn_wide_kernel(WideParams p) {
   float* posn = pos0 + n * 4;            // [n][4] positions leaving the layer
   const long long nw = (long long)gridDim.x * waves;
   for (long long w = (long long)blockIdx.x * waves + wave; w < p.B; w += nw) {
+    if (p.only_bad) {
+      bool bad = false;
+      for (int q = lane; q < n * DIM; q += 64) bad = bad || !__builtin_isfinite(p.out[w * n * DIM + q]);
+      if (!__any(bad)) continue;  // wave-uniform
+    }
     const float tv = p.t[w];
     const float bet = p.has_beta ? p.beta[w] : 0.f;
     float c_s = 0.f, c_in = 1.f, c_out = 1.f, tfeat = tv, hval = 1.f;
@@ -297,8 +297,8 @@ extern "C" int pita_egnn_wide_create(pita_egnn_wide_t** out, const pita_egnn_wid
   if (e == hipSuccess) e = hipMemcpy(net->d_w, hw, n_w * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(net->d_estatic, he, (size_t)n * WIDE_HP * sizeof(float), hipMemcpyHostToDevice);
   delete[] hw;
-  delete[] he;
   if (e != hipSuccess) {
+    delete[] he;
     (void)hipFree(net->d_w);
     (void)hipFree(net->d_estatic);
     delete net;
@@ -310,12 +310,26 @@ extern "C" int pita_egnn_wide_create(pita_egnn_wide_t** out, const pita_egnn_wid
     net->device = dev;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) net->n_cu = prop.multiProcessorCount;
   }
+  const int rc64 = wide64_prepare(net, w, he);
+  delete[] he;
+  if (rc64 != PITA_OK) {
+    (void)hipFree(net->d_w);
+    (void)hipFree(net->d_estatic);
+    delete net;
+    return rc64;
+  }
   *out = net;
   return PITA_OK;
 }
 
+extern "C" int pita_egnn_wide_uses_matrix_pipe(const pita_egnn_wide_t* net) {
+  // PITA_WIDE_NO_MFMA (read at every call): A/B against the vector-pipe kernel
+  return (net && net->shape64 && getenv("PITA_WIDE_NO_MFMA") == nullptr) ? 1 : 0;
+}
+
 extern "C" int pita_egnn_wide_destroy(pita_egnn_wide_t* net) {
   if (!net) return PITA_OK;
+  wide64_release(net);
   (void)hipFree(net->d_w);
   (void)hipFree(net->d_estatic);
   delete net;
@@ -339,12 +353,19 @@ extern "C" int pita_egnn_wide_eval(pita_egnn_wide_t* net, int what, const float*
   p.attention = net->cfg.attention; p.tanh_on = net->cfg.tanh; p.has_beta = net->cfg.condition_beta;
   p.coord_scale = net->cfg.coords_range / (float)net->cfg.n_layers;
   p.B = B; p.mode = what; p.x = x; p.t = t; p.beta = beta; p.out = out;
+  int rc = PITA_OK;
+  // matrix-pipe kernel first where the particle system has one; the vector-pipe kernel then recomputes the walkers whose
+  // result came out non-finite (an activation beyond the f16 range) and returns at once for all others
+  if (pita_egnn_wide_uses_matrix_pipe(net)) {
+    rc = wide64_launch(net, what, t, x, beta, out, B, (hipStream_t)stream);
+    p.only_bad = 1;
+  }
   const size_t per_wave = sizeof(float) * (size_t)(3 * p.n * WIDE_HP + 3 * p.n * 4);
   int waves = 4;
   while (waves > 1 && per_wave * waves > 72 * 1024) waves >>= 1;  // two blocks per CU inside the 160 KB
-  int rc = PITA_OK;
   auto kernel = p.H <= 32 ? egnn_wide_kernel<32> : egnn_wide_kernel<64>;
-  if (per_wave * waves > 150 * 1024) {
+  if (rc != PITA_OK) {
+  } else if (per_wave * waves > 150 * 1024) {
     rc = fail(PITA_EUNSUPPORTED, "pita_egnn_wide_eval: %d particles need %zu B of LDS per wave", p.n, per_wave);
   } else if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(per_wave * waves)) != hipSuccess) {

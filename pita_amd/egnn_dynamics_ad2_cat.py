@@ -1,13 +1,13 @@
 """EGNN backbone of the alanine-dipeptide class (hidden 64 x 5 layers, one-hot atom-type node features) on the HIP
-vector-pipe kernel.
+kernels of ``pita_egnn_wide_eval``: the matrix-pipe kernel for 22 atoms, the vector-pipe kernel for every other shape.
 
 Mirror of ``EGNN_dynamics_AD2_cat`` (pita/src/models/components/egnn_dynamics_ad2_cat.py:11-203; the ``_target_`` of
 ``configs/model/net/egnn_dynamics_ad2_cat.yaml``): same constructor arguments and defaults, same parameter names and
 creation order (``egnn.embedding``, ``egnn.embedding_out``, ``egnn.gcl_<l>.{edge_mlp,node_mlp,coord_mlp,att_mlp}``: a
 seeded construction gives the reference's weights and its ``state_dict`` loads unchanged), same
 ``forward(t, xs, beta) -> vel`` contract.  Node features are ``[h_initial (static one-hot rows), t, beta]`` (:157-184);
-the arithmetic of ``EGNN.forward`` / ``E_GCL`` (egnn.py:108-346) lives in pita_amd/csrc/egnn_wide_kernel.hip
-(``pita_egnn_wide_eval``).  ``edm`` lets ``ScoreNet`` evaluate the EDM preconditioning in the same launch.
+the arithmetic of ``EGNN.forward`` / ``E_GCL`` (egnn.py:108-346) lives in pita_amd/csrc/egnn_wide_mfma_kernel.hip and
+pita_amd/csrc/egnn_wide_kernel.hip (``pita_egnn_wide_eval``).  ``edm`` lets ``ScoreNet`` evaluate the EDM preconditioning in the same launch.
 """
 import ctypes
 
@@ -78,6 +78,10 @@ class EGNN_dynamics_AD2_cat(nn.Module):
                                                             h0.ctypes.data_as(ctypes.c_void_p)), "pita_egnn_wide_create")
             self._handle, self._handle_key = h, key
         return self._handle
+
+    def uses_matrix_pipe(self, device):
+        """True when evaluations on ``device`` run on the MFMA kernel (22 atoms x 3 unless PITA_WIDE_NO_MFMA is set)."""
+        return bool(_lib.lib().pita_egnn_wide_uses_matrix_pipe(self._native(torch.device(device))))
 
     def __getstate__(self):
         state = self.__dict__.copy()

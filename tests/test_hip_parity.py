@@ -270,9 +270,10 @@ def test_egnn_golden(pa, golden, name, tag, wfile, precision):
 
 @pytest.mark.parametrize("tag,L,tanh,att", [("h64", 5, True, True), ("h48", 2, False, False)])
 def test_egnn_ad2cat_golden(pa, golden, tag, L, tanh, att):
-    """EGNN_dynamics_AD2_cat on the vector-pipe kernel (pita_egnn_wide_eval; hidden 64 x 5 layers and a hidden-48 net
-    that exercises the padding): backbone output within 4x the reference's own fp32-vs-fp64 error, denoiser and score
-    through ScoreNet's fused EDM path, batch edges, and the per-step sampler path of the integrator against the oracle."""
+    """EGNN_dynamics_AD2_cat through pita_egnn_wide_eval (22 atoms: the matrix-pipe kernel; hidden 64 x 5 layers and a
+    hidden-48 net that exercises the padding): backbone output within 4x the reference's own fp32-vs-fp64 error, denoiser
+    and score through ScoreNet's fused EDM path, batch edges, and the per-step sampler path of the integrator against
+    the oracle."""
     from pita_amd.egnn_dynamics_ad2_cat import EGNN_dynamics_AD2_cat
 
     g = golden(f"egnn_ad2cat_{tag}_fwd.npz")
@@ -290,6 +291,7 @@ def test_egnn_ad2cat_golden(pa, golden, tag, L, tanh, att):
     print(f"[ad2cat/{tag}] err_hip_vs_fp64={err_hip:.3e} err_ref_vs_fp64={err_ref:.3e}")
     assert err_hip < max(4 * err_ref, 2e-6), (err_hip, err_ref)
     assert rel(F, g["F"]) < max(2e-5, 6 * err_ref)
+    assert net.uses_matrix_pipe("cuda:0")
     sn = pa.ScoreNet(net)
     assert rel(sn.denoiser(h, x, beta), g["D"]) < 2e-6
     sc = sn(h, x, beta).cpu().numpy()
@@ -327,6 +329,53 @@ def test_egnn_ad2cat_golden(pa, golden, tag, L, tanh, att):
                           lambda t, xc: O.f_not_debiased(bb, osched, ogam, t, xc, 1.3), osched.g, lambda i, shp: noise[i],
                           22, 3)["x"]
     assert torch.isfinite(ref).all() and rel(xh, ref) < 1e-4
+
+
+def test_egnn_ad2cat_matrix_pipe_vs_vector_pipe(pa, golden, monkeypatch):
+    """The two kernels behind pita_egnn_wide_eval on the same inputs: the matrix-pipe kernel (f16 two-piece split) agrees
+    with the vector-pipe kernel (fp32 FMA chains) to fp32 rounding in all three modes and at ragged batch sizes (1 .. 9
+    walkers: partial groups of 4); walkers whose activations leave the f16 range come back from the vector-pipe repair
+    pass with exactly its values, their neighbours in the batch untouched."""
+    from pita_amd.egnn_dynamics_ad2_cat import EGNN_dynamics_AD2_cat
+
+    g = golden("egnn_ad2cat_h64_fwd.npz")
+    w = {k[2:]: T(v) for k, v in g.items() if k.startswith("w.")}
+    net = EGNN_dynamics_AD2_cat(22, 3, hidden_nf=64, n_layers=5, tanh=True, attention=True, condition_beta=True)
+    net.load_state_dict(w)
+    gen = torch.Generator().manual_seed(11)
+    B = 37
+    x = (torch.randn(B, 66, generator=gen) * 2.0).cuda()
+    h = (torch.rand(B, generator=gen) * 4.0 + 0.05).cuda()
+    beta = (torch.rand(B, generator=gen) + 0.5).cuda()
+
+    def both(fn):
+        a = fn()
+        monkeypatch.setenv("PITA_WIDE_NO_MFMA", "1")
+        try:
+            assert not net.uses_matrix_pipe("cuda:0")
+            b = fn()
+        finally:
+            monkeypatch.delenv("PITA_WIDE_NO_MFMA")
+        assert net.uses_matrix_pipe("cuda:0")
+        return a, b
+
+    for what in (0, 1, 2):
+        fn = (lambda: net(h, x, beta)) if what == 0 else (lambda: net.edm(what, h, x, beta))
+        a, b = both(fn)
+        assert torch.isfinite(a).all() and rel(a, b) < 2e-6, (what, rel(a, b))
+    full = net(h, x, beta)
+    for n in (1, 2, 3, 4, 5, 9):
+        assert torch.equal(net(h[:n], x[:n], beta[:n]), full[:n]), n
+    # out-of-range walkers: beta = 1e7 drives the node features beyond 65504 in the first dense layer
+    hot = torch.tensor([3, 4, 17, 36])
+    beta2 = beta.clone()
+    beta2[hot.cuda()] = 1.0e7
+    a, b = both(lambda: net(h, x, beta2))
+    assert torch.equal(a[hot].view(torch.int32), b[hot].view(torch.int32))  # bitwise (holds for non-finite values too)
+    assert torch.isfinite(a[hot]).all(), "the vector-pipe kernel handles this range in fp32"
+    keep = torch.ones(B, dtype=torch.bool)
+    keep[hot] = False
+    assert torch.equal(a[keep], full[keep])
 
 
 def test_f16x2_out_of_range_walkers_are_recomputed_on_the_bf16_path(pa, golden):
