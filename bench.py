@@ -516,7 +516,7 @@ def main():
     ad2cat = None
     if rank == 0 and world == 1 and args.config == "aldp22" and not args.force_last:
         # the reference's alanine-dipeptide EGNN (egnn_dynamics_ad2_cat.yaml: hidden 64 x 5 layers, one-hot atom types) on
-        # the vector-pipe kernel, through the integrator's per-step path (fused EDM evaluation + pita_em_step)
+        # the matrix-pipe wide kernel, through the integrator's per-step path (fused EDM evaluation + pita_em_step)
         from pita_amd.egnn_dynamics_ad2_cat import EGNN_dynamics_AD2_cat
 
         torch.manual_seed(12345)
@@ -543,9 +543,13 @@ def main():
         torch.cuda.synchronize()
         dt64 = (time.perf_counter() - t0) / 8
         mac = 5 * (n * (n - 1) * ((2 * 64 + 2) * 64 + 2 * 64 * 64 + 2 * 64) + n * 3 * 64 * 64)
-        ad2cat = {"backbone": "EGNN_dynamics_AD2_cat hidden 64 x 5 layers (pita_egnn_wide_eval, fp32 vector pipe)",
+        on_mfma = net64.uses_matrix_pipe(dev)
+        ad2cat = {"backbone": "EGNN_dynamics_AD2_cat hidden 64 x 5 layers (pita_egnn_wide_eval, "
+                              + ("f16 two-piece MFMA, matrix pipe)" if on_mfma else "fp32 vector pipe)"),
                   "walkers": B, "ms_per_step": dt64 * 1e3, "value": B / dt64, "unit": "walker-steps/s",
-                  "algorithmic_TFLOPs": 2 * mac * B / dt64 / 1e12, "frac_of_plain_fma_rate_78.6": 2 * mac * B / dt64 / 78.65e12,
+                  "algorithmic_TFLOPs": 2 * mac * B / dt64 / 1e12,
+                  ("frac_of_dense_f16_mfma_peak_2500" if on_mfma else "frac_of_plain_fma_rate_78.6"):
+                      2 * mac * B / dt64 / (2500e12 if on_mfma else 78.65e12),
                   "finite": bool(torch.isfinite(xa).all())}
         del xa
     run(0, W)  # warm-up (also builds the native handle)

@@ -58,6 +58,9 @@ struct Wide64Cfg {
   }
 };
 
+#ifndef PITA_WIDE64_AGPR_WEIGHTS
+#define PITA_WIDE64_AGPR_WEIGHTS 1
+#endif
 // the four 32 x 32 blocks of a 64 x 64 matrix, resident
 struct W64Mat {
   WFrag<2> b[2][2];
@@ -66,6 +69,20 @@ struct W64Mat {
     for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) b[ob][kb].load(nullptr, layer, mat * 4 + ob * 2 + kb, lane);
+  }
+  // park the fragments in accumulation registers: the MFMA reads its A operand from there directly, so the resident
+  // matrices cost no VALU-visible registers (left to itself the allocator keeps them in VGPRs and spills around them)
+  __device__ __forceinline__ void to_agpr() {
+#if PITA_WIDE64_AGPR_WEIGHTS
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+          for (int st = 0; st < 2; ++st) asm volatile("" : "+a"(b[ob][kb].w[pc][st]));
+#endif
   }
   __device__ __forceinline__ void mul(const f32x16 (&in)[2], f32x16 (&acc)[2]) const {
     u32x4 xs[2][2][2];
@@ -99,7 +116,30 @@ __device__ __forceinline__ void lds_store16(float* dst, const f32x16& v) {
   for (int q = 0; q < 4; ++q) d[q] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
 }
 
-template <int N, int DIM, int G, int WAVES>
+// accurate_tanh (common.h) with both branches pinned: left alone the compiler turns the select back into a divergent
+// branch (the exp / rcp side is "expensive"), which splits the edge loop's basic block.  Same values.
+__device__ __forceinline__ float tanh_select(float v) {
+  const float a = fabsf(v);
+  const float v2 = v * v;
+  float p = 62.0f / 2835.0f;
+  p = fmaf(p, v2, -17.0f / 315.0f);
+  p = fmaf(p, v2, 2.0f / 15.0f);
+  p = fmaf(p, v2, -1.0f / 3.0f);
+  p = fmaf(p, v2, 1.0f);
+  float small = v * p;
+  const float e = __builtin_amdgcn_exp2f(2.88539008177792681f * a);
+  float big = copysignf(1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e), v);
+  asm volatile("" : "+v"(small), "+v"(big));
+  return a < 0.25f ? small : big;
+}
+
+// ATT / TANH: the network's attention gate and tanh-bounded coordinate head as compile-time switches: the edge loop is
+// one basic block (with the branch-free tanh above and the branch-free partner index below: 14.8 -> 13.9 ms per 65 536
+// forwards).
+// Measured and dropped: the edge loop as a software pipeline (two edges in flight, the 24 MFMAs of a dense layer dealt
+// out between the vector stage of the neighbouring edge with sched_group_barrier, 1 / 2 / 4 / 8 regions per stage):
+// 14.7-15.4 ms -- a lone wave's stalls are dependent-instruction latencies, which the extra live state makes worse.
+template <int N, int DIM, int G, int WAVES, bool ATT, bool TANH>
 __global__ void __launch_bounds__(WAVES * 64, 1) egnn_wide64_kernel(Wide64Params p) {
   using C = Wide64Cfg<N, DIM, G, WAVES>;
   constexpr int NT = C::NT;
@@ -191,6 +231,8 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_wide64_kernel(Wide64Params
       W64Mat w2f, wc1f;
       w2f.load(ml, WM_W2, lane);
       wc1f.load(ml, WM_WC1, lane);
+      w2f.to_agpr();
+      wc1f.to_agpr();
       const float a_re0 = vbase[WV_WRE * 64 + lane], a_re1 = vbase[WV_WRE * 64 + 64 + lane];
       const float b_att = vbase[WV_COUNT * 64];
 
@@ -210,11 +252,12 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_wide64_kernel(Wide64Params
           p0own[k] = pos0[col[T] * DIM + k];
         }
         const int cbase = col[T] - nodei[T];
+        const int live = valid[T] ? 1 : 0;  // columns beyond the group's walkers pair with themselves (no select per edge)
         for (int dd = 1; dd < N; ++dd) {
           asm volatile("" ::: "memory");  // keep the per-edge LDS vector loads inside the loop
-          int j = nodei[T] + dd;
+          int j = nodei[T] + dd * live;
           j = (j >= N) ? j - N : j;
-          const int cj = (col[T] < ncol) ? cbase + j : col[T];
+          const int cj = cbase + j;
           float df[DIM], radial = 0.f, ea = 0.f;  // coord2radial (egnn.py E_GCL), frozen edge attribute (ad2_cat.py:186)
 #pragma unroll
           for (int k = 0; k < DIM; ++k) {
@@ -235,7 +278,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_wide64_kernel(Wide64Params
           w2f.mul(m, z);
           silu16_acc(z[0]);
           silu16_acc(z[1]);
-          if (p.attention) {
+          if (ATT) {
             const float s = dot16(lds_vec16(vl + WV_WATT * 64), z[0]) + dot16(lds_vec16(vl + WV_WATT * 64 + 32), z[1]);
             const float att = fast_sigmoid(xhalf_sum(s) + b_att);
             z[0] *= att;
@@ -250,7 +293,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_wide64_kernel(Wide64Params
           silu16_acc(c1[0]);
           silu16_acc(c1[1]);
           float cs = xhalf_sum(dot16(lds_vec16(vl + WV_WC2 * 64), c1[0]) + dot16(lds_vec16(vl + WV_WC2 * 64 + 32), c1[1]));
-          if (p.tanh_on) cs = accurate_tanh(cs) * p.coord_scale;
+          if (TANH) cs = tanh_select(cs) * p.coord_scale;
           const float inrm = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(radial + 1e-8f) + 1.0f);
 #pragma unroll
           for (int k = 0; k < DIM; ++k) xacc[k] = fmaf(df[k] * inrm, cs, xacc[k]);
@@ -306,13 +349,16 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_wide64_kernel(Wide64Params
 
 struct Wide64Shape {
   int n, dim, G, waves;
-  void (*kernel)(Wide64Params);
+  void (*kernel[2][2])(Wide64Params);  // [attention][tanh]
   size_t (*lds_bytes)(int);
 };
 template <int N, int DIM, int G, int WAVES>
 static size_t wide64_lds_of(int L) { return Wide64Cfg<N, DIM, G, WAVES>::lds_bytes(L); }
-#define PITA_WIDE64_SHAPE(N, DIM, G, WAVES) \
-  Wide64Shape { N, DIM, G, WAVES, egnn_wide64_kernel<N, DIM, G, WAVES>, wide64_lds_of<N, DIM, G, WAVES> }
+#define PITA_WIDE64_SHAPE(N, DIM, G, WAVES)                                                                         \
+  Wide64Shape { N, DIM, G, WAVES,                                                                                  \
+                {{egnn_wide64_kernel<N, DIM, G, WAVES, false, false>, egnn_wide64_kernel<N, DIM, G, WAVES, false, true>}, \
+                 {egnn_wide64_kernel<N, DIM, G, WAVES, true, false>, egnn_wide64_kernel<N, DIM, G, WAVES, true, true>}}, \
+                wide64_lds_of<N, DIM, G, WAVES> }
 // alanine dipeptide (22 atoms: 4 walkers = 88 of 96 columns)
 static const Wide64Shape kWide64Shapes[] = {PITA_WIDE64_SHAPE(22, 3, 4, 4)};
 
@@ -415,8 +461,8 @@ int wide64_prepare(pita_egnn_wide* net, const float* w, const float* he) {
   if (e == hipSuccess) e = hipMemcpy(net->d_vecs64, hv, n_v * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(net->d_est64, hes, (size_t)n * 64 * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(shape->kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)shape->lds_bytes(L));
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(shape->kernel[cfg.attention ? 1 : 0][cfg.tanh ? 1 : 0]),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shape->lds_bytes(L));
   delete[] hm;
   delete[] hv;
   delete[] hes;
@@ -449,7 +495,7 @@ int wide64_launch(pita_egnn_wide* net, int what, const float* t, const float* x,
   const long long ngroups = (B + s->G - 1) / s->G;
   const long long want = (ngroups + s->waves - 1) / s->waves, cap = net->n_cu;  // one 4-wave block per CU
   const unsigned grid = (unsigned)(want < cap ? want : cap);
-  hipLaunchKernelGGL(s->kernel, dim3(grid), dim3(s->waves * 64), s->lds_bytes(p.L), stream, p);
+  hipLaunchKernelGGL(s->kernel[p.attention ? 1 : 0][p.tanh_on ? 1 : 0], dim3(grid), dim3(s->waves * 64), s->lds_bytes(p.L), stream, p);
   PITA_LAUNCH_CHECK();
   return PITA_OK;
 }
