@@ -318,6 +318,23 @@ __device__ __forceinline__ float xhalf_sum(float v) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// accurate_tanh (common.h) with both branches pinned: left alone the compiler turns the select back into a divergent
+// branch (the exp / rcp side is "expensive"), which splits the edge loop's basic block.  Same values.
+__device__ __forceinline__ float tanh_select(float v) {
+  const float a = fabsf(v);
+  const float v2 = v * v;
+  float p = 62.0f / 2835.0f;
+  p = fmaf(p, v2, -17.0f / 315.0f);
+  p = fmaf(p, v2, 2.0f / 15.0f);
+  p = fmaf(p, v2, -1.0f / 3.0f);
+  p = fmaf(p, v2, 1.0f);
+  float small = v * p;
+  const float e = __builtin_amdgcn_exp2f(2.88539008177792681f * a);
+  float big = copysignf(1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e), v);
+  asm volatile("" : "+v"(small), "+v"(big));
+  return a < 0.25f ? small : big;
+}
+
 }  // namespace pita
 
 // makes `device` current for the lifetime of the guard (no-op when it already is)

@@ -107,9 +107,27 @@ __device__ __forceinline__ void lds_add16(float* dst, const f32x16& v) {
   }
 }
 
-template <int N, int DIM, int G, int WAVES>
+#ifndef PITA_VJP_AGPR_WEIGHTS
+#define PITA_VJP_AGPR_WEIGHTS 1
+#endif
+// park a resident weight fragment in accumulation registers: the MFMA reads its A operand from there directly
+__device__ __forceinline__ void frag_to_agpr(WFrag<1>& f) {
+#if PITA_VJP_AGPR_WEIGHTS
+#pragma unroll
+  for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+    for (int st = 0; st < 2; ++st) asm volatile("" : "+a"(f.w[pc][st]));
+#endif
+}
+
+// FIXED: attention gate, tanh-bounded coordinate head and the h-derivative output are compile-time "on" (every reference
+// configuration of the debiased regime): the edge loops carry no run-time branch.  FIXED = false keeps them run-time.
+template <int N, int DIM, int G, int WAVES, bool FIXED>
 __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
   using C = VjpCfg<N, DIM, G, WAVES>;
+  const bool att_on = FIXED ? true : (p.attention != 0);
+  const bool tanh_on = FIXED ? true : (p.tanh_on != 0);
+  const bool want_h = FIXED ? true : (p.dot_h != nullptr);
   constexpr int NT = C::NT;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int L = p.n_layers;
@@ -211,6 +229,8 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
       WFrag<1> w2f, wc1f;
       w2f.load(nullptr, mats16, M_W2, lane);
       wc1f.load(nullptr, mats16, M_WC1, lane);
+      frag_to_agpr(w2f);
+      frag_to_agpr(wc1f);
       const float a_re = lds[VEC_EMB_F + l * VEC_LAYER_F + V_WRE * EH + lane];
       const float b_att = lds[VEC_EMB_F + l * VEC_LAYER_F + V_COUNT * EH];
 #pragma unroll
@@ -227,11 +247,12 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
 #pragma unroll
         for (int k = 0; k < DIM; ++k) xacc[k] = 0.f;
         const int cbase = col[T] - nodei[T];
+        const int live = valid[T] ? 1 : 0;  // columns beyond the group's walkers pair with themselves
         for (int dd = 1; dd < N; ++dd) {
           asm volatile("" ::: "memory");
-          int j = nodei[T] + dd;
+          int j = nodei[T] + dd * live;
           j = (j >= N) ? j - N : j;
-          const int cj = (col[T] < ncol) ? cbase + j : col[T];
+          const int cj = cbase + j;
           float df[DIM], radial = 0.f, ea = 0.f;
 #pragma unroll
           for (int k = 0; k < DIM; ++k) {
@@ -245,7 +266,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
           silu16(z);
           z = w2f.mul(z, lds_vec16(vl + V_B2 * EH));
           silu16(z);
-          if (p.attention) {
+          if (att_on) {
             const float att = fast_sigmoid(xhalf_sum(dot16(lds_vec16(vl + V_WATT * EH), z)) + b_att);
             z *= att;
           }
@@ -253,7 +274,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
           f32x16 c1 = wc1f.mul(z, lds_vec16(vl + V_BC1 * EH));
           silu16(c1);
           float cs = xhalf_sum(dot16(lds_vec16(vl + V_WC2 * EH), c1));
-          if (p.tanh_on) cs = accurate_tanh(cs) * p.coord_scale;
+          if (tanh_on) cs = tanh_select(cs) * p.coord_scale;
           const float inv = 1.0f / (sqrtf(radial + 1e-8f) + 1.0f);
 #pragma unroll
           for (int k = 0; k < DIM; ++k) xacc[k] = fmaf(df[k] * inv, cs, xacc[k]);
@@ -304,7 +325,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
         for (int q = 0; q < N; ++q) { s += scr[(cb + q) * DIM + k]; sc += scr[C::POS_F + (cb + q) * DIM + k]; }
         const float F = (posi[T][k] - p0i[T][k]) - s / (float)N;
         if (p.out && valid[T] && hh == 0) p.out[(walker0 * N + col[T]) * DIM + k] = fmaf(c_s[T], xin[T][k], c_out[T] * F);
-        if (p.dot_h && valid[T] && hh == 0) {  // explicit h-dependence of D = c_s(h) x + c_out(h) F
+        if (want_h && valid[T] && hh == 0) {  // explicit h-dependence of D = c_s(h) x + c_out(h) F
           const float op = 1.0f + hvv[T];
           const float dcs = -c_s[T] * c_s[T];                               // d/dh 1/(1+h)
           const float dcin = -0.5f * c_in[T] / op;                          // d/dh (1+h)^-1/2
@@ -360,6 +381,10 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
       wc1f.load(nullptr, mats16, M_WC1, lane);
       w2t.load(nullptr, mats16, M_W2T, lane);
       wc1t.load(nullptr, mats16, M_WC1T, lane);
+      frag_to_agpr(w2f);
+      frag_to_agpr(wc1f);
+      frag_to_agpr(w2t);
+      frag_to_agpr(wc1t);
       const float a_re = lds[VEC_EMB_F + l * VEC_LAYER_F + V_WRE * EH + lane];
       const float b_att = lds[VEC_EMB_F + l * VEC_LAYER_F + V_COUNT * EH];
 #pragma unroll
@@ -386,7 +411,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
           { f32x16 yv, gv; silu_grad16(zn, yv, gv); znb *= gv; }
           wt.load(nullptr, mats16, M_WN1BT, lane);
           aggb = wt.mul(znb, zero16);
-          if (l > 0 || p.dot_h) {
+          if (l > 0 || want_h) {
             wt.load(nullptr, mats16, M_WN1AT, lane);
             hb[T] = wt.mul(znb, hb[T]);
           }
@@ -396,11 +421,12 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
 #pragma unroll
         for (int k = 0; k < DIM; ++k) pacc[k] = 0.f;
         const int cbase = col[T] - nodei[T];
+        const int live = valid[T] ? 1 : 0;  // columns beyond the group's walkers pair with themselves
         for (int dd = 1; dd < N; ++dd) {
           asm volatile("" ::: "memory");
-          int j = nodei[T] + dd;
+          int j = nodei[T] + dd * live;
           j = (j >= N) ? j - N : j;
-          const int cj = (col[T] < ncol) ? cbase + j : col[T];
+          const int cj = cbase + j;
           float df[DIM], e0[DIM], radial = 0.f, ea = 0.f;
 #pragma unroll
           for (int k = 0; k < DIM; ++k) {
@@ -418,7 +444,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
           silu_grad16(z, m2, g2);
           float att = 1.0f;
           f32x16 m = m2;
-          if (p.attention) {
+          if (att_on) {
             att = fast_sigmoid(xhalf_sum(dot16(lds_vec16(vl + V_WATT * EH), m2)) + b_att);
             m *= att;
           }
@@ -426,8 +452,8 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
           { f32x16 yv; silu_grad16(z, yv, gc); z = yv; }
           const f32x16 v_wc2 = lds_vec16(vl + V_WC2 * EH);
           float cs = xhalf_sum(dot16(v_wc2, z)), dcs_raw = 1.0f;
-          if (p.tanh_on) {
-            const float th = accurate_tanh(cs);
+          if (tanh_on) {
+            const float th = tanh_select(cs);
             dcs_raw = p.coord_scale * fmaf(-th, th, 1.0f);
             cs = th * p.coord_scale;
           }
@@ -445,7 +471,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) z[r] = (c1w * v_wc2[r]) * gc[r];  // zc_bar
           f32x16 mb = wc1t.mul(z, aggb);
-          if (p.attention) {
+          if (att_on) {
             const float attb = xhalf_sum(dot16(mb, m2)) * kSi;  // <m_bar, m2>, m2 held as kS m2
             const float lw = kS * (attb * att * (1.0f - att));   // true w_att = kS * packed w_att
             const f32x16 v_watt = lds_vec16(vl + V_WATT * EH);
@@ -457,7 +483,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
           f32x16 z1b = w2t.mul(mb, zero16);
 #pragma unroll
           for (int r = 0; r < 16; ++r) z1b[r] *= g1[r];
-          if (l > 0 || p.dot_h) {  // h^0 does not depend on x (but on h, through the time feature)
+          if (l > 0 || want_h) {  // h^0 does not depend on x (but on h, through the time feature)
             S += z1b;
             lds_add16(TB + cj * PBS + hh * 16, z1b);
           }
@@ -476,7 +502,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
             }
           }
         }
-        if (l > 0 || p.dot_h) {
+        if (l > 0 || want_h) {
           WFrag<1> wt;
           wt.load(nullptr, mats16, M_WAT, lane);
           hb[T] = wt.mul(S, hb[T]);
@@ -487,13 +513,13 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
       wave_lds_fence();  // all scatter contributions of this layer are in LDS
       {
         WFrag<1> wt;
-        if (l > 0 || p.dot_h) wt.load(nullptr, mats16, M_WBT, lane);
+        if (l > 0 || want_h) wt.load(nullptr, mats16, M_WBT, lane);
 #pragma unroll
         for (int T = 0; T < NT; ++T) {
           if (T >= ntile) continue;
 #pragma unroll
           for (int k = 0; k < DIM; ++k) pb[T][k] += pbsc[col[T] * DIM + k];
-          if (l > 0 || p.dot_h) hb[T] = wt.mul(lds_vec16(TB + col[T] * PBS + hh * 16), hb[T]);
+          if (l > 0 || want_h) hb[T] = wt.mul(lds_vec16(TB + col[T] * PBS + hh * 16), hb[T]);
         }
       }
       wave_lds_fence();
@@ -507,11 +533,11 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
       for (int k = 0; k < DIM; ++k) {
         const float yb = pb[T][k] + p0acc[T][k] + p0sc[col[T] * DIM + k] - vfin[T][k];
         p.vjp[(walker0 * N + col[T]) * DIM + k] = fmaf(c_s[T], cot[T][k], c_in[T] * yb);
-        if (p.dot_h) dhacc[T] = fmaf((-0.5f * c_in[T] / (1.0f + hvv[T])) * yb, xin[T][k], dhacc[T]);  // through c_in(h) x
+        if (want_h) dhacc[T] = fmaf((-0.5f * c_in[T] / (1.0f + hvv[T])) * yb, xin[T][k], dhacc[T]);  // through c_in(h) x
       }
     }
     wave_lds_fence();
-    if (p.dot_h) {
+    if (want_h) {
       // through the time feature c_noise = ln(h)/8: t_bar = sum_nodes <h_bar^0, d h^0 / dt>; then one lane per walker
       // adds up its particles' partial sums (both feature halves) in a fixed order
       float* red = TB;  // [2][NCOLP]
@@ -539,7 +565,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
 
 struct VjpShape {
   int n, dim, G, waves;
-  void (*kernel)(VjpParams);
+  void (*kernel[2])(VjpParams);  // [FIXED]
   size_t (*lds_bytes)(int);
   size_t (*ws_f)(int);
 };
@@ -548,7 +574,8 @@ static size_t vjp_lds_bytes_of(int L) { return VjpCfg<N, DIM, G, WAVES>::lds_byt
 template <int N, int DIM, int G, int WAVES>
 static size_t vjp_ws_f_of(int L) { return VjpCfg<N, DIM, G, WAVES>::ws_f(L); }
 #define PITA_VJP_SHAPE(N, DIM, G, WAVES)                                                         \
-  VjpShape { N, DIM, G, WAVES, egnn_vjp_kernel<N, DIM, G, WAVES>, vjp_lds_bytes_of<N, DIM, G, WAVES>, \
+  VjpShape { N, DIM, G, WAVES, {egnn_vjp_kernel<N, DIM, G, WAVES, false>, egnn_vjp_kernel<N, DIM, G, WAVES, true>}, \
+             vjp_lds_bytes_of<N, DIM, G, WAVES>, \
              vjp_ws_f_of<N, DIM, G, WAVES> }
 static const VjpShape kVjpShapes[] = {
     PITA_VJP_SHAPE(4, 2, 8, 4),
@@ -578,11 +605,12 @@ extern "C" int pita_egnn_vjp(pita_egnn_t* net, const float* h, const float* x, c
   p.coord_scale = net->cfg.coords_range / (float)net->cfg.n_layers;
   p.B = B; p.h = h; p.x = x; p.beta = beta; p.cot = cot; p.out = out; p.vjp = vjp; p.dot_h = dot_h;
   const size_t lds = s->lds_bytes(p.n_layers);
+  const auto kernel = s->kernel[(p.attention && p.tanh_on && dot_h) ? 1 : 0];
   static thread_local const void* configured = nullptr;
-  if (configured != (const void*)s->kernel) {
-    PITA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(s->kernel),
+  if (configured != (const void*)kernel) {
+    PITA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = (const void*)s->kernel;
+    configured = (const void*)kernel;
   }
   const long long ngroups = (B + s->G - 1) / s->G;
   long long want = (ngroups + s->waves - 1) / s->waves;
@@ -597,7 +625,7 @@ extern "C" int pita_egnn_vjp(pita_egnn_t* net, const float* h, const float* x, c
     net->ws_bytes = need;
   }
   p.ws = net->d_ws;
-  hipLaunchKernelGGL(s->kernel, dim3(grid), dim3(s->waves * 64), lds, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(s->waves * 64), lds, (hipStream_t)stream, p);
   PITA_LAUNCH_CHECK();
   return PITA_OK;
 }

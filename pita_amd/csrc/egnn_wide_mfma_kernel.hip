@@ -116,23 +116,6 @@ __device__ __forceinline__ void lds_store16(float* dst, const f32x16& v) {
   for (int q = 0; q < 4; ++q) d[q] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
 }
 
-// accurate_tanh (common.h) with both branches pinned: left alone the compiler turns the select back into a divergent
-// branch (the exp / rcp side is "expensive"), which splits the edge loop's basic block.  Same values.
-__device__ __forceinline__ float tanh_select(float v) {
-  const float a = fabsf(v);
-  const float v2 = v * v;
-  float p = 62.0f / 2835.0f;
-  p = fmaf(p, v2, -17.0f / 315.0f);
-  p = fmaf(p, v2, 2.0f / 15.0f);
-  p = fmaf(p, v2, -1.0f / 3.0f);
-  p = fmaf(p, v2, 1.0f);
-  float small = v * p;
-  const float e = __builtin_amdgcn_exp2f(2.88539008177792681f * a);
-  float big = copysignf(1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e), v);
-  asm volatile("" : "+v"(small), "+v"(big));
-  return a < 0.25f ? small : big;
-}
-
 // ATT / TANH: the network's attention gate and tanh-bounded coordinate head as compile-time switches: the edge loop is
 // one basic block (with the branch-free tanh above and the branch-free partner index below: 14.8 -> 13.9 ms per 65 536
 // forwards).
