@@ -318,6 +318,22 @@ __device__ __forceinline__ float xhalf_sum(float v) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// Park a resident weight fragment in accumulation registers (one-wave-per-SIMD kernels with 512 registers): the MFMA
+// reads its A operand from there directly, so the resident matrices cost no VALU-visible registers.  Left to itself
+// the allocator keeps them in VGPRs and spills other values around them.
+__device__ __forceinline__ void frag_to_agpr(WFrag<2>& f) {
+#pragma unroll
+  for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+    for (int st = 0; st < 2; ++st) asm volatile("" : "+a"(f.w[pc][st]));
+}
+__device__ __forceinline__ void frag_to_agpr(WFrag<1>& f) {
+#pragma unroll
+  for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+    for (int st = 0; st < 2; ++st) asm volatile("" : "+a"(f.w[pc][st]));
+}
+
 // accurate_tanh (common.h) with both branches pinned: left alone the compiler turns the select back into a divergent
 // branch (the exp / rcp side is "expensive"), which splits the edge loop's basic block.  Same values.
 __device__ __forceinline__ float tanh_select(float v) {

@@ -107,19 +107,6 @@ __device__ __forceinline__ void lds_add16(float* dst, const f32x16& v) {
   }
 }
 
-#ifndef PITA_VJP_AGPR_WEIGHTS
-#define PITA_VJP_AGPR_WEIGHTS 1
-#endif
-// park a resident weight fragment in accumulation registers: the MFMA reads its A operand from there directly
-__device__ __forceinline__ void frag_to_agpr(WFrag<1>& f) {
-#if PITA_VJP_AGPR_WEIGHTS
-#pragma unroll
-  for (int pc = 0; pc < 3; ++pc)
-#pragma unroll
-    for (int st = 0; st < 2; ++st) asm volatile("" : "+a"(f.w[pc][st]));
-#endif
-}
-
 // FIXED: attention gate, tanh-bounded coordinate head and the h-derivative output are compile-time "on" (every reference
 // configuration of the debiased regime): the edge loops carry no run-time branch.  FIXED = false keeps them run-time.
 template <int N, int DIM, int G, int WAVES, bool FIXED>
