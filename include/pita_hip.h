@@ -124,7 +124,7 @@ int pita_dw_mala(float* x, float* logp, const float* noise /*nullable*/, const f
  * node features concatenated with t and beta) over EGNN / E_GCL of egnn.py:108-346, and ScoreNet's EDM preconditioning
  * (score_net.py:13-43).  Two kernels serve the handle: a matrix-pipe kernel (csrc/egnn_wide_mfma_kernel.hip: 64 x 64 dense
  * layers as 2 x 2 blocks of 32 x 32 x 16 f16 MFMAs on the fp32-equivalent two-piece split) for the particle systems it is
- * instantiated for (22 atoms x 3), and a vector-pipe kernel (csrc/egnn_wide_kernel.hip: lane = hidden feature, fp32 FMA
+ * instantiated for (22, 33, 42, 13, 55 particles x 3), and a vector-pipe kernel (csrc/egnn_wide_kernel.hip: lane = hidden feature, fp32 FMA
  * chains) for every other shape -- which also recomputes, behind the matrix-pipe launch, exactly those walkers whose
  * result came out non-finite (an activation beyond the f16 range).
  * weights: the module's state_dict flattened in registration order (embedding, embedding_out, gcl_0 .. gcl_{L-1}, like

@@ -342,8 +342,12 @@ static size_t wide64_lds_of(int L) { return Wide64Cfg<N, DIM, G, WAVES>::lds_byt
                 {{egnn_wide64_kernel<N, DIM, G, WAVES, false, false>, egnn_wide64_kernel<N, DIM, G, WAVES, false, true>}, \
                  {egnn_wide64_kernel<N, DIM, G, WAVES, true, false>, egnn_wide64_kernel<N, DIM, G, WAVES, true, true>}}, \
                 wide64_lds_of<N, DIM, G, WAVES> }
-// alanine dipeptide (22 atoms: 4 walkers = 88 of 96 columns)
-static const Wide64Shape kWide64Shapes[] = {PITA_WIDE64_SHAPE(22, 3, 4, 4)};
+// the particle counts EGNN_dynamics_AD2_cat.get_h_initial knows (egnn_dynamics_ad2_cat.py:66-92): alanine dipeptide (22
+// atoms: 4 walkers = 88 of 96 columns), tri- / tetra-alanine (33, 42 atoms: 2 walkers = 66 / 84 of 96), LJ13 (7 walkers =
+// 91 of 96), LJ55 (1 walker = 55 of 64)
+static const Wide64Shape kWide64Shapes[] = {PITA_WIDE64_SHAPE(22, 3, 4, 4), PITA_WIDE64_SHAPE(33, 3, 2, 4),
+                                            PITA_WIDE64_SHAPE(42, 3, 2, 4), PITA_WIDE64_SHAPE(13, 3, 7, 4),
+                                            PITA_WIDE64_SHAPE(55, 3, 1, 4)};
 
 static inline int kfeat64(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 

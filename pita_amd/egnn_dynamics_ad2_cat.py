@@ -1,5 +1,6 @@
 """EGNN backbone of the alanine-dipeptide class (hidden 64 x 5 layers, one-hot atom-type node features) on the HIP
-kernels of ``pita_egnn_wide_eval``: the matrix-pipe kernel for 22 atoms, the vector-pipe kernel for every other shape.
+kernels of ``pita_egnn_wide_eval``: the matrix-pipe kernel for 22 / 33 / 42 / 13 / 55 particles, the vector-pipe kernel
+for every other shape.
 
 Mirror of ``EGNN_dynamics_AD2_cat`` (pita/src/models/components/egnn_dynamics_ad2_cat.py:11-203; the ``_target_`` of
 ``configs/model/net/egnn_dynamics_ad2_cat.yaml``): same constructor arguments and defaults, same parameter names and
@@ -80,7 +81,8 @@ class EGNN_dynamics_AD2_cat(nn.Module):
         return self._handle
 
     def uses_matrix_pipe(self, device):
-        """True when evaluations on ``device`` run on the MFMA kernel (22 atoms x 3 unless PITA_WIDE_NO_MFMA is set)."""
+        """True when evaluations on ``device`` run on the MFMA kernel (the instantiated particle counts, unless
+        PITA_WIDE_NO_MFMA is set)."""
         return bool(_lib.lib().pita_egnn_wide_uses_matrix_pipe(self._native(torch.device(device))))
 
     def __getstate__(self):
