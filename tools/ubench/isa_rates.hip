@@ -154,6 +154,44 @@ __global__ void __launch_bounds__(512) k_mix(float* out, long long* cyc) {
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
 }
 
+// Two waves per SIMD running DIFFERENT instruction kinds: waves 0-3 one kind, waves 4-7 (the SIMD partners) the other.
+// Tells whether the transcendental unit (or the half-rate conversions) issue beside plain VALU work of the partner wave.
+#define KERNEL_PAIR(NAME, INSTR_A, INSTR_B)                                     \
+  __global__ void __launch_bounds__(512) NAME(float* out, long long* cyc) {     \
+    float r[8];                                                                 \
+    for (int i = 0; i < 8; ++i) r[i] = 1.0f + threadIdx.x * 1e-3f + i;          \
+    float a = 1.0001f, b = 0.5f;                                                \
+    const bool first = (threadIdx.x >> 6) < 4;                                  \
+    __syncthreads();                                                            \
+    long long t0 = __builtin_amdgcn_s_memtime();                                \
+    if (first) { for (int it = 0; it < REPS; ++it) { BODY8(INSTR_A) BODY8(INSTR_A) BODY8(INSTR_A) BODY8(INSTR_A) } } \
+    else { for (int it = 0; it < REPS; ++it) { BODY8(INSTR_B) BODY8(INSTR_B) BODY8(INSTR_B) BODY8(INSTR_B) } } \
+    long long t1 = __builtin_amdgcn_s_memtime();                                \
+    float s = 0;                                                                \
+    for (int i = 0; i < 8; ++i) s += r[i];                                      \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;                             \
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0; \
+  }
+KERNEL_PAIR(k_pair_exp_fma, I_EXP, I_FMA)
+KERNEL_PAIR(k_pair_exp_exp, I_EXP, I_EXP)
+KERNEL_PAIR(k_pair_fma_fma, I_FMA, I_FMA)
+KERNEL_PAIR(k_pair_cvt_fma, I_CVTPK, I_FMA)
+KERNEL_PAIR(k_pair_exp_cvt, I_EXP, I_CVTPK)
+
+template <typename K>
+static void run_pair(const char* name, K kern) {
+  float* out; long long* cyc;
+  CHECK(hipMalloc(&out, 512 * 4 * 256)); CHECK(hipMalloc(&cyc, 8 * 8 * 256));
+  for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(kern, dim3(1), dim3(512), 0, 0, out, cyc); CHECK(hipDeviceSynchronize()); }
+  long long h[8];
+  CHECK(hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost));
+  double a = 0, b = 0;
+  for (int w = 0; w < 4; ++w) { a = h[w] > a ? h[w] : a; b = h[w + 4] > b ? h[w + 4] : b; }
+  printf("%-44s A-waves %7.2f, B-waves %7.2f cyc per wave-instruction (two waves per SIMD, one of each kind)\n", name,
+         a / (32.0 * REPS), b / (32.0 * REPS));
+  CHECK(hipFree(out)); CHECK(hipFree(cyc));
+}
+
 // f16 MFMA denormal probe: A = 1 (k=0), B = tiny -> C should be tiny if denormals are honoured
 __global__ void k_denorm(float* out) {
   const float vals[8] = {6.2e-5f /*just above min normal 6.1e-5*/, 3.0e-5f, 1.0e-6f, 6.0e-8f /*smallest denormal 5.96e-8*/, 2.0e-8f, 0.f, 0.f, 0.f};
@@ -210,6 +248,11 @@ int main() {
   run("v_fma_mix_f32 (f16 lo)", k_fmamix, 32, REPS);
   run("v_fma_mix_f32 (f16 hi)", k_fmamixhi, 32, REPS);
   run("v_pk_fma_f32", k_pkfma, 8, REPS * 4);
+  run_pair("pair: v_exp_f32 | v_fma_f32", k_pair_exp_fma);
+  run_pair("pair: v_exp_f32 | v_exp_f32", k_pair_exp_exp);
+  run_pair("pair: v_fma_f32 | v_fma_f32", k_pair_fma_fma);
+  run_pair("pair: v_cvt_pk_f16_f32 | v_fma_f32", k_pair_cvt_fma);
+  run_pair("pair: v_exp_f32 | v_cvt_pk_f16_f32", k_pair_exp_cvt);
   run("mfma_f32_32x32x16_f16 dependent chain", k_mfma<0, true>, 16, REPS);
   run("mfma_f32_32x32x16_f16 2 accumulators", k_mfma<0, false>, 16, REPS);
   run("mfma_f32_32x32x16_bf16 dependent chain", k_mfma<1, true>, 16, REPS);
