@@ -18,8 +18,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", 
 PER_FILE_FLAGS = {"egnn_wide_mfma_kernel.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                   # reverse-mode kernel (one wave per SIMD, resident weight fragments parked in AGPRs): 5.74 -> 5.22 ms
                   "egnn_vjp_kernel.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
-# (egnn_div_kernel.hip: the same treatment gained 4 % on the LJ55 trace, nothing on LJ13, and one instantiation then
-# faulted with a memory aperture violation in test_jacobian_trace_multi_direction -- not adopted.)
+# (egnn_div_kernel.hip: the same treatment gained 4 % on the LJ55 trace, nothing on LJ13, and ONE instantiation --
+# egnn_div_fast_kernel<4,2,8,4,3,1>, the DW4 writer -- then faulted with a memory aperture violation: bisected to the
+# combination of this experimental option with the AGPR-parked fragments in that kernel; either alone is fine there.
+# Not adopted for that file.  Every instantiation of the two files above is exercised by the GPU tests: a mis-compile of
+# this kind shows as a hard fault.)
 
 
 def needs_build():

@@ -1529,6 +1529,44 @@ def test_vjp_vs_oracle(pa, golden):
                                            atol=1e-4 * float(dj.abs().mean()))
 
 
+@pytest.mark.parametrize("variant", ["no_attention", "no_tanh", "layers2"])
+def test_vjp_network_variants(pa, golden, variant):
+    """The reverse-mode kernel's run-time instantiation (gate off, tanh off, two layers; the compile-time path covers
+    the reference configuration): J^T cot and the h-derivative against torch.autograd of the fp64 oracle."""
+    w = {k: T(v) for k, v in golden("egnn_weights_trainedlike.npz").items()}
+    kw = dict(hidden_nf=32, n_layers=3, recurrent=True, tanh=True, attention=True, condition_time=True,
+              condition_temperature=True, agg="sum")
+    if variant == "no_attention":
+        kw["attention"] = False
+    elif variant == "no_tanh":
+        kw["tanh"] = False
+    else:
+        kw["n_layers"] = 2
+    net = pa.EGNN_dynamics(13, 3, **kw)
+    sd = net.state_dict()
+    gen = torch.Generator().manual_seed(29)
+    for k in sd:
+        src = w.get(k)
+        sd[k] = src.clone() if src is not None and src.shape == sd[k].shape else 0.2 * torch.randn(sd[k].shape, generator=gen)
+    net.load_state_dict(sd)
+    wt = {k: v.double() for k, v in sd.items()}
+    B = 19
+    h = torch.tensor([0.05, 0.8, 12.0])[torch.arange(B) % 3]
+    x = O.remove_mean(torch.randn(B, 39, generator=gen) * (1 + h.sqrt())[:, None], 13, 3)
+    beta = torch.rand(B, generator=gen) + 0.7
+    cot = torch.randn(B, 39, generator=gen)
+    bb = lambda cn, xs, b: O.egnn_forward(wt, cn, xs, b, 13, 3, n_layers=kw["n_layers"], tanh=kw["tanh"],
+                                          attention=kw["attention"])
+    xd, hd = x.double().requires_grad_(True), h.double().requires_grad_(True)
+    Dref = O.denoiser(bb, hd, xd, beta.double())
+    gx, gh = torch.autograd.grad((Dref * cot.double()).sum(), (xd, hd))
+    for want_h in (False, True):
+        out = net.vjp(h.cuda(), x.cuda(), beta.cuda(), cot=cot.cuda(), want_dot_h=want_h)
+        assert rel(out[0], Dref.detach()) < 2e-6 and rel(out[1], gx) < 2e-5, (variant, want_h, rel(out[1], gx))
+        if want_h:
+            np.testing.assert_allclose(out[2].cpu().numpy(), gh.numpy(), rtol=5e-5, atol=5e-5 * float(gh.abs().mean()))
+
+
 def test_debiased_terms_and_trajectory_golden(pa, golden):
     """Feynman-Kac drift terms at identical inputs and the 8-step weighted trajectory with resampling, against the
     reference run stored in em_traj_lj13_debias.npz (autograd + vmap(jacrev) there, HIP JVPs here)."""
