@@ -331,38 +331,42 @@ def test_egnn_ad2cat_golden(pa, golden, tag, L, tanh, att):
     assert torch.isfinite(ref).all() and rel(xh, ref) < 1e-4
 
 
-@pytest.mark.parametrize("n", [13, 33, 42, 55])
+@pytest.mark.parametrize("n", [13, 22, 33, 42, 55])
 def test_egnn_ad2cat_other_particle_counts(pa, n, monkeypatch):
-    """The other particle counts EGNN_dynamics_AD2_cat knows node features for (tri- / tetra-alanine, LJ13, LJ55) on the
-    matrix-pipe kernel: seeded reference-style weights, backbone output against the fp64 oracle (fp32-level error) and
-    against the vector-pipe kernel, ragged batch (partial last group)."""
+    """Every instantiation of the matrix-pipe kernel -- the particle counts EGNN_dynamics_AD2_cat knows node features for
+    (alanine di- / tri- / tetra-peptide, LJ13, LJ55) x attention gate on / off x tanh head on / off: seeded
+    reference-style weights, backbone output against the fp64 oracle (fp32-level error) and against the vector-pipe
+    kernel, ragged batch (partial last group)."""
     from pita_amd.egnn_dynamics_ad2_cat import EGNN_dynamics_AD2_cat
 
-    torch.manual_seed(100 + n)
-    net = EGNN_dynamics_AD2_cat(n, 3, hidden_nf=64, n_layers=3, tanh=True, attention=True, condition_beta=True)
-    with torch.no_grad():
-        for prm in net.parameters():  # trained-like magnitudes: the fresh coordinate head (gain 1e-3) hides errors
-            if prm.dim() == 2 and prm.shape[0] == 1:
-                prm.mul_(200.0)
-    w = {k: v.detach().clone() for k, v in net.state_dict().items()}
     gen = torch.Generator().manual_seed(n)
     B = 9
     x = O.remove_mean(torch.randn(B, n * 3, generator=gen) * 1.5, n, 3)
     t = torch.rand(B, generator=gen) - 0.5
     beta = torch.rand(B, generator=gen) + 0.5
-    assert net.uses_matrix_pipe("cuda:0")
-    F = net(t.cuda(), x.cuda(), beta.cuda())
-    F64 = O.egnn_ad2_cat_forward({k: v.double() for k, v in w.items()}, t.double(), x.double(), beta.double(), n, 3,
-                                 n_layers=3, tanh=True, attention=True)
-    F32 = O.egnn_ad2_cat_forward(w, t, x, beta, n, 3, n_layers=3, tanh=True, attention=True)
-    err_hip, err_ref = rel(F, F64), rel(F32, F64)
-    print(f"[ad2cat n={n}] err_hip_vs_fp64={err_hip:.3e} err_fp32_oracle_vs_fp64={err_ref:.3e}")
-    assert float(F64.abs().max()) > 1e-3 and err_hip < max(4 * err_ref, 2e-6), (err_hip, err_ref)
-    monkeypatch.setenv("PITA_WIDE_NO_MFMA", "1")
-    Fv = net(t.cuda(), x.cuda(), beta.cuda())
-    monkeypatch.delenv("PITA_WIDE_NO_MFMA")
-    assert rel(Fv, F64) < max(4 * err_ref, 2e-6) and rel(F, Fv) < max(8 * err_ref, 2e-6), (rel(F, Fv), err_ref)
-    assert torch.equal(net(t[:5].cuda(), x[:5].cuda(), beta[:5].cuda()), F[:5])
+    for att in (True, False):
+        for tanh in (True, False):
+            torch.manual_seed(100 + n)
+            net = EGNN_dynamics_AD2_cat(n, 3, hidden_nf=64, n_layers=3, tanh=tanh, attention=att, condition_beta=True)
+            with torch.no_grad():
+                for prm in net.parameters():  # trained-like magnitudes: the fresh coordinate head (gain 1e-3) hides errors
+                    if prm.dim() == 2 and prm.shape[0] == 1 and prm.shape[1] == 64:
+                        prm.mul_(200.0 if tanh else 20.0)
+            w = {k: v.detach().clone() for k, v in net.state_dict().items()}
+            assert net.uses_matrix_pipe("cuda:0")
+            F = net(t.cuda(), x.cuda(), beta.cuda())
+            kw = dict(n_layers=3, tanh=tanh, attention=att)
+            F64 = O.egnn_ad2_cat_forward({k: v.double() for k, v in w.items()}, t.double(), x.double(), beta.double(), n, 3, **kw)
+            F32 = O.egnn_ad2_cat_forward(w, t, x, beta, n, 3, **kw)
+            err_hip, err_ref = rel(F, F64), rel(F32, F64)
+            print(f"[ad2cat n={n} att={att} tanh={tanh}] err_hip_vs_fp64={err_hip:.3e} err_fp32_oracle_vs_fp64={err_ref:.3e}")
+            assert torch.isfinite(F64).all() and float(F64.abs().max()) > 1e-3, float(F64.abs().max())
+            assert err_hip < max(4 * err_ref, 2e-6), (att, tanh, err_hip, err_ref)
+            monkeypatch.setenv("PITA_WIDE_NO_MFMA", "1")
+            Fv = net(t.cuda(), x.cuda(), beta.cuda())
+            monkeypatch.delenv("PITA_WIDE_NO_MFMA")
+            assert rel(Fv, F64) < max(4 * err_ref, 2e-6) and rel(F, Fv) < max(8 * err_ref, 2e-6), (rel(F, Fv), err_ref)
+            assert torch.equal(net(t[:5].cuda(), x[:5].cuda(), beta[:5].cuda()), F[:5])
 
 
 def test_egnn_ad2cat_matrix_pipe_vs_vector_pipe(pa, golden, monkeypatch):
