@@ -348,6 +348,10 @@ static size_t wide64_lds_of(int L) { return Wide64Cfg<N, DIM, G, WAVES>::lds_byt
 static const Wide64Shape kWide64Shapes[] = {PITA_WIDE64_SHAPE(22, 3, 4, 4), PITA_WIDE64_SHAPE(33, 3, 2, 4),
                                             PITA_WIDE64_SHAPE(42, 3, 2, 4), PITA_WIDE64_SHAPE(13, 3, 7, 4),
                                             PITA_WIDE64_SHAPE(55, 3, 1, 4)};
+// Fewer walkers per wave for batches that leave SIMDs empty with the mapping above (4 096 alanine-dipeptide walkers are
+// 1 024 groups of four = one wave per SIMD; below that, one walker per wave -- 22 of 32 columns -- fills the chip
+// sooner).  Results do not depend on the grouping (columns are independent; tested bitwise).
+static const Wide64Shape kWide64Small[] = {PITA_WIDE64_SHAPE(22, 3, 1, 4)};
 
 static inline int kfeat64(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
@@ -450,6 +454,10 @@ int wide64_prepare(pita_egnn_wide* net, const float* w, const float* he) {
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(shape->kernel[cfg.attention ? 1 : 0][cfg.tanh ? 1 : 0]),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)shape->lds_bytes(L));
+  for (const auto& t : kWide64Small)
+    if (e == hipSuccess && t.n == shape->n && t.dim == shape->dim)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(t.kernel[cfg.attention ? 1 : 0][cfg.tanh ? 1 : 0]),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes(L));
   delete[] hm;
   delete[] hv;
   delete[] hes;
@@ -474,6 +482,8 @@ void wide64_release(pita_egnn_wide* net) {
 int wide64_launch(pita_egnn_wide* net, int what, const float* t, const float* x, const float* beta, float* out,
                   long long B, hipStream_t stream) {
   const Wide64Shape* s = static_cast<const Wide64Shape*>(net->shape64);
+  for (const auto& t : kWide64Small)  // small batch: the one-walker mapping when the regular one fills under 3/4 of the SIMDs
+    if (t.n == s->n && t.dim == s->dim && (B + s->G - 1) / s->G < (long long)net->n_cu * 3) s = &t;
   Wide64Params p{};
   p.m16h = net->d_m16h; p.vecs = net->d_vecs64; p.est = net->d_est64;
   p.L = net->cfg.n_layers; p.attention = net->cfg.attention; p.tanh_on = net->cfg.tanh; p.has_beta = net->cfg.condition_beta;

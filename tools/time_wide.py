@@ -11,7 +11,7 @@ net = EGNN_dynamics_AD2_cat(22, 3, condition_beta=True)
 for mfma in (1, 0):
   if mfma: os.environ.pop("PITA_WIDE_NO_MFMA", None)
   else: os.environ["PITA_WIDE_NO_MFMA"] = "1"
-  for B in (4096, 16384, 65536):
+  for B in (256, 1024, 2048, 4096, 16384, 65536):
       x = pita_amd.Prior(scale=3.0, n_particles=22, spatial_dim=3, seed=1).sample(B)
       t = torch.full((B,), 0.1).cuda(); b = torch.ones(B).cuda()
       for _ in range(2): net(t, x, b)
