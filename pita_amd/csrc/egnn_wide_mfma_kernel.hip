@@ -117,8 +117,8 @@ __device__ __forceinline__ void lds_store16(float* dst, const f32x16& v) {
 }
 
 // ATT / TANH: the network's attention gate and tanh-bounded coordinate head as compile-time switches: the edge loop is
-// one basic block (with the branch-free tanh above and the branch-free partner index below: 14.8 -> 13.9 ms per 65 536
-// forwards).
+// one basic block (with the branch-free tanh_select of egnn_common.h and the branch-free partner index below: 14.8 ->
+// 13.9 ms per 65 536 forwards).
 // Measured and dropped: the edge loop as a software pipeline (two edges in flight, the 24 MFMAs of a dense layer dealt
 // out between the vector stage of the neighbouring edge with sched_group_barrier, 1 / 2 / 4 / 8 regions per stage):
 // 14.7-15.4 ms -- a lone wave's stalls are dependent-instruction latencies, which the extra live state makes worse.
