@@ -68,6 +68,43 @@ KERNEL(k_fmamixhi, I_FMAMIXHI)
 KERNEL(k_mov, I_MOV)
 KERNEL(k_dpp, I_DPP)
 
+// three DISTINCT vector-register operands per instruction (the kernels' usual case; the rows above share two of them)
+__global__ void __launch_bounds__(1024) k_fma3(float* out, long long* cyc) {
+  float r[8];
+  for (int i = 0; i < 8; ++i) r[i] = 1.0f + threadIdx.x * 1e-3f + i * 1e-4f;
+  __syncthreads();
+  long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < REPS * 4; ++it) {
+    asm volatile(
+        "v_fma_f32 %0, %1, %2, %0\nv_fma_f32 %1, %2, %3, %1\nv_fma_f32 %2, %3, %4, %2\nv_fma_f32 %3, %4, %5, %3\n"
+        "v_fma_f32 %4, %5, %6, %4\nv_fma_f32 %5, %6, %7, %5\nv_fma_f32 %6, %7, %0, %6\nv_fma_f32 %7, %0, %1, %7\n"
+        : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
+  }
+  long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0;
+  for (int i = 0; i < 8; ++i) s += r[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
+}
+// the same with VOP2 v_fmac (dst = accumulator) and v_mul / v_sub on distinct registers
+__global__ void __launch_bounds__(1024) k_vop2mix(float* out, long long* cyc) {
+  float r[8];
+  for (int i = 0; i < 8; ++i) r[i] = 1.0f + threadIdx.x * 1e-3f + i * 1e-4f;
+  __syncthreads();
+  long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < REPS * 4; ++it) {
+    asm volatile(
+        "v_fmac_f32 %0, %1, %2\nv_sub_f32 %3, %4, %5\nv_mul_f32 %6, %7, %1\nv_fmac_f32 %2, %3, %4\n"
+        "v_sub_f32 %5, %6, %7\nv_mul_f32 %1, %0, %2\nv_fmac_f32 %4, %5, %6\nv_sub_f32 %7, %1, %3\n"
+        : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
+  }
+  long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0;
+  for (int i = 0; i < 8; ++i) s += r[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
+}
+
 // packed f32 on register pairs
 __global__ void __launch_bounds__(512) k_pkfma(float* out, long long* cyc) {
   typedef float f2 __attribute__((ext_vector_type(2)));
@@ -213,10 +250,11 @@ __global__ void k_denorm(float* out) {
 }
 
 template <typename K>
-static void run(const char* name, K kern, int instr_per_iter, int iters) {
+static void run(const char* name, K kern, int instr_per_iter, int iters, bool four = false) {
   float* out; long long* cyc;
-  CHECK(hipMalloc(&out, 512 * 4 * 256)); CHECK(hipMalloc(&cyc, 8 * 8 * 256));
-  for (int waves : {4, 8}) {  // per workgroup = per CU: 1 or 2 waves per SIMD
+  CHECK(hipMalloc(&out, 1024 * 4 * 256)); CHECK(hipMalloc(&cyc, 8 * 16 * 256));
+  for (int waves : {4, 8, 16}) {  // per workgroup = per CU: 1, 2 or (kernels built for 1024 threads) 4 waves per SIMD
+    if (waves == 16 && !four) continue;
     hipLaunchKernelGGL(kern, dim3(1), dim3(64 * waves), 0, 0, out, cyc);
     CHECK(hipDeviceSynchronize());
     hipLaunchKernelGGL(kern, dim3(1), dim3(64 * waves), 0, 0, out, cyc);
@@ -248,6 +286,8 @@ int main() {
   run("v_fma_mix_f32 (f16 lo)", k_fmamix, 32, REPS);
   run("v_fma_mix_f32 (f16 hi)", k_fmamixhi, 32, REPS);
   run("v_pk_fma_f32", k_pkfma, 8, REPS * 4);
+  run("v_fma_f32, 3 distinct VGPR operands", k_fma3, 8, REPS * 4, true);
+  run("v_fmac/v_sub/v_mul mix, distinct VGPRs", k_vop2mix, 8, REPS * 4, true);
   run_pair("pair: v_exp_f32 | v_fma_f32", k_pair_exp_fma);
   run_pair("pair: v_exp_f32 | v_exp_f32", k_pair_exp_exp);
   run_pair("pair: v_fma_f32 | v_fma_f32", k_pair_fma_fma);
