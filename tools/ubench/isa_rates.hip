@@ -105,6 +105,25 @@ __global__ void __launch_bounds__(1024) k_vop2mix(float* out, long long* cyc) {
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
 }
 
+// straight-line code: the same v_fma_f32 stream with a loop body of 2 048 instructions (16 KB of code) instead of 32 --
+// does the instruction fetch keep up when nothing is re-used from the instruction buffers?
+#define B32(I) BODY8(I) BODY8(I) BODY8(I) BODY8(I)
+#define B256(I) B32(I) B32(I) B32(I) B32(I) B32(I) B32(I) B32(I) B32(I)
+#define B2048(I) B256(I) B256(I) B256(I) B256(I) B256(I) B256(I) B256(I) B256(I)
+__global__ void __launch_bounds__(1024) k_fma_long(float* out, long long* cyc) {
+  float r[8];
+  for (int i = 0; i < 8; ++i) r[i] = 1.0f + threadIdx.x * 1e-3f + i;
+  float a = 1.0001f, b = 0.5f;
+  __syncthreads();
+  long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < REPS / 64; ++it) { B2048(I_FMA) }
+  long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0;
+  for (int i = 0; i < 8; ++i) s += r[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
+}
+
 // packed f32 on register pairs
 __global__ void __launch_bounds__(512) k_pkfma(float* out, long long* cyc) {
   typedef float f2 __attribute__((ext_vector_type(2)));
@@ -286,6 +305,7 @@ int main() {
   run("v_fma_mix_f32 (f16 lo)", k_fmamix, 32, REPS);
   run("v_fma_mix_f32 (f16 hi)", k_fmamixhi, 32, REPS);
   run("v_pk_fma_f32", k_pkfma, 8, REPS * 4);
+  run("v_fma_f32, 2 048-instruction loop body", k_fma_long, 2048, REPS / 64, true);
   run("v_fma_f32, 3 distinct VGPR operands", k_fma3, 8, REPS * 4, true);
   run("v_fmac/v_sub/v_mul mix, distinct VGPRs", k_vop2mix, 8, REPS * 4, true);
   run_pair("pair: v_exp_f32 | v_fma_f32", k_pair_exp_fma);
