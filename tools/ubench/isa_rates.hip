@@ -268,6 +268,23 @@ __global__ void k_denorm(float* out) {
   }
 }
 
+// the same measurement with the WHOLE chip busy (one workgroup per CU, or several): does a wave-instruction cost the same
+// when all 256 CUs issue at once (power management) as when one CU runs alone?
+template <typename K>
+static void run_chip(const char* name, K kern, int instr_per_iter, int iters, int blocks, int waves) {
+  float* out; long long* cyc;
+  CHECK(hipMalloc(&out, (size_t)blocks * 1024 * 4)); CHECK(hipMalloc(&cyc, (size_t)blocks * 16 * 8));
+  for (int rep = 0; rep < 3; ++rep) { hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * waves), 0, 0, out, cyc); CHECK(hipDeviceSynchronize()); }
+  std::vector<long long> h((size_t)blocks * waves);
+  CHECK(hipMemcpy(h.data(), cyc, 8 * h.size(), hipMemcpyDeviceToHost));
+  double mx = 0, sum = 0;
+  for (auto v : h) { mx = v > mx ? v : mx; sum += (double)v; }
+  const double per = (sum / h.size()) / ((double)instr_per_iter * iters);
+  printf("%-44s %4d blocks x %2d waves: mean %6.2f (max %6.2f) cyc per wave-instruction, %5.2f cyc/SIMD per instruction\n", name,
+         blocks, waves, per, mx / ((double)instr_per_iter * iters), per / (waves / 4.0));
+  CHECK(hipFree(out)); CHECK(hipFree(cyc));
+}
+
 template <typename K>
 static void run(const char* name, K kern, int instr_per_iter, int iters, bool four = false) {
   float* out; long long* cyc;
@@ -307,6 +324,9 @@ int main() {
   run("v_pk_fma_f32", k_pkfma, 8, REPS * 4);
   run("v_fma_f32, 2 048-instruction loop body", k_fma_long, 2048, REPS / 64, true);
   run("v_fma_f32, 3 distinct VGPR operands", k_fma3, 8, REPS * 4, true);
+  for (int blocks : {1, 32, 256, 512})
+    for (int waves : {8, 16}) run_chip("v_fma_f32 (3 operands), chip-wide", k_fma3, 8, REPS * 4, blocks, waves);
+  for (int blocks : {1, 256}) run_chip("v_fmac/v_sub/v_mul mix, chip-wide", k_vop2mix, 8, REPS * 4, blocks, 16);
   run("v_fmac/v_sub/v_mul mix, distinct VGPRs", k_vop2mix, 8, REPS * 4, true);
   run_pair("pair: v_exp_f32 | v_fma_f32", k_pair_exp_fma);
   run_pair("pair: v_exp_f32 | v_exp_f32", k_pair_exp_exp);
