@@ -124,6 +124,32 @@ __global__ void __launch_bounds__(1024) k_fma_long(float* out, long long* cyc) {
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
 }
 
+// operand banks: three source registers per FMA from the SAME register bank (index mod 4 equal) or from three different
+// banks; explicit registers (v16 .. v63 are initialised and clobbered)
+#define FMA_SAME(d, a) "v_fma_f32 v" #d ", v" #a ", v" #a "+16, v" #a "+32\n"
+template <int SAME>
+__global__ void __launch_bounds__(1024) k_bank(float* out, long long* cyc) {
+  __syncthreads();
+  long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < REPS * 4; ++it) {
+    if (SAME)
+      asm volatile(
+          "v_fma_f32 v0, v16, v32, v48\nv_fma_f32 v1, v20, v36, v52\nv_fma_f32 v2, v24, v40, v56\nv_fma_f32 v3, v28, v44, v60\n"
+          "v_fma_f32 v4, v17, v33, v49\nv_fma_f32 v5, v21, v37, v53\nv_fma_f32 v6, v25, v41, v57\nv_fma_f32 v7, v29, v45, v61\n"
+          ::: "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7");
+    else
+      asm volatile(
+          "v_fma_f32 v0, v16, v33, v50\nv_fma_f32 v1, v20, v37, v54\nv_fma_f32 v2, v24, v41, v58\nv_fma_f32 v3, v28, v45, v62\n"
+          "v_fma_f32 v4, v17, v34, v51\nv_fma_f32 v5, v21, v38, v55\nv_fma_f32 v6, v25, v42, v59\nv_fma_f32 v7, v29, v46, v63\n"
+          ::: "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7");
+  }
+  long long t1 = __builtin_amdgcn_s_memtime();
+  float s;
+  asm volatile("v_add_f32 %0, v0, v7" : "=v"(s));
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
+}
+
 // packed f32 on register pairs
 __global__ void __launch_bounds__(512) k_pkfma(float* out, long long* cyc) {
   typedef float f2 __attribute__((ext_vector_type(2)));
@@ -323,6 +349,8 @@ int main() {
   run("v_fma_mix_f32 (f16 hi)", k_fmamixhi, 32, REPS);
   run("v_pk_fma_f32", k_pkfma, 8, REPS * 4);
   run("v_fma_f32, 2 048-instruction loop body", k_fma_long, 2048, REPS / 64, true);
+  run("v_fma_f32, sources in ONE register bank", k_bank<1>, 8, REPS * 4, true);
+  run("v_fma_f32, sources in three banks", k_bank<0>, 8, REPS * 4, true);
   run("v_fma_f32, 3 distinct VGPR operands", k_fma3, 8, REPS * 4, true);
   for (int blocks : {1, 32, 256, 512})
     for (int waves : {8, 16}) run_chip("v_fma_f32 (3 operands), chip-wide", k_fma3, 8, REPS * 4, blocks, waves);
