@@ -288,6 +288,37 @@ def gen_egnn_ad2cat():
              **{"w." + k: v for k, v in sd_np(net).items()})
 
 
+def gen_egnn_ad2cat_sizes():
+    """EGNN_dynamics_AD2_cat for the other particle counts its get_h_initial knows without a topology file (33 and 42
+    atoms: tri- / tetra-alanine; 13 and 55: the LJ systems with a zero feature): the reference module's static node
+    features and, for a two-layer hidden-32 net, its backbone output on seeded inputs."""
+    _ref_shims._mod("mdtraj")
+    from src.models.components import egnn_dynamics_ad2_cat as ad2
+
+    out = {}
+    for n in (13, 33, 42, 55):
+        torch.manual_seed(1000 + n)
+        net = ad2.EGNN_dynamics_AD2_cat(n_particles=n, n_dimensions=3, hidden_nf=32, n_layers=2, condition_beta=True)
+        out[f"h_initial_{n}"] = net.h_initial.numpy().astype(np.float32)
+        if n not in (33, 42):
+            continue
+        with torch.no_grad():
+            for l in range(2):
+                getattr(net.egnn, f"gcl_{l}").coord_mlp[2].weight.mul_(300.0)
+            for p in net.parameters():
+                p.add_(0.02 * torch.randn_like(p))
+        gen = torch.Generator().manual_seed(n)
+        B = 6
+        x = lattice_cluster(n, 3, B, gen, spacing=1.1, jitter=0.1) + 0.3 * torch.randn(B, n * 3, generator=gen)
+        t = torch.rand(B, generator=gen) - 0.5
+        betas = torch.tensor([1.0, 1.33, 4.0])[torch.arange(B) % 3]
+        with torch.no_grad():
+            F = net(t, x, betas)
+        out.update({f"x_{n}": x.numpy(), f"t_{n}": t.numpy(), f"beta_{n}": betas.numpy(), f"F_{n}": F.numpy()})
+        out.update({f"w{n}." + k: v for k, v in sd_np(net).items()})
+    save("egnn_ad2cat_sizes.npz", **out)
+
+
 # ----------------------------------------------------------------------------- MLP
 def gen_mlp():
     torch.manual_seed(12345)
@@ -736,7 +767,7 @@ def gen_traj_gmm():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "lj", "lj_smooth", "gmm", "egnn", "egnn_ad2cat", "mlp", "prior", "resample", "traj_nodebias", "traj_1000",
+    which = sys.argv[1:] or ["schedules", "lj", "lj_smooth", "gmm", "egnn", "egnn_ad2cat", "egnn_ad2cat_sizes", "mlp", "prior", "resample", "traj_nodebias", "traj_1000",
                              "traj_debias", "traj_debias_end", "debias_variants", "post", "post55", "traj_1000_lj55", "traj_gmm"]
     for w in which:
         globals()["gen_" + w]()

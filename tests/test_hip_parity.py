@@ -369,6 +369,25 @@ def test_egnn_ad2cat_other_particle_counts(pa, n, monkeypatch):
             assert torch.equal(net(t[:5].cuda(), x[:5].cuda(), beta[:5].cuda()), F[:5])
 
 
+def test_egnn_ad2cat_other_sizes_golden(pa, golden):
+    """33 and 42 atoms (tri- / tetra-alanine) against the REFERENCE module's output (egnn_ad2cat_sizes.npz): hidden 32
+    padded to the matrix-pipe kernel's 64, static node features from the module's own tables."""
+    from pita_amd.egnn_dynamics_ad2_cat import EGNN_dynamics_AD2_cat
+
+    g = golden("egnn_ad2cat_sizes.npz")
+    for n in (33, 42):
+        w = {k[len(f"w{n}."):]: T(v) for k, v in g.items() if k.startswith(f"w{n}.")}
+        net = EGNN_dynamics_AD2_cat(n, 3, hidden_nf=32, n_layers=2, condition_beta=True)
+        net.load_state_dict(w)
+        F = net(cu(g[f"t_{n}"]), cu(g[f"x_{n}"]), cu(g[f"beta_{n}"]))
+        F64 = O.egnn_ad2_cat_forward({k: v.double() for k, v in w.items()}, T(g[f"t_{n}"]).double(), T(g[f"x_{n}"]).double(),
+                                     T(g[f"beta_{n}"]).double(), n, 3, n_layers=2)
+        err_ref, err_hip = rel(g[f"F_{n}"], F64), rel(F, F64)
+        print(f"[ad2cat sizes n={n}] err_hip_vs_fp64={err_hip:.3e} err_ref_vs_fp64={err_ref:.3e}")
+        assert net.uses_matrix_pipe("cuda:0") and err_hip < max(4 * err_ref, 2e-6), (n, err_hip, err_ref)
+        assert rel(F, g[f"F_{n}"]) < max(2e-5, 6 * err_ref)
+
+
 def test_egnn_ad2cat_matrix_pipe_vs_vector_pipe(pa, golden, monkeypatch):
     """The two kernels behind pita_egnn_wide_eval on the same inputs: the matrix-pipe kernel (f16 two-piece split) agrees
     with the vector-pipe kernel (fp32 FMA chains) to fp32 rounding in all three modes and at ragged batch sizes (1 .. 9

@@ -162,6 +162,23 @@ def test_egnn_ad2cat(golden, tag, L, tanh, att):
     assert torch.equal(m.h_initial.float(), T(g["h_initial"]))
 
 
+def test_egnn_ad2cat_other_sizes(golden):
+    """The static node features of the other particle counts EGNN_dynamics_AD2_cat knows (13, 33, 42, 55) as the reference
+    module builds them, and its backbone output for 33 and 42 atoms (two-layer hidden-32 net): oracle and the pita_amd
+    module's feature tables against the reference."""
+    from pita_amd.egnn_dynamics_ad2_cat import EGNN_dynamics_AD2_cat
+
+    g = golden("egnn_ad2cat_sizes.npz")
+    for n in (13, 33, 42, 55):
+        np.testing.assert_array_equal(O.egnn_ad2_cat_h_initial(n).numpy(), g[f"h_initial_{n}"])
+        m = EGNN_dynamics_AD2_cat(n, 3, hidden_nf=32, n_layers=2, condition_beta=True)
+        assert torch.equal(m.h_initial.float(), T(g[f"h_initial_{n}"]))
+    for n in (33, 42):
+        w = {k[len(f"w{n}."):]: T(v) for k, v in g.items() if k.startswith(f"w{n}.")}
+        F = O.egnn_ad2_cat_forward(w, T(g[f"t_{n}"]), T(g[f"x_{n}"]), T(g[f"beta_{n}"]), n, 3, n_layers=2)
+        assert rel(F.numpy(), g[f"F_{n}"]) < 2e-6, n
+
+
 def test_egnn_quirk_layout():
     h0 = O.egnn_node_features(T([0.5]), T([2.0]), 13).numpy()
     assert (h0[:6] == [0.5, 0.5]).all() and (h0[6] == [0.5, 2.0]).all() and (h0[7:] == [2.0, 2.0]).all()
