@@ -227,9 +227,13 @@ class WeightedSDEIntegrator:
     # ------------------------------------------------------------------ A1 integrate_sde
     @torch.no_grad()
     def integrate_sde(self, x1, energy_function, annealing_factor_schedule, inverse_temperature=1.0,
-                      annealing_factor_score=1.0, resampling_interval=None, noise=None, resample_u=None):
+                      annealing_factor_score=1.0, resampling_interval=None, noise=None, resample_u=None,
+                      mala_noise=None, mala_uniforms=None):
         """``noise``: optional [N, B, D] device normals (global batch); ``resample_u``: optional
-        iterable of float64 uniforms, one per resampling event (parity hooks)."""
+        iterable of float64 uniforms, one per resampling event; ``mala_noise`` [steps, B, D] / ``mala_uniforms``
+        [steps, B]: the proposal normals and accept uniforms of the post-processing MALA chain (parity hooks;
+        single rank)."""
+        self._mala_draws = (mala_noise, mala_uniforms)
         if resampling_interval is None:
             resampling_interval = self.resampling_interval
         N = self.num_integration_steps
@@ -309,7 +313,7 @@ class WeightedSDEIntegrator:
             fn = self.metropolis_hastings_mala_adaptive if self.adaptive_mcmc else self.metropolis_hastings_mala
             kw = dict(dt_init=self.dt_negative_time) if self.adaptive_mcmc else {}
             x, acceptance_rate_list = fn(x, energy_function, return_acceptance_rate=True, walker_offset=off, comm=comm,
-                                         **kw)
+                                         noise=self._mala_draws[0], uniforms=self._mala_draws[1], **kw)
         x = self._gather_final(x, comm, Bl)  # X1: the only collective on the resampling-free path
         return x, logweights, num_unique_idxs, sde_terms_all, acceptance_rate_list
 
@@ -387,7 +391,7 @@ class WeightedSDEIntegrator:
             fn = self.metropolis_hastings_mala_adaptive if self.adaptive_mcmc else self.metropolis_hastings_mala
             kw = dict(dt_init=self.dt_negative_time) if self.adaptive_mcmc else {}
             x, acceptance_rate_list = fn(x, energy_function, return_acceptance_rate=True, walker_offset=off, comm=comm,
-                                         **kw)
+                                         noise=self._mala_draws[0], uniforms=self._mala_draws[1], **kw)
         return self._gather_final(x, comm, Bl), logweights, num_unique_idxs, sde_terms_all, acceptance_rate_list
 
     def _gather_final(self, x, comm, Bl):

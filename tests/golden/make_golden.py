@@ -641,6 +641,104 @@ def gen_traj_debias_end():
          drift_A=np.stack([t.drift_A.reshape(B).detach().numpy() for t in terms]))
 
 
+def gen_traj_debias_long():
+    """PITA's DEFAULT regime at the LJ13 experiment's settings (configs/experiment/lj13.yaml:24-42 with
+    model/energytemp.yaml:64-85) over a real horizon: ``debias_inference=True``, ``resampling_interval=1`` (an event
+    after EVERY step of the window), two inference chunks per step (per-chunk 0.9-quantile clamp, sdes.py:230),
+    ``resample_at_end=True`` (sde_integration.py:158-183), then the 5 adaptive MALA steps at ``dt_negative_time=1e-13``
+    that quirk Q9 leaves switched on.  N = 200, B = 64, window [0, 160).  Every random number the reference draws is
+    replaced by a seeded numpy PCG64 stream (the fixture stores the seeds; tests regenerate the arrays):
+    ``randn_like`` -> pcg_noise(seed), ``torch.rand`` (one float64 uniform per resampling event, utils.py:112) ->
+    PCG64(seed + 4), MALA ``randn_like`` -> pcg_noise(seed + 2), MALA ``rand_like`` -> PCG64(seed + 3).
+    ``sample_cat_sys`` is wrapped to record the parent ids of every event."""
+    wt = dict(np.load(os.path.join(HERE, "egnn_weights_trainedlike.npz")))
+    sde, sched = build_lj13_stack(wt, debias=True)
+    N, B, chunk, seed, end = 200, 64, 32, 20261004, 160
+    n_mala = 5
+    gamma = annealing_factor_schedules.ConstantAnnealingFactorSchedule(4 / 3)
+    integ = sde_integration.WeightedSDEIntegrator(
+        sde=sde, num_integration_steps=N, start_resampling_step=0, end_resampling_step=end, lightning_module=FakeLM(),
+        partial_annealing_factor_schedule=None, resampling_interval=1, num_negative_time_steps=0,
+        post_mcmc_steps=n_mala, adaptive_mcmc=True, dt_negative_time=1e-13, batch_size=chunk, no_grad=True,
+        should_mean_free=True, resample_at_end=True)
+    e_raw = LJ(39, 13, 3, data_path="", temperature=1.0)
+
+    class Detached:
+        """See gen_post: the reference's MALA needs a detached alias under torch >= 2.10 to run at all."""
+
+        is_molecule, n_particles, n_spatial_dim = True, 13, 3
+
+        plain_calls = []  # walkers of the calls without force: [0] end-of-trajectory reweighting (:163), [1] MALA's first (:418)
+
+        def __call__(self, x, return_force=False):
+            if not return_force and len(self.plain_calls) < 2:
+                self.plain_calls.append(x.detach().clone().numpy())
+            return e_raw(x.detach(), return_force=return_force)
+
+    e = Detached()
+    noise = pcg_noise(seed, N, B, 39)
+    mala_noise = pcg_noise(seed + 2, n_mala, B, 39)
+    mala_u = np.random.Generator(np.random.PCG64(seed + 3)).random((n_mala, B), dtype=np.float32)
+    us = np.random.Generator(np.random.PCG64(seed + 4)).random(end + 1)
+    scale = float((sched.h(torch.tensor(1.0)) / gamma.gamma(torch.tensor(1.0))) ** 0.5)
+    x1 = data_utils.remove_mean(torch.from_numpy(pcg_noise(seed + 1, 1, B, 39)[0]) * scale, 13, 3)
+
+    cnt = {"f": 0, "rn": 0, "u": 0, "ru": 0}
+    xs, ids_all = [], []
+    real = (sde.f, torch.randn_like, torch.rand, torch.rand_like, sde_integration.sample_cat_sys)
+
+    def rec_f(t, x, *a, **k):
+        if cnt["f"] % (2 * 20) == 0:  # first chunk of steps 0, 20, 40, ...: the walkers ENTERING the step
+            xs.append(None)
+        if cnt["f"] % (2 * 20) in (0, 1):
+            xs[-1] = x.detach().clone().numpy() if xs[-1] is None else np.concatenate([xs[-1], x.detach().numpy()])
+        cnt["f"] += 1
+        return real[0](t, x, *a, **k)
+
+    def fixed_randn_like(x, *a, **k):
+        i = cnt["rn"]
+        cnt["rn"] += 1
+        if i < 2 * N:
+            return torch.from_numpy(noise[i // 2][(i % 2) * chunk:(i % 2 + 1) * chunk].copy()).reshape(x.shape)
+        return torch.from_numpy(mala_noise[i - 2 * N].copy()).reshape(x.shape)
+
+    def fixed_rand(*a, **k):
+        assert k.get("dtype") == torch.float64 and tuple(k.get("size")) == (1,)
+        v = torch.tensor([us[cnt["u"]]], dtype=torch.float64)
+        cnt["u"] += 1
+        return v
+
+    def fixed_rand_like(x, *a, **k):
+        v = torch.from_numpy(mala_u[cnt["ru"]].copy()).reshape(x.shape)
+        cnt["ru"] += 1
+        return v
+
+    def rec_cat(bs, logits):
+        ids, nu = real[4](bs, logits)
+        ids_all.append(np.asarray(ids, dtype=np.int64).copy())
+        return ids, nu
+
+    sde.f = rec_f
+    torch.randn_like, torch.rand, torch.rand_like = fixed_randn_like, fixed_rand, fixed_rand_like
+    sde_integration.sample_cat_sys = rec_cat
+    try:
+        x, logw, uniq, terms, acc = integ.integrate_sde(x1.clone(), e, gamma, inverse_temperature=1.0)
+    finally:
+        torch.randn_like, torch.rand, torch.rand_like = real[1:4]
+        sde_integration.sample_cat_sys = real[4]
+    # the reference's MALA draws one normal tensor in mala_proposal and one uniform tensor per step
+    assert cnt == {"f": 2 * N, "rn": 2 * N + n_mala, "u": end + 1, "ru": n_mala}, cnt
+    assert len(ids_all) == end + 1 and len(acc) == n_mala
+    out = dict(seed=seed, N=N, B=B, chunk=chunk, end=end, n_mala=n_mala, dt_mala=1e-13, x1=x1.numpy(),
+               x_at=np.stack(xs), at=np.arange(0, N, 20), x_final=x.detach().numpy(), x_pre_end=e.plain_calls[0],
+               x_post_end=e.plain_calls[1],
+               logweights=logw.detach().numpy(), num_unique=np.asarray(uniq), ids=np.stack(ids_all).astype(np.int16),
+               mala_acc=np.asarray(acc), prior_scale=scale, gamma=4 / 3, beta=1.0, sigma_min=0.05)
+    for nm in ("drift_A", "divergence_score", "cross_term", "dUt_dt"):
+        out[nm] = np.stack([getattr(t, nm).reshape(B).detach().numpy() for t in terms])
+    save("em_traj_lj13_debias_long.npz", **out)
+
+
 def gen_debias_variants():
     """Debiased drift terms of VEReverseSDE.f (sdes.py:151-239) in the configurations the experiment files do not
     exercise: pin_energy=True (energy_net.py:43-48: the energy is blended with the clamped target energy, which the
@@ -768,6 +866,6 @@ def gen_traj_gmm():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["schedules", "lj", "lj_smooth", "gmm", "egnn", "egnn_ad2cat", "egnn_ad2cat_sizes", "mlp", "prior", "resample", "traj_nodebias", "traj_1000",
-                             "traj_debias", "traj_debias_end", "debias_variants", "post", "post55", "traj_1000_lj55", "traj_gmm"]
+                             "traj_debias", "traj_debias_end", "traj_debias_long", "debias_variants", "post", "post55", "traj_1000_lj55", "traj_gmm"]
     for w in which:
         globals()["gen_" + w]()

@@ -701,7 +701,7 @@ def test_traj_1000_steps_golden(pa, golden, precision, n):
     for k, a in enumerate(at):
         e_ref, e_hip = rel(want[k], truth[k]), rel(got[k], truth[k])
         print(f"[traj1000/lj{n}/{precision}] step {a:4d}: HIP vs fp64 {e_hip:.2e}, reference vs fp64 {e_ref:.2e}, HIP vs reference {rel(got[k], want[k]):.2e}")
-        assert e_hip <= 4 * e_ref + 1e-6, (a, e_hip, e_ref)
+        assert e_hip <= 4 * e_ref, (a, e_hip, e_ref)
     # the whole trajectory through the integrator front end in one launch gives the same walkers
     sde = pa.VEReverseSDE(noise_schedule=sched, score_net=pa.ScoreNet(net), debias_inference=False)
     integ = pa.WeightedSDEIntegrator(sde=sde, num_integration_steps=N, start_resampling_step=0, end_resampling_step=N,
@@ -1825,6 +1825,150 @@ def test_debiased_resample_at_end_golden(pa, golden):
     np.testing.assert_allclose(logw[:N].cpu().numpy(), g["logweights"][:N], rtol=1e-2, atol=1e-2)
     np.testing.assert_allclose(logw[N].cpu().numpy(), g["logweights"][N], rtol=2e-4)
     assert rel(x, g["x_final"]) < 3e-3
+
+
+def _long_stack(pa, golden):
+    import copy
+
+    from pita_amd.energy_net import EnergyNet
+
+    w = golden("egnn_weights_trainedlike.npz")
+    net = make_net(pa, 13, 3, w)
+    sched = pa.ElucidatingNoiseSchedule(sigma_min=0.05, sigma_max=80.0, rho=7)
+    sde = pa.VEReverseSDE(noise_schedule=sched, score_net=pa.ScoreNet(net), energy_net=EnergyNet(copy.deepcopy(net)),
+                          debias_inference=True)
+    return sde, sched, pa.ConstantAnnealingFactorSchedule(4 / 3)
+
+
+def test_debiased_default_regime_long_golden(pa, golden, monkeypatch):
+    """PITA's DEFAULT regime at the LJ13 experiment's settings over a real horizon, against the reference's own run
+    (em_traj_lj13_debias_long.npz; configs/experiment/lj13.yaml:24-42, model/energytemp.yaml:64-85): debiased drift,
+    a resampling event after EVERY step of the window [0, 160), two inference chunks of 32 (per-chunk 0.9-quantile
+    clamp), resample_at_end, 5 adaptive MALA steps at dt = 1e-13; N = 200, B = 64, the fixture's PCG64 noise and
+    uniforms.  Through WeightedSDEIntegrator.integrate_sde:
+      * the parent ids of all 161 events, event by event.  A differing id must be a +-1 neighbour with the event's
+        uniform within fp32 rounding of the bin edge (counted; at most 2 % of the events may have one), and the
+        reference's ids are then fed forward so the run stays on the recorded trajectory and EVERY later event is still
+        compared exactly;
+      * the weight-drift terms (drift_A after the per-chunk clamp, divergence, cross term, dU/dt) of all 200 steps;
+      * the walkers entering steps 0, 20, ..., 180, the end-of-trajectory log-weights, the final walkers."""
+    from tests._long_fixture import ids_mismatch_is_bin_edge_tie, long_fixture_draws
+
+    import pita_amd.sde_integration as si
+
+    g = golden("em_traj_lj13_debias_long.npz")
+    N, B, chunk, end, n_mala = (int(g[k]) for k in ("N", "B", "chunk", "end", "n_mala"))
+    noise, mala_noise, mala_u, us = long_fixture_draws(g)
+    sde, sched, gam = _long_stack(pa, golden)
+    integ = pa.WeightedSDEIntegrator(sde=sde, num_integration_steps=N, start_resampling_step=0, end_resampling_step=end,
+                                     resampling_interval=1, num_negative_time_steps=0, post_mcmc_steps=n_mala,
+                                     adaptive_mcmc=True, dt_negative_time=float(g["dt_mala"]), batch_size=chunk,
+                                     resample_at_end=True)
+    events, seen = [], {"x": [], "terms": []}
+    real_cat, real_f = si.sample_cat_sys, sde.f
+
+    def forced_cat(bs, logits, u=None):
+        ids, nu = real_cat(bs, logits, u)
+        k = len(events)
+        want = torch.as_tensor(g["ids"][k].astype(np.int64), device=ids.device)
+        same = bool(torch.equal(ids, want))
+        if not same:
+            assert ids_mismatch_is_bin_edge_tie(logits.cpu().numpy(), float(us[k]), ids.cpu().numpy(), g["ids"][k]), \
+                f"event {k}: ids differ from the reference's by more than a bin-edge tie"
+        events.append(same)
+        return want, nu
+
+    def rec_f(t, x, *a, **k):
+        if len(seen["terms"]) % 20 == 0:
+            seen["x"].append(x.clone())
+        terms = real_f(t, x, *a, **k)
+        seen["terms"].append(terms)
+        return terms
+
+    monkeypatch.setattr(si, "sample_cat_sys", forced_cat)
+    sde.f = rec_f
+    x, logw, uniq, _, acc = integ.integrate_sde(cu(g["x1"]), pa.LennardJonesEnergy(39, 13, 3), gam, inverse_temperature=1.0,
+                                                noise=cu(noise), resample_u=[float(u) for u in us],
+                                                mala_noise=cu(mala_noise), mala_uniforms=cu(mala_u))
+    assert len(events) == end + 1 and len(seen["terms"]) == N
+    n_tie = sum(1 for e in events if not e)
+    assert n_tie <= max(1, (end + 1) // 50), f"{n_tie} of {end + 1} events needed the bin-edge allowance"
+    for s in range(N):
+        for nm in ("drift_A", "divergence_score", "cross_term", "dUt_dt"):
+            want = g[nm][s]
+            np.testing.assert_allclose(getattr(seen["terms"][s], nm).cpu().numpy(), want, rtol=3e-3,
+                                       atol=3e-3 * float(np.abs(want).mean()), err_msg=f"step {s} {nm}")
+    for k in range(len(g["at"])):
+        assert rel(seen["x"][k], g["x_at"][k]) < 3e-3, f"walkers entering step {int(g['at'][k])}"
+    assert logw.shape == (N + 1, B)
+    np.testing.assert_array_equal(logw[:N].cpu().numpy(), 0.0)  # an event (or the closed window) resets a every step
+    np.testing.assert_allclose(logw[N].cpu().numpy(), g["logweights"][N], rtol=2e-4)
+    assert uniq == list(g["num_unique"])  # the fed-forward ids are the reference's
+    assert rel(x, g["x_final"]) < 3e-3
+    # log p ~ -1e10 .. -1e21 on the collapsed final walkers: the 5 accept decisions per walker are signs of rounding
+    # differences, so only the shape of the result is pinned here (post_lj13.npz pins the chain's arithmetic)
+    assert len(acc) == n_mala and all(0.0 <= r <= 1.0 for r in acc)
+
+
+def test_debiased_default_regime_long_free_run(pa, golden):
+    """The same run WITHOUT feeding the reference's ids forward: after the first bin-edge tie two correct samplers are on
+    different trajectories, so the comparison is statistical -- the trace of distinct parents per event and the final
+    interatomic-distance distribution against the reference's, bounded by the sampler's own spread over resampling
+    uniforms."""
+    from tests._long_fixture import long_fixture_draws
+
+    g = golden("em_traj_lj13_debias_long.npz")
+    N, B, chunk, end = (int(g[k]) for k in ("N", "B", "chunk", "end"))
+    noise, _, _, us = long_fixture_draws(g)
+    sde, sched, gam = _long_stack(pa, golden)
+
+    def run(u):
+        integ = pa.WeightedSDEIntegrator(sde=sde, num_integration_steps=N, start_resampling_step=0,
+                                         end_resampling_step=end, resampling_interval=1, num_negative_time_steps=0,
+                                         post_mcmc_steps=0, batch_size=chunk, resample_at_end=False)
+        x, _, uniq, _, _ = integ.integrate_sde(cu(g["x1"]), pa.LennardJonesEnergy(39, 13, 3), gam,
+                                               inverse_temperature=1.0, noise=cu(noise), resample_u=[float(v) for v in u])
+        v = x.reshape(B, 13, 3)
+        d = torch.cdist(v, v)[:, torch.triu(torch.ones(13, 13, dtype=torch.bool), 1)].reshape(-1).cpu().numpy()
+        return np.asarray(uniq[:end], dtype=np.float64), d
+
+    uq, d = run(us)
+    ref_uq = g["num_unique"][:end].astype(np.float64)
+    vr = g["x_pre_end"].reshape(B, 13, 3)
+    ref_d = np.linalg.norm(vr[:, :, None] - vr[:, None], axis=-1)[:, np.triu(np.ones((13, 13), dtype=bool), 1)].reshape(-1)
+    others = [run(np.random.default_rng(100 + i).random(end + 1)) for i in range(3)]
+    spread_uq = max(abs(o[0].mean() - uq.mean()) for o in others)
+    spread_d = max(O.w2_1d(o[1], d) for o in others)
+    assert abs(uq.mean() - ref_uq.mean()) <= max(2 * spread_uq, 0.5), (uq.mean(), ref_uq.mean(), spread_uq)
+    assert O.w2_1d(d, ref_d) <= 2 * spread_d + 1e-3, (O.w2_1d(d, ref_d), spread_d)
+
+
+def test_default_regime_at_metric_batch(pa, golden):
+    """The LJ13 experiment's settings at the METRIC'S batch (65 536 walkers, inference chunks of 512, debiased, an event
+    after every step of the window, resample_at_end, 5 adaptive MALA steps at dt = 1e-13) for 20 steps: size-independent
+    properties -- every walker finite, the log-weights zero after every event and outside the window, the number of
+    distinct parents in [1, B] and below B whenever weights differ, the end-of-trajectory log-weights clamped at their
+    0.9 quantile, centre of mass zero."""
+    sde, sched, gam = _long_stack(pa, golden)
+    B, N, end = 65536, 20, 16
+    integ = pa.WeightedSDEIntegrator(sde=sde, num_integration_steps=N, start_resampling_step=0, end_resampling_step=end,
+                                     resampling_interval=1, num_negative_time_steps=0, post_mcmc_steps=5,
+                                     adaptive_mcmc=True, dt_negative_time=1e-13, batch_size=512, resample_at_end=True,
+                                     seed=11)
+    scale = float((sched.h(torch.tensor(1.0)) / gam.gamma(torch.tensor(1.0))) ** 0.5)
+    x1 = pa.Prior(scale=scale, n_particles=13, spatial_dim=3, seed=5).sample(B)
+    x, logw, uniq, terms, acc = integ.integrate_sde(x1, pa.LennardJonesEnergy(39, 13, 3), gam, inverse_temperature=1.0)
+    assert x.shape == (B, 39) and bool(torch.isfinite(x).all())
+    assert logw.shape == (N + 1, B) and len(uniq) == N + 1 and len(terms) == N and len(acc) == 5
+    assert bool((logw[:N] == 0).all())
+    assert all(1 <= u <= B for u in uniq) and all(u < B for u in uniq[:end]) and all(u == B for u in uniq[end:N])
+    fin = logw[N]
+    assert bool(torch.isfinite(fin).all())
+    q = torch.quantile(fin.double().cpu(), 0.9)
+    assert float(fin.max()) <= float(q) * (1 - 1e-6 * np.sign(float(q))) + 1e-6 * abs(float(q))
+    assert float(x.reshape(B, 13, 3).mean(1).abs().max()) < 1e-4
+    for t in terms:  # device-reduced statistics of every step answer the reference's logging calls
+        assert np.isfinite(float(t.drift_A.mean())) and np.isfinite(float(t.divergence_score.std()))
 
 
 @pytest.mark.parametrize("n,chunk", [(12, 12), (1000, 1000), (65536, 512), (65536, 65536), (777, 100), (5, 1), (4096, 1024), (4100, 1025)])

@@ -364,6 +364,72 @@ def test_traj_debias_resample_at_end(golden):
     assert rel(x.numpy(), g["x_final"]) < 2e-3
 
 
+def test_traj_debias_long_default_regime(golden):
+    """PITA's default regime at the LJ13 experiment's settings (em_traj_lj13_debias_long.npz: the reference's
+    integrate_sde, debiased, an event after EVERY step of [0, 160), two clamp chunks of 32, resample_at_end, 5 adaptive
+    MALA steps at dt = 1e-13; N = 200, B = 64).  The oracle restarts from the ten recorded walker sets (the x entering
+    steps 0, 20, ..., 180) and runs 4 steps from each on the fixture's noise and uniforms: every weight-drift term of
+    every step against the reference's, and the parent ids of every event IDENTICAL to the reference's (the reference's
+    ids are fed forward, so a segment never drifts off the recorded trajectory); then the end-of-trajectory reweighting
+    from the recorded pre-event walkers and the MALA chain.  (The full 200-step run is the GPU test's; on this CPU it
+    would take minutes.)"""
+    from tests._long_fixture import ids_mismatch_is_bin_edge_tie, long_fixture_draws
+
+    g = golden("em_traj_lj13_debias_long.npz")
+    bb = _lj13_backbone(golden)
+    sched, gam = O.Elucidating(0.05, 80.0, 7), O.GammaConstant(4 / 3)
+    N, B, chunk, end = (int(g[k]) for k in ("N", "B", "chunk", "end"))
+    noise, mala_noise, mala_u, us = long_fixture_draws(g)
+    times = torch.linspace(1.0, 0.0, N + 1)[:-1]
+    dt = 1.0 / N
+    seg = 4
+    n_events = n_tie = 0
+    for k, s0 in enumerate(g["at"]):
+        x = T(g["x_at"][k])
+        for s in range(int(s0), int(s0) + seg):
+            t = times[s]
+            parts = [O.f_debiased(bb, bb, sched, gam, t, x[lo:lo + chunk], 1.0) for lo in range(0, B, chunk)]
+            for nm, tol in (("drift_A", 2e-3), ("divergence_score", 2e-3), ("cross_term", 2e-3), ("dUt_dt", 2e-3)):
+                got = torch.cat([getattr(p_, nm) for p_ in parts]).numpy()
+                np.testing.assert_allclose(got, g[nm][s], rtol=tol, atol=tol * float(np.abs(g[nm][s]).mean()),
+                                           err_msg=f"step {s} {nm}")
+            dX = torch.cat([p_.drift_X for p_ in parts])
+            dA = torch.cat([p_.drift_A for p_ in parts])
+            tb = t * torch.ones(B)
+            x = x + (dX * dt + (sched.g(tb)[:, None] * T(noise[s])) * np.sqrt(dt))
+            if s < end:  # resampling_interval = 1: the log-weights of ONE step decide the event, then reset (:283-297)
+                a = dA * dt
+                ids = O.sample_cat_sys(a, float(us[s]))
+                want = g["ids"][s].astype(np.int64)
+                if not np.array_equal(ids, want):
+                    assert ids_mismatch_is_bin_edge_tie(a.numpy(), float(us[s]), ids, want), f"event {s}"
+                    n_tie += 1
+                n_events += 1
+                assert len(np.unique(want)) == int(g["num_unique"][s])
+                x = x[torch.from_numpy(want)]
+            x = O.remove_mean(x, 13, 3)
+    assert n_events == 4 * 8 and n_tie <= 1, (n_events, n_tie)
+    np.testing.assert_array_equal(g["logweights"][:N], 0.0)  # every in-window step resets a; outside the window a = 0
+    # end of trajectory (sde_integration.py:158-183): time of step `end`, a = 0 after the window
+    x_pre = T(g["x_pre_end"])
+    x, a_next, nu = O.resample_at_end(x_pre, torch.zeros(B), times[end], lambda xx: O.lj_logp(xx, 13, 3),
+                                      lambda tb, xx: O.energy_theta(bb, sched.h(tb), xx, 1.0), 4 / 3, float(us[end]))
+    np.testing.assert_allclose(a_next.numpy(), g["logweights"][N], rtol=2e-4)
+    assert nu == int(g["num_unique"][N])
+    np.testing.assert_array_equal(x.numpy(), g["x_post_end"])
+    # 5 adaptive MALA steps at dt = 1e-13 (quirk Q9).  log p is ~ -1e10 .. -1e21 on these collapsed walkers, so every
+    # accept decision is the sign of a rounding difference: rates are compared loosely, x tightly (moves are ~3e-7).
+    lf = lambda xx: O.lj_logp_force(xx, 13, 3)
+    lp, dtm = O.lj_logp(x, 13, 3), float(g["dt_mala"])
+    for k in range(int(g["n_mala"])):
+        x, lp, acc = O.mala_step(x, lp, lf, dtm, T(mala_noise[k]), torch.log(T(mala_u[k])))
+        x = O.remove_mean(x, 13, 3)
+        r = acc.float().mean().item()
+        assert abs(r - g["mala_acc"][k]) < 0.25
+        dtm = dtm * 1.1 if r > 0.55 else dtm / 1.1
+    assert rel(x.numpy(), g["x_final"]) < 1e-5
+
+
 @pytest.mark.parametrize("n", [13, 55])
 def test_post(golden, n):
     """negative-time descent, Langevin descent, MALA and adaptive MALA of the reference on the LJ13 and LJ55 targets."""
