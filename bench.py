@@ -302,6 +302,7 @@ def force_roofline(pita_amd, cfg, energy, x, dev, reps):
     if ks and B == cfg["walkers"]:
         v = max(ks.values(), key=lambda e: e["launches"])
         out["traffic"] = v["fetch_bytes_x2_streaming_correction"] + v["write_bytes"]
+        out["traffic_source"] = "committed PMC (profiles/pmc_sampler_current.json); not collected in this run"
     if cfg["target"] == "lj" and n == 55:  # VALU-bound: SURVEY 8(d) 1 485 pairs x 28 + 55 x 9 flop per walker-eval
         flop = 1485 * 28 + 55 * 9
         tf = B * flop / (us * 1e-6) / 1e12
@@ -365,6 +366,50 @@ def force_roofline(pita_amd, cfg, energy, x, dev, reps):
     return out
 
 
+def resample_exchange_leg(comm, x, every, B, world, rank, ids_fn, sync, events=3):
+    """Optional leg (--resample-every K; NOT part of the metric): what ONE global resampling event costs at this shard
+    when a trajectory resamples every K steps (PITA's default regime, sde_integration.py:283-297): all-gather of the B
+    log-weights per rank, the identical systematic resampling on every rank (``ids_fn``), and _Comm.exchange_rows -- one
+    uneven all_to_all_single that carries each rank the distinct parents it does not hold.  Times are per event on
+    this rank; rows_received counts the walkers that crossed ranks."""
+    import torch
+
+    gen = torch.Generator().manual_seed(77)
+    per_event, rows = [], []
+    for e in range(events + 1):  # the first event is a warm-up (communicator set-up)
+        a = (0.5 * torch.randn(B, generator=gen)).to(x.device)  # one step's log-weights: spread ~0.5 (fixture: 0.3-1)
+        comm.rows_received = 0
+        sync()
+        t0 = time.perf_counter()
+        ag = comm.all_gather(a)
+        ids = ids_fn(ag, 0.37 + 0.01 * e)
+        x = comm.exchange_rows(x, ids, B)
+        sync()
+        if e > 0:
+            per_event.append(time.perf_counter() - t0)
+            rows.append(int(comm.rows_received))
+    return {"every": every, "events_timed": events, "ms_per_event_this_rank": [round(1e3 * t, 4) for t in per_event],
+            "rows_received_from_other_ranks": rows, "rows_per_rank": B,
+            "bytes_received_per_event": [r * x.shape[1] * 4 for r in rows],
+            "amortised_ms_per_step": 1e3 * sum(per_event) / len(per_event) / max(every, 1),
+            "note": "log-weight all-gather + global systematic resampling + one uneven all_to_all_single "
+                    "(_Comm.exchange_rows); not inside the timed region, not part of `value`"}, x
+
+
+def rank_breakdown(world, gather_fn, wall_s, launches_s, allgather_s):
+    """Per-rank attribution of a multi-rank timed region: [wall seconds barrier-to-barrier, seconds inside the
+    sampler launches (HIP events), seconds of the final all-gather (HIP events)] of every rank, so a loss against the
+    one-GPU number can be pinned on a slow rank, on the collective or on neither (launch gaps / host)."""
+    import torch
+
+    mine = torch.tensor([wall_s, launches_s, allgather_s], dtype=torch.float64)
+    allr = gather_fn(mine).reshape(world, 3).tolist()
+    return {"wall_s": [r[0] for r in allr], "sampler_launches_s": [r[1] for r in allr],
+            "final_allgather_ms": [1e3 * r[2] for r in allr],
+            "slowest_rank": int(max(range(world), key=lambda r: allr[r][0])),
+            "max_over_min_wall": max(r[0] for r in allr) / max(min(r[0] for r in allr), 1e-12)}
+
+
 def dry_run(args, world, rank):
     """The multi-rank protocol of the real run -- process group, barrier, timed region, max-over-ranks, rank-0 JSON,
     final barrier -- with the kernels replaced by nothing, over gloo on the CPU."""
@@ -376,19 +421,48 @@ def dry_run(args, world, rank):
         torch.distributed.barrier()
     t0 = time.perf_counter()
     shard = torch.full((4, 3), float(rank))
+    t_ag = 0.0
     if world > 1:
         gathered = torch.empty(world * 4, 3)
+        ta = time.perf_counter()
         torch.distributed.all_gather_into_tensor(gathered, shard)
+        t_ag = time.perf_counter() - ta
         assert [float(gathered[4 * r, 0]) for r in range(world)] == [float(r) for r in range(world)]
         torch.distributed.barrier()
-    elapsed = time.perf_counter() - t0
+    wall = elapsed = time.perf_counter() - t0
+    per_rank = exchange = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+
+        def gather64(v):
+            out = torch.empty(world * v.numel(), dtype=torch.float64)
+            torch.distributed.all_gather_into_tensor(out, v)
+            return out
+
+        per_rank = rank_breakdown(world, gather64, wall, 0.0, t_ag)
+        if args.resample_every > 0:
+            from pita_amd.sde_integration import _Comm
+
+            Bl = 64
+
+            def ids_cpu(ag, u0):  # utils.py:111-120 on the host (the dry run has no kernels)
+                import numpy as np
+
+                w = torch.clip(torch.softmax(ag, -1), 1e-6, 1.0)
+                u = (u0 + torch.arange(ag.shape[0], dtype=torch.float64) / ag.shape[0]) % 1.0
+                ids = np.digitize(u.numpy(), torch.cumsum(w, -1).numpy(), right=True)
+                return torch.from_numpy(np.minimum(ids, ag.shape[0] - 1))
+
+            xs = torch.arange(Bl * 3, dtype=torch.float32).reshape(Bl, 3) + 1000.0 * rank
+            exchange, xs = resample_exchange_leg(_Comm(None), xs, args.resample_every, Bl, world, rank, ids_cpu,
+                                                 lambda: None)
+            assert xs.shape == (Bl, 3)
     if rank == 0:
         print(json.dumps({"metric": "dry run (no kernels)", "value": None, "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "scaling": "strong" if args.strong else "weak",
+                          "per_rank": per_rank, "resample_exchange": exchange,
                           "config": {"backend": "gloo" if world > 1 else None}}), flush=True)
     if world > 1:
         torch.distributed.barrier()
@@ -412,6 +486,10 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=0, help="CPU sample steps (default sized for ~10-20 s)")
     ap.add_argument("--precision", choices=["f32", "bf16x3", "f16x2"], default=None,
                     help="dense-layer arithmetic of the EGNN kernel (default: the library's)")
+    ap.add_argument("--resample-every", type=int, default=0,
+                    help="with several ranks: after the timed region, time global resampling events (log-weight all-gather + "
+                         "systematic resampling + _Comm.exchange_rows) at this shard, as a trajectory that resamples every K "
+                         "steps would pay them; reported beside the metric, never inside it")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / timing protocol only, no kernels and no GPU (gloo): CPU test of the "
                          "multi-rank path; the JSON carries value null")
@@ -564,17 +642,35 @@ def main():
     for i, s in enumerate(range(W, W + K, chunk)):
         net.sampler_run(x, tab[s:s + chunk], chunk, seed=seed, walker_offset=rank * B, step0=s, remove_mean=True)
         evs[i + 1].record()
+    ev_ag = torch.cuda.Event(enable_timing=True)
     if world > 1:  # X1: the only collective of the resampling-free path
         all_gather(gathered, x)
+        ev_ag.record()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
-    elapsed = time.perf_counter() - t0
+    wall = elapsed = time.perf_counter() - t0
+    per_rank = exchange = None
+    launch_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(n_launch)]
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         elapsed = float(all_reduce_max(t).item())
-    launch_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(n_launch)]
+
+        def gather64(v):
+            out = torch.empty(world * v.numel(), device=dev, dtype=torch.float64)
+            all_gather(out, v.to(dev))
+            return out.cpu()
+
+        # (the all-gather's event interval starts when the last sampler launch ends on this rank: it includes the wait
+        # for the slowest rank to arrive, which is what a rank loses to the collective)
+        per_rank = rank_breakdown(world, gather64, wall, sum(launch_ms) * 1e-3, evs[n_launch].elapsed_time(ev_ag) * 1e-3)
     assert torch.isfinite(x).all(), "sampler produced non-finite walkers"
+    if world > 1 and args.resample_every > 0:
+        from pita_amd.sde_integration import _Comm
+        from pita_amd.utils import sample_cat_sys
+
+        exchange, _ = resample_exchange_leg(_Comm(None), x.clone(), args.resample_every, B, world, rank,
+                                            lambda ag, u0: sample_cat_sys(ag.shape[0], ag, u0)[0], torch.cuda.synchronize)
 
     if rank == 0 and args.force_evals > 0 and args.force_last:
         energy = make_target(pita_amd, cfg, dev)
@@ -613,6 +709,8 @@ def main():
                 "algorithmic_flop_per_walker_step": alg, "algorithmic_flop_per_launch": alg * B * chunk,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "traffic": traffic,
+                "traffic_source": "committed PMC (profiles/pmc_sampler_current.json), scaled to this launch size; not "
+                                  "collected in this run" if traffic is not None else None,
                 "traffic_model": {k: pk[k] for k in ("fixed_bytes_per_launch", "bytes_per_walker_step", "fit_from",
                                                      "fetch_size_correction") if k in pk} if same else None,
                 "ms_per_launch": avg_ms, "launches": n_launch, "steps_per_launch": chunk,
@@ -624,7 +722,8 @@ def main():
                 "mfma16_per_walker_step": m16, "mfma32_per_walker_step": m32,
                 "mfma_pipe_busy_frac_at_2.4GHz": pipe_busy,
                 "valu_issue_frac": pk.get("valu_issue_frac") if same else None,
-                "pmc_source": pk.get("source") if same else None,
+                "pmc_source": ("committed PMC (profiles/pmc_sampler_current.json; not collected in this run): "
+                               + str(pk.get("source"))) if same else None,
                 "dense_layer_arithmetic": {0: "f32 MFMA", 1: "bf16 MFMA, 3-piece split", 2: "f16 MFMA, 2-piece split"}[net.precision],
                 "note": "achieved/frac follow SURVEY 8(d): algorithmic flops of the reference's formulation per launch / "
                         "launch time (HIP events on the launch stream) against the dense 16-bit MFMA peak.  *_executed "
@@ -658,6 +757,10 @@ def main():
             "roofline": roof,
             "roofline_force": force_rl,
         }
+        if world > 1:
+            out["per_rank"] = per_rank
+            if exchange is not None:
+                out["resample_exchange"] = exchange
         if ad2cat is not None:
             out["ad2cat_backbone"] = ad2cat
         if world == 1 and not args.no_cpu_baseline:

@@ -866,12 +866,8 @@ __global__ void __launch_bounds__(256, 2) lj13_mala_kernel(float* __restrict__ x
     if (tid == 0) {
       __hip_atomic_fetch_add(&q.sync[s], (1ull << 32) | (unsigned long long)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (q.adaptive) {  // grid-wide barrier: wait until every block has added its count
-        unsigned long long v = 0;
-        int spins = 0;
-        while (((v = __hip_atomic_load(&q.sync[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) < gridDim.x) {
-          if (++spins > q.spin_limit) { q.sync[q.nsteps] = 1; break; }  // never hang the device
-          __builtin_amdgcn_s_sleep(2);
-        }
+        const unsigned long long v = mala_grid_wait(q.sync, s, q.nsteps,
+                                                    (unsigned long long)gridDim.x + q.debug_missing_blocks, q.spin_limit);
         total_acc = (int)(v & 0xFFFFFFFFull);
       }
     }
@@ -1203,6 +1199,8 @@ static int run_mala_chain(int nsteps, double* dt_dev, int adaptive, int64_t tota
   PITA_HIP_CHECK(hipMemsetAsync(sync, 0, pita_lj_mala_workspace_bytes(nsteps), (hipStream_t)stream));
   q.sync = sync;
   q.spin_limit = mala_spin_limit();
+  const char* miss = getenv("PITA_DEBUG_MALA_MISSING_BLOCKS");
+  q.debug_missing_blocks = (miss && *miss) ? atoi(miss) : 0;
   const int rc = chain();
   if (rc != PITA_OK) return rc;
   return launch_mala_finish(dt_dev, sync, nsteps, (long long)total, adaptive, rates_out, stream);

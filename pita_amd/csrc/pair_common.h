@@ -30,6 +30,7 @@ struct MalaParams {
   const double* dt_dev;
   int nsteps, adaptive, remove_mean;
   int spin_limit;            // bound of the adaptive chain's grid-barrier spin (polls); see mala_spin_limit()
+  int debug_missing_blocks;  // tests only (PITA_DEBUG_MALA_MISSING_BLOCKS): the barrier waits for this many blocks that never come
   unsigned long long* sync;  // [nsteps + 1]: per step (blocks arrived << 32 | walkers accepted), error flag; zeroed by the wrapper
 };
 
@@ -37,6 +38,27 @@ struct MalaParams {
 // sync[nsteps] (the launch then poisons dt / rates with NaN and the caller reruns the launch-per-kernel chain).
 // PITA_DEBUG_MALA_SPIN_LIMIT overrides it (tests force the timeout path with 0).
 int mala_spin_limit();
+
+#ifdef __HIPCC__
+// One block's bounded wait for the `nblocks` arrivals of step s (sync[s] = arrivals << 32 | accepted walkers); returns the
+// counter as last read.  A wait that runs out raises the chain's error flag sync[nsteps].  The flag is read before the
+// first poll and every 64 polls, so once ANY block has given up every other wait of the launch ends at once: a chain
+// whose grid turned out not to be co-resident costs one timeout, not one per remaining step and block.
+__device__ __forceinline__ unsigned long long mala_grid_wait(unsigned long long* sync, int s, int nsteps,
+                                                             unsigned long long nblocks, int spin_limit) {
+  unsigned long long v = 0;
+  int spins = 0;
+  while (((v = __hip_atomic_load(&sync[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) < nblocks) {
+    if ((spins & 63) == 0 && __hip_atomic_load(&sync[nsteps], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+    if (++spins > spin_limit) {  // never hang the device
+      __hip_atomic_store(&sync[nsteps], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  return v;
+}
+#endif
 
 // rates_out[s] and the final dt from the per-step counts of a fused chain; NaN everywhere when the chain flagged a
 // barrier timeout (energy_kernels.hip)

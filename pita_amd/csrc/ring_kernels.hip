@@ -469,12 +469,8 @@ __global__ void __launch_bounds__(256) ring_mala_kernel(float* __restrict__ x, f
     if (threadIdx.x == 0) {
       const unsigned long long c = (unsigned long long)(cnt[0] + cnt[1] + cnt[2] + cnt[3]);
       __hip_atomic_fetch_add(&q.sync[s], (1ull << 32) | c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      unsigned long long v = 0;
-      int spins = 0;
-      while (((v = __hip_atomic_load(&q.sync[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) < gridDim.x) {
-        if (++spins > q.spin_limit) { q.sync[q.nsteps] = 1; break; }  // never hang the device
-        __builtin_amdgcn_s_sleep(2);
-      }
+      const unsigned long long v = mala_grid_wait(q.sync, s, q.nsteps, (unsigned long long)gridDim.x + q.debug_missing_blocks,
+                                                  q.spin_limit);
       total_acc = (int)(v & 0xFFFFFFFFull);
     }
     __syncthreads();

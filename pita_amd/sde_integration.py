@@ -486,7 +486,9 @@ class WeightedSDEIntegrator:
               walker_offset=0, comm=None, fused=True):
         """MALA with the reference's finite-mask semantics (:362-470): non-finite-logp walkers are set aside and
         re-appended AFTER the valid ones (order not preserved, quirk Q7).  Proposal, accept/reject and the step-size
-        adaptation run as HIP kernels with the step size on the device: no host synchronisation inside the chain.
+        adaptation run as HIP kernels with the step size on the device: no host synchronisation inside the chain (the
+        fused chains synchronise once, after the launch, when the acceptance rates -- which also say whether an adaptive
+        chain's grid barrier held -- are copied to the host).
         With several ranks the acceptance count is all-reduced so the adaptation sees the global rate, as the
         reference (which runs the chain on the gathered batch on every rank) does."""
         n, d = self._geometry(x, energy_function)
@@ -537,15 +539,18 @@ class WeightedSDEIntegrator:
                 if energy_function.fused_mala(x_valid, logp, steps, dt_dev, adaptive, total, noise=nz, uniforms=uu, seed=key,
                                               walker_offset=walker_offset, walker_ids=ids, step0=0, remove_mean=rm,
                                               rates_out=rates) is not None:
-                    if adaptive and bool(torch.isnan(rates[:steps]).any()):
+                    # the validity check is the chain's ONE host synchronisation: the transfer of the rates the caller
+                    # asked for (or of the final step size when it did not)
+                    host_rates = rates[:steps].tolist() if return_acceptance_rate else (dt_dev.tolist() if adaptive else [])
+                    if adaptive and any(math.isnan(r) for r in host_rates):
                         x_valid.copy_(backup[0])
                         logp.copy_(backup[1])
                         dt_dev.copy_(backup[2])
                         rates.zero_()
                         self._fused_mala_fallbacks = getattr(self, "_fused_mala_fallbacks", 0) + 1
                     else:
-                        done = steps
-                        steps = 0
+                        out = torch.cat([x_valid, x_invalid], dim=0)
+                        return (out, host_rates) if return_acceptance_rate else (out, None)
             for i in range(steps):
                 if Bv > 0:
                     _, grad = energy_function(x_valid, return_force=True)

@@ -127,6 +127,19 @@ def test_bench_gpus_flag_launches_that_many_ranks():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 2 and out["config"]["backend"] == "gloo"
+    # the multi-rank line explains itself: per-rank wall / launch / all-gather times (gathered from every rank)
+    pr = out["per_rank"]
+    assert len(pr["wall_s"]) == 2 and len(pr["sampler_launches_s"]) == 2 and len(pr["final_allgather_ms"]) == 2
+    assert all(w > 0 for w in pr["wall_s"]) and pr["slowest_rank"] in (0, 1) and pr["max_over_min_wall"] >= 1.0
+    assert out["resample_exchange"] is None
+    # --resample-every: the cost of global resampling events at the shard (log-weight all-gather + _Comm.exchange_rows)
+    r3 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                         "--dry-run", "--resample-every", "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert r3.returncode == 0, r3.stderr[-2000:]
+    ex = json.loads([ln for ln in r3.stdout.splitlines() if ln.startswith("{")][0])["resample_exchange"]
+    assert ex["every"] == 1 and len(ex["ms_per_event_this_rank"]) == ex["events_timed"] == 3
+    assert all(0 <= r <= ex["rows_per_rank"] for r in ex["rows_received_from_other_ranks"])
+    assert ex["amortised_ms_per_step"] > 0
     r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run"], capture_output=True, text=True,
                         timeout=300, env=env)
     assert r1.returncode == 0 and json.loads(r1.stdout.strip().splitlines()[-1])["n_gpus"] == 1

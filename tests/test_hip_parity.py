@@ -1038,6 +1038,46 @@ def test_fused_adaptive_mala_barrier_timeout_falls_back(pa, golden, name, monkey
     assert getattr(integ, "_fused_mala_fallbacks", 0) == 0 and torch.equal(got[0], want[0]) and got[1] == want[1]
 
 
+@pytest.mark.parametrize("name", ["lj13", "lj55", "dw4"])
+def test_fused_adaptive_mala_failed_barrier_costs_one_timeout(pa, golden, name, monkeypatch):
+    """A chain whose grid is not fully co-resident (here: PITA_DEBUG_MALA_MISSING_BLOCKS=1 makes every barrier wait for
+    a block that never arrives) must give up ONCE: the block whose bounded spin runs out raises the error flag and
+    every other wait of the launch -- same step, later steps -- ends as soon as it sees the flag.  40 steps with a
+    spin budget of 200 000 polls per wait: one timeout's worth of device time, not 40, and NaN rates."""
+    gen = torch.Generator().manual_seed(6)
+    steps = 40
+    if name == "lj13":
+        g = golden("post_lj13.npz")
+        e, dt = pa.LennardJonesEnergy(39, 13, 3), 3e-4
+        base = T(g["x0"])
+        x0 = O.remove_mean(base[torch.arange(2000) % base.shape[0]] + 0.02 * torch.randn(2000, 39, generator=gen), 13, 3).cuda()
+    else:
+        e, n, d, x0 = _ring_target(pa, name, 2000, gen)
+        dt = 2e-4 if name == "lj55" else 0.05
+    lp = e(x0)
+
+    def timed(nsteps):
+        xc, lpc = x0.clone(), lp.clone()
+        dt_dev = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        rates = torch.zeros(nsteps, device="cuda")
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0.record()
+        assert e.fused_mala(xc, lpc, nsteps, dt_dev, True, x0.shape[0], seed=1, rates_out=rates) is not None
+        t1.record()
+        torch.cuda.synchronize()
+        return t0.elapsed_time(t1), rates, dt_dev
+
+    monkeypatch.setenv("PITA_DEBUG_MALA_MISSING_BLOCKS", "1")
+    monkeypatch.setenv("PITA_DEBUG_MALA_SPIN_LIMIT", "200000")
+    timed(1)
+    one, r1, _ = timed(1)
+    many, r40, d40 = timed(steps)
+    assert torch.isnan(r1).all() and torch.isnan(r40).all() and torch.isnan(d40).all()
+    print(f"[barrier bail-out/{name}] 1 step {one:.2f} ms, {steps} steps {many:.2f} ms")
+    assert many < 3 * one + 5.0, (one, many)
+
+
 def test_mala_sets_non_finite_walkers_aside(pa, golden):
     """Quirk Q7 (sde_integration.py:366-369,400): walkers whose target log-density is not finite are taken out before
     the chain and re-appended AFTER the valid ones (order not preserved); the chain itself runs on the valid rows with
@@ -1948,7 +1988,7 @@ def test_default_regime_at_metric_batch(pa, golden):
     after every step of the window, resample_at_end, 5 adaptive MALA steps at dt = 1e-13) for 20 steps: size-independent
     properties -- every walker finite, the log-weights zero after every event and outside the window, the number of
     distinct parents in [1, B] and below B whenever weights differ, the end-of-trajectory log-weights clamped at their
-    0.9 quantile, centre of mass zero."""
+    0.9 quantile (a tenth of them equal the maximum), centre of mass zero."""
     sde, sched, gam = _long_stack(pa, golden)
     B, N, end = 65536, 20, 16
     integ = pa.WeightedSDEIntegrator(sde=sde, num_integration_steps=N, start_resampling_step=0, end_resampling_step=end,
@@ -1964,8 +2004,8 @@ def test_default_regime_at_metric_batch(pa, golden):
     assert all(1 <= u <= B for u in uniq) and all(u < B for u in uniq[:end]) and all(u == B for u in uniq[end:N])
     fin = logw[N]
     assert bool(torch.isfinite(fin).all())
-    q = torch.quantile(fin.double().cpu(), 0.9)
-    assert float(fin.max()) <= float(q) * (1 - 1e-6 * np.sign(float(q))) + 1e-6 * abs(float(q))
+    # clamped at the 0.9 quantile (sde_integration.py:179): the top tenth of the walkers sits AT the maximum
+    assert int((fin == fin.max()).sum()) >= int(0.1 * (B - 1))
     assert float(x.reshape(B, 13, 3).mean(1).abs().max()) < 1e-4
     for t in terms:  # device-reduced statistics of every step answer the reference's logging calls
         assert np.isfinite(float(t.drift_A.mean())) and np.isfinite(float(t.divergence_score.std()))

@@ -66,6 +66,12 @@ def test_checkpoint_layouts_without_ema_and_empty_checkpoint():
 
 
 def test_w2_matches_oracle():
+    """N4: POT UNPINNED.  The reference computes these distances with POT's ``ot.emd2_1d``
+    (distribution_distances.py:16-17), which is not installed here and not in the reference tree: W2 is checked against
+    the oracle's own restatement of the 1-D quantile coupling (closed form for equal sample counts), W1 additionally
+    against an independent third-party implementation (scipy.stats.wasserstein_distance)."""
+    from scipy.stats import wasserstein_distance
+
     from pita_amd import metrics
 
     rng = np.random.default_rng(0)
@@ -74,6 +80,8 @@ def test_w2_matches_oracle():
     assert abs(d["t/energy_w2"] - O.w2_1d(a, b)) < 1e-9
     assert abs(metrics._w_1d(torch.tensor(a[:500]), torch.tensor(b), 2) ** 0.5 - O.w2_1d(a[:500], b)) < 1e-9
     assert d["t/num_cropped"] == 0
+    assert abs(d["t/energy_w1"] - wasserstein_distance(a, b)) < 1e-9
+    assert abs(metrics._w_1d(torch.tensor(a[:500]), torch.tensor(b), 1) - wasserstein_distance(a[:500], b)) < 1e-9
 
 
 def test_openmm_system_xml_tables_roundtrip(tmp_path):
