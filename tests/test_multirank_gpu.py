@@ -49,7 +49,8 @@ def test_bench_two_ranks_on_one_device():
     env = _env()
     env["PITA_BENCH_ONE_DEVICE"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-                        "--walkers", "1024", "--no-cpu-baseline", "--no-debiased", "--force-evals", "0"],
+                        "--walkers", "1024", "--no-cpu-baseline", "--no-debiased", "--force-evals", "0",
+                        "--resample-every", "1"],
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -57,3 +58,10 @@ def test_bench_two_ranks_on_one_device():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_walkers"] == 2048 and out["scaling"] == "weak"
     assert out["value"] > 0 and 0 < out["roofline"]["frac"] <= 1
+    # the multi-rank line attributes its time: per-rank wall / launch / all-gather seconds, and the optional exchange leg
+    pr = out["per_rank"]
+    assert len(pr["wall_s"]) == 2 and all(0 < a <= w for a, w in zip(pr["sampler_launches_s"], pr["wall_s"]))
+    assert all(ms >= 0 for ms in pr["final_allgather_ms"]) and pr["slowest_rank"] in (0, 1)
+    ex = out["resample_exchange"]
+    assert ex["rows_per_rank"] == 1024 and len(ex["ms_per_event_this_rank"]) == 3
+    assert all(0 < r <= 1024 for r in ex["rows_received_from_other_ranks"])
