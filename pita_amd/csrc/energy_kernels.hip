@@ -1090,6 +1090,7 @@ extern "C" int pita_lj_logp_force(const float* x, float* logp, float* force, int
   p.cw = -p.inv_T * (2.0f * energy_factor * eps * 12.0f / p.rm2); p.co = -p.inv_T * osc_scale;
   if (n == 13 && d == 3 && B > 0) {
     PITA_REQUIRE(x && logp, "pita_lj_logp_force: null argument");
+    if (getenv("PITA_LJ13_RING")) return ring_launch_energy(E_LJ, x, logp, force, B, n, d, p, stream);
     // 2 lanes per walker while the batch cannot fill every SIMD twice with 1 lane per walker
     const bool two = B <= 256LL * 1024;
     const int WPB = two ? 128 : 256;

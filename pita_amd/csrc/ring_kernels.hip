@@ -78,6 +78,13 @@ __device__ __forceinline__ float quad_sum(float v) {
   v = dpp_add<0xb1>(v);
   return dpp_add<0x4e>(v);
 }
+// sum over each DPP row (16 aligned lanes), in every lane of the row
+__device__ __forceinline__ float row_sum(float v) {
+  v = dpp_add<0xb1>(v);
+  v = dpp_add<0x4e>(v);
+  v = dpp_add<0x124>(v);  // row_ror 4
+  return dpp_add<0x128>(v);  // row_ror 8
+}
 __device__ __forceinline__ float lane_bcast(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
@@ -85,25 +92,30 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
 template <int N, int DIM>
 struct Ring {
   static_assert(N >= 2 && N <= 64 && DIM >= 1 && DIM <= 3, "ring kernels: a walker must fit one wavefront");
-  static constexpr int WPW = 64 / N;                     // walkers per wavefront
+  // a walker owns an aligned group of STRIDE lanes -- a quad, a DPP row or the whole wave -- so that the sums over
+  // its particles are DPP reductions (quad_sum / row_sum / wave_sum); lanes N .. STRIDE-1 of a group shadow its first
+  // particles (valid reads, identical arithmetic) and are masked out of sums and stores
+  static constexpr int STRIDE = N <= 4 ? 4 : N <= 16 ? 16 : 64;
+  static constexpr int WPW = 64 / STRIDE;                // walkers per wavefront
   static constexpr int NH = (N - 1) / 2;                 // circulant distances with two distinct partners
   static constexpr bool EVEN = (N % 2) == 0;             // + the antipodal distance N / 2
   static constexpr int TAB_F = WPW * 2 * N * 4;          // floats of one coordinate table of a wave
-  static_assert(WPW == 1 || N == 4, "reductions are written for one walker per wave or for quads");
+  static_assert(2 * N >= STRIDE, "a shadow lane must map onto a particle");
 
   int wl, i;      // walker of the wave, particle
-  bool real;      // false: a shadow lane past the last whole walker
+  bool real;      // false: a shadow lane past the walker's last particle
   int bp[NH > 0 ? NH : 1];  // ds_bpermute byte address of the lane holding particle (i - dd) mod N of this walker
 
   __device__ explicit Ring(int lane) {
-    int l = lane;
-    real = l < WPW * N;
-    if (!real) l -= WPW * N;
-    wl = l / N;
-    i = l - wl * N;
+    wl = lane / STRIDE;
+    i = lane - wl * STRIDE;
+    real = i < N;
+    if (!real) i -= N;
 #pragma unroll
-    for (int dd = 1; dd <= NH; ++dd) bp[dd - 1] = 4 * (wl * N + (i >= dd ? i - dd : i - dd + N));
+    for (int dd = 1; dd <= NH; ++dd) bp[dd - 1] = 4 * (wl * STRIDE + (i >= dd ? i - dd : i - dd + N));
   }
+  // sum of v over the walker's lanes (callers zero the shadow lanes), in every lane of the walker
+  static __device__ __forceinline__ float walker_sum(float v);
   // this lane's first-copy entry of a wave's table
   __device__ float* entry(float* tab) const { return tab + (wl * 2 * N + i) * 4; }
   __device__ float* walker_tab(float* tab) const { return tab + wl * 2 * N * 4; }
@@ -116,6 +128,11 @@ struct Ring {
     *reinterpret_cast<float4*>(t + N * 4) = e;
   }
 };
+
+template <int N, int DIM>
+__device__ __forceinline__ float Ring<N, DIM>::walker_sum(float v) {
+  return STRIDE == 4 ? quad_sum(v) : STRIDE == 16 ? row_sum(v) : wave_sum(v);
+}
 
 // f = sum over the partners j of coef_ij (x_i - x_j), coef = e'(r)/r (LJ: in units of 12 eps / rm^2);
 // e = this lane's share of the pair energy: the pairs (i, i + dd), LJ in units of eps -- accumulated as
@@ -191,19 +208,19 @@ __device__ __forceinline__ void ring_finish(const Ring<N, DIM>& r, const float (
     float c[DIM], osc = 0.f;
 #pragma unroll
     for (int k = 0; k < DIM; ++k) {
-      const float mean = wave_sum(r.real ? xi[k] : 0.f) * (1.0f / (float)N);
+      const float mean = Ring<N, DIM>::walker_sum(r.real ? xi[k] : 0.f) * (1.0f / (float)N);
       c[k] = xi[k] - mean;
       osc = fmaf(c[k], c[k], osc);
       f[k] = fmaf(p.cw, f[k], p.co * c[k]);
     }
     if (WANT_E) {
       const float v = fmaf(2.0f * p.energy_factor * p.eps, e, 0.5f * p.osc_scale * osc);
-      logp = -p.inv_T * wave_sum(r.real ? v : 0.f);
+      logp = -p.inv_T * Ring<N, DIM>::walker_sum(r.real ? v : 0.f);
     }
   } else {
 #pragma unroll
     for (int k = 0; k < DIM; ++k) f[k] = -p.inv_T * f[k];
-    if (WANT_E) logp = -p.inv_T * quad_sum(e);
+    if (WANT_E) logp = -p.inv_T * Ring<N, DIM>::walker_sum(r.real ? e : 0.f);
   }
 }
 
@@ -612,6 +629,7 @@ struct RingLaunch {
 int ring_launch_energy(int kind, const float* x, float* logp, float* force, int64_t B, int n, int d, const PairParams& p,
                        void* stream) {
   if (kind == E_LJ && n == 55 && d == 3) return RingLaunch<55, 3, E_LJ>::energy(x, logp, force, B, p, (hipStream_t)stream);
+  if (kind == E_LJ && n == 13 && d == 3) return RingLaunch<13, 3, E_LJ>::energy(x, logp, force, B, p, (hipStream_t)stream);
   if (kind == E_DW && n == 4 && d == 2) return RingLaunch<4, 2, E_DW>::energy(x, logp, force, B, p, (hipStream_t)stream);
   return 1;
 }

@@ -1,11 +1,12 @@
 #!/bin/bash
-# SQ counters of the kernels of one command, two passes (development aid; run through gpurun from the repo root):
+# SQ counters of the kernels of one command, three passes (development aid; run through gpurun from the repo root):
 #   tools/pmc_kernels.sh <tag> <kernel-name-substring> <python script and args...>
 TAG=$1; PAT=$2; shift 2
 export TMPDIR=/tmp
 O=$PWD/gpurun_out/$TAG; mkdir -p $O; R=$PWD
 ( cd /tmp; rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/p1 -- python3 $R/$* > $O/p1.log 2>&1
-  rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE --output-format csv -d $O/p2 -- python3 $R/$* > $O/p2.log 2>&1 )
+  rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE --output-format csv -d $O/p2 -- python3 $R/$* > $O/p2.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_INSTS_VMEM GRBM_GUI_ACTIVE --output-format csv -d $O/p3 -- python3 $R/$* > $O/p3.log 2>&1 )
 python3 - "$O" "$PAT" <<'PY'
 import csv, glob, collections, sys
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
