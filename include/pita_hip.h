@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PITA_ABI_VERSION 5
+#define PITA_ABI_VERSION 6
 
 enum {
   PITA_OK = 0,
@@ -146,6 +146,17 @@ int pita_egnn_wide_uses_matrix_pipe(const pita_egnn_wide_t* net);
 /* what = 0: vel[B, n*d] = backbone(t[B], x[B, n*d], beta[B]) (mean-free); 1: denoiser D_theta(h = t, x); 2: score */
 int pita_egnn_wide_eval(pita_egnn_wide_t* net, int what, const float* t, const float* x, const float* beta /*nullable*/,
                         float* out, int64_t B, void* stream);
+
+/* Forward-mode derivative of the EDM denoiser D(h, x) = c_s x + c_out F(c_noise(h), c_in(h) x, beta) around this
+ * backbone, one tangent direction per launch (arguments as pita_egnn_jvp):  dout = J_x D . vx + dD/dh . vh, out = D
+ * (nullable), dot_out[b * dot_stride + dot_off] = <x_b, dD_b>, diag_acc[b] += dD[b, dir].  What the debiased
+ * Feynman-Kac regime (pita/src/models/components/sdes.py:151-239 with utils.py:30-51, energy_net.py:51-62) needs of
+ * EGNN_dynamics_AD2_cat: trace J_x D, J_x D^T x and <x, dD/dh> are sums over such directions; the reference takes them
+ * from vmap(jacrev) and autograd.  fp32 vector-pipe kernel (csrc/egnn_wide_kernel.hip: egnn_wide_jvp_kernel). */
+int pita_egnn_wide_jvp(pita_egnn_wide_t* net, const float* h, const float* x, const float* beta /*nullable*/,
+                       const float* vx /*nullable*/, int dir, const float* vh /*nullable*/, float* out /*nullable*/,
+                       float* dout /*nullable*/, float* dot_out /*nullable*/, int64_t dot_stride, int64_t dot_off,
+                       float* diag_acc /*nullable*/, int64_t B, void* stream);
 
 /* Diagonal Gaussian mixture with equal weights.
  * replaces GMM.__call__ (pita/src/energies/gmm_energy.py:87-90) ->

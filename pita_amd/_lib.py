@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpita_hip.so")
 
 STEP_STRIDE = 16
-ABI_VERSION = 5
+ABI_VERSION = 6
 ST_CS, ST_CIN, ST_COUT, ST_CNOISE, ST_H, ST_G2, ST_GAMMA, ST_DT, ST_NOISE_SCALE, ST_SQRT_DT, ST_BETA = range(11)
 
 
@@ -85,6 +85,8 @@ _PROTOS = {
     "pita_egnn_wide_destroy": (c_int, [c_void_p]),
     "pita_egnn_wide_uses_matrix_pipe": (c_int, [c_void_p]),
     "pita_egnn_wide_eval": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "pita_egnn_wide_jvp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "pita_egnn_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "pita_egnn_edm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "pita_egnn_jvp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

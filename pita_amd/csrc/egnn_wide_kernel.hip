@@ -211,6 +211,225 @@ __global__ void __launch_bounds__(256) egnn_wide_kernel(WideParams p) {
 }
 
 }  // namespace
+
+// ---------------------------------------------------------------------------- forward-mode derivative (vector pipe)
+// dD = J_x D(h, x) . vx + dD/dh . vh of the EDM denoiser D(h, x) = c_s x + c_out F(c_noise(h), c_in(h) x, beta) around
+// this backbone, ONE tangent direction per launch beside the primal (the building block the debiased Feynman-Kac
+// regime needs, sdes.py:151-239: trace J_x D, J_x D^T x and <x, dD/dh> are sums of such directions; the reference takes
+// them from vmap(jacrev) / autograd).  Same mapping as egnn_wide_kernel -- one wavefront = one walker, lane = hidden
+// feature -- with a tangent beside every primal quantity: the node features, the partner table Wb dh_j, the positions.
+// A tangent dense layer costs what the primal one does (v_readlane + v_fma per k on the same weight row); the SiLU
+// derivative sigma (1 + z (1 - sigma)) re-uses the primal's sigmoid.  fp32 FMA chains like the primal.
+struct WideJvpParams {
+  WideParams base;       // mode is ignored: the denoiser (mode 1) is differentiated
+  const float* vx;       // nullable [B, n*dim]: position direction; null -> unit vector e_dir (dir >= 0) or zero (dir < 0)
+  const float* vh;       // nullable [B]: direction in h
+  int dir;
+  float* dout;           // nullable [B, n*dim]
+  float* dot_out;        // nullable: dot_out[b * dot_stride + dot_off] = <x_b, dD_b>
+  long long dot_stride, dot_off;
+  float* diag_acc;       // nullable: diag_acc[b] += dD[b, dir]
+};
+
+namespace {
+
+// silu(z) and d silu / dz from one sigmoid
+__device__ __forceinline__ float wsilu_d(float z, float& dz) {
+  const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * z));
+  dz = sg * fmaf(z, 1.0f - sg, 1.0f);
+  return z * sg;
+}
+// primal and tangent of one dense layer on the same weight row (registers)
+template <int HK>
+__device__ __forceinline__ void dense_reg2(const float (&row)[WIDE_HP], float v, float dv, float& acc, float& dacc) {
+#pragma unroll
+  for (int k = 0; k < HK; ++k) {
+    acc = fmaf(row[k], wlane(v, k), acc);
+    dacc = fmaf(row[k], wlane(dv, k), dacc);
+  }
+}
+template <int HK>
+__device__ __forceinline__ void dense_mem2(const float* __restrict__ wt, int lane, float v, float dv, float& acc, float& dacc) {
+#pragma unroll 8
+  for (int k = 0; k < HK; ++k) {
+    const float w = wt[k * WIDE_HP + lane];
+    acc = fmaf(w, wlane(v, k), acc);
+    dacc = fmaf(w, wlane(dv, k), dacc);
+  }
+}
+
+template <int HK>
+__global__ void __launch_bounds__(256) egnn_wide_jvp_kernel(WideJvpParams q) {
+  const WideParams& p = q.base;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = p.n, DIM = p.dim;
+  const int per_wave = 5 * n * WIDE_HP + 6 * n * 4;
+  float* hf = lds + wave * per_wave;     // [n][64] node features
+  float* At = hf + n * WIDE_HP;          // [n][64] Wa h_i + b1
+  float* Bt = At + n * WIDE_HP;          // [n][64] Wb h_j
+  float* dhf = Bt + n * WIDE_HP;         // tangents of hf and Bt (Wa dh_i is formed per node on the fly)
+  float* dBt = dhf + n * WIDE_HP;
+  float* pos = dBt + n * WIDE_HP;        // [n][4] each: pos, pos0, posn and their tangents
+  float* pos0 = pos + n * 4;
+  float* posn = pos0 + n * 4;
+  float* dpos = posn + n * 4;
+  float* dpos0 = dpos + n * 4;
+  float* dposn = dpos0 + n * 4;
+  const long long nw = (long long)gridDim.x * waves;
+  for (long long w = (long long)blockIdx.x * waves + wave; w < p.B; w += nw) {
+    const float hval = p.t[w];
+    const float bet = p.has_beta ? p.beta[w] : 0.f;
+    const float vh = q.vh ? q.vh[w] : 0.f;
+    // score_net.py:26-29 and their h-derivatives
+    const float c_s = 1.0f / (1.0f + hval), c_in = 1.0f / sqrtf(1.0f + hval), sh = sqrtf(hval);
+    const float c_out = sh * c_in, tfeat = 0.125f * logf(hval);
+    const float dc_s = -c_s * c_s, dc_in = -0.5f * c_in * c_s, dc_out = 0.5f * c_in / sh + sh * dc_in;
+    const float dtf = vh * (0.125f / hval);
+    for (int qd = lane; qd < n * DIM; qd += 64) {
+      const int i = qd / DIM, k = qd - i * DIM;
+      const float xv = p.x[w * n * DIM + qd];
+      const float dx = q.vx ? q.vx[w * n * DIM + qd] : (qd == q.dir ? 1.0f : 0.0f);
+      const float v = c_in * xv, dv = fmaf(c_in, dx, (vh * dc_in) * xv);
+      pos[i * 4 + k] = v; pos0[i * 4 + k] = v;
+      dpos[i * 4 + k] = dv; dpos0[i * 4 + k] = dv;
+    }
+    {
+      const float et = p.w[lane], eb = p.w[64 + lane];
+      for (int i = 0; i < n; ++i) {
+        hf[i * WIDE_HP + lane] = fmaf(et, tfeat, fmaf(eb, bet, p.estatic[i * WIDE_HP + lane]));
+        dhf[i * WIDE_HP + lane] = et * dtf;
+      }
+    }
+    wfence();
+    for (int l = 0; l < p.L; ++l) {
+      const float* wl = p.w + WIDE_HEAD + (size_t)l * WideLayer::SIZE;
+      for (int i = 0; i < n; ++i) {
+        const float hv = hf[i * WIDE_HP + lane], dhv = dhf[i * WIDE_HP + lane];
+        At[i * WIDE_HP + lane] = dense_mem<HK>(wl + WideLayer::WA, lane, hv, wl[WideLayer::B1 + lane]);
+        float b = 0.f, db = 0.f;
+        dense_mem2<HK>(wl + WideLayer::WB, lane, hv, dhv, b, db);
+        Bt[i * WIDE_HP + lane] = b;
+        dBt[i * WIDE_HP + lane] = db;
+      }
+      wfence();
+      float w2[WIDE_HP], wc1[WIDE_HP];
+#pragma unroll
+      for (int k = 0; k < HK; ++k) {
+        w2[k] = wl[WideLayer::W2 + k * WIDE_HP + lane];
+        wc1[k] = wl[WideLayer::WC1 + k * WIDE_HP + lane];
+      }
+      const float wr = wl[WideLayer::WR + lane], we = wl[WideLayer::WE + lane], b2 = wl[WideLayer::B2 + lane];
+      const float watt = wl[WideLayer::WATT + lane], batt = wl[WideLayer::BATT], bc1 = wl[WideLayer::BC1 + lane];
+      const float wc2 = wl[WideLayer::WC2 + lane];
+      const bool last = (l == p.L - 1);
+      for (int i = 0; i < n; ++i) {
+        const float Ai = At[i * WIDE_HP + lane];
+        const float dAi = dense_mem<HK>(wl + WideLayer::WA, lane, dhf[i * WIDE_HP + lane], 0.f);
+        float pi[3] = {0.f, 0.f, 0.f}, p0i[3] = {0.f, 0.f, 0.f}, xacc[3] = {0.f, 0.f, 0.f};
+        float dpi[3] = {0.f, 0.f, 0.f}, dp0i[3] = {0.f, 0.f, 0.f}, dxacc[3] = {0.f, 0.f, 0.f};
+        for (int k = 0; k < DIM; ++k) {
+          pi[k] = pos[i * 4 + k]; p0i[k] = pos0[i * 4 + k];
+          dpi[k] = dpos[i * 4 + k]; dp0i[k] = dpos0[i * 4 + k];
+        }
+        float agg = 0.f, dagg = 0.f;
+        for (int j = 0; j < n; ++j) {
+          if (j == i) continue;
+          float df[3] = {0.f, 0.f, 0.f}, ddf[3] = {0.f, 0.f, 0.f}, radial = 0.f, ea = 0.f, dradial = 0.f, dea = 0.f;
+          for (int k = 0; k < DIM; ++k) {
+            df[k] = pi[k] - pos[j * 4 + k];
+            ddf[k] = dpi[k] - dpos[j * 4 + k];
+            radial = fmaf(df[k], df[k], radial);
+            dradial = fmaf(df[k], ddf[k], dradial);
+            const float e0 = p0i[k] - pos0[j * 4 + k];
+            ea = fmaf(e0, e0, ea);
+            dea = fmaf(e0, dp0i[k] - dpos0[j * 4 + k], dea);
+          }
+          dradial *= 2.0f; dea *= 2.0f;
+          float g1, g2, gc;
+          const float z1 = fmaf(we, ea, fmaf(wr, radial, Ai + Bt[j * WIDE_HP + lane]));
+          const float dz1 = fmaf(we, dea, fmaf(wr, dradial, dAi + dBt[j * WIDE_HP + lane]));
+          const float m1 = wsilu_d(z1, g1), dm1 = g1 * dz1;
+          float z2 = b2, dz2 = 0.f;
+          dense_reg2<HK>(w2, m1, dm1, z2, dz2);
+          float m = wsilu_d(z2, g2), dm = g2 * dz2;
+          if (p.attention) {
+            const float a = fast_sigmoid(wwave_sum(watt * m) + batt);
+            const float da = a * (1.0f - a) * wwave_sum(watt * dm);
+            dm = fmaf(dm, a, m * da);
+            m *= a;
+          }
+          agg += m; dagg += dm;
+          float zc = bc1, dzc = 0.f;
+          dense_reg2<HK>(wc1, m, dm, zc, dzc);
+          const float c1 = wsilu_d(zc, gc), dc1 = gc * dzc;
+          float cs = wwave_sum(wc2 * c1), dcs = wwave_sum(wc2 * dc1);
+          if (p.tanh_on) {
+            const float th = accurate_tanh(cs);
+            dcs = (1.0f - th * th) * p.coord_scale * dcs;
+            cs = th * p.coord_scale;
+          }
+          const float sq = sqrtf(radial + 1e-8f), inv = 1.0f / (sq + 1.0f);
+          const float dinv = -inv * inv * (0.5f * dradial / sq);
+          const float dsc = fmaf(dinv, cs, inv * dcs);  // d(inv cs)
+          for (int k = 0; k < DIM; ++k) {
+            xacc[k] = fmaf(df[k] * inv, cs, xacc[k]);
+            dxacc[k] = fmaf(ddf[k], inv * cs, fmaf(df[k], dsc, dxacc[k]));
+          }
+        }
+        if (lane < DIM) {
+          const int k = lane < 3 ? lane : 0;
+          posn[i * 4 + lane] = pi[k] + xacc[k];
+          dposn[i * 4 + lane] = dpi[k] + dxacc[k];
+        }
+        if (!last) {
+          const float hv = hf[i * WIDE_HP + lane], dhv = dhf[i * WIDE_HP + lane];
+          float z = wl[WideLayer::BN1 + lane], dz = 0.f, gz;
+          dense_mem2<HK>(wl + WideLayer::WN1A, lane, hv, dhv, z, dz);
+          dense_mem2<HK>(wl + WideLayer::WN1B, lane, agg, dagg, z, dz);
+          const float sz = wsilu_d(z, gz);
+          float o = wl[WideLayer::BN2 + lane], d_o = 0.f;
+          dense_mem2<HK>(wl + WideLayer::WN2, lane, sz, gz * dz, o, d_o);
+          hf[i * WIDE_HP + lane] = hv + o;
+          dhf[i * WIDE_HP + lane] = dhv + d_o;
+        }
+      }
+      wfence();
+      for (int qd = lane; qd < n * 4; qd += 64) { pos[qd] = posn[qd]; dpos[qd] = dposn[qd]; }
+      wfence();
+    }
+    float mean[3] = {0.f, 0.f, 0.f}, dmean[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < DIM; ++k) {
+      float s = 0.f, ds = 0.f;
+      for (int i = 0; i < n; ++i) { s += pos[i * 4 + k] - pos0[i * 4 + k]; ds += dpos[i * 4 + k] - dpos0[i * 4 + k]; }
+      mean[k] = s / (float)n; dmean[k] = ds / (float)n;
+    }
+    float dot = 0.f, diag = 0.f;
+    for (int qd = lane; qd < n * DIM; qd += 64) {
+      const int i = qd / DIM, k = qd - i * DIM;
+      const float F = (pos[i * 4 + k] - pos0[i * 4 + k]) - mean[k];
+      const float dF = (dpos[i * 4 + k] - dpos0[i * 4 + k]) - dmean[k];
+      const float xc = p.x[w * n * DIM + qd];
+      const float dx = q.vx ? q.vx[w * n * DIM + qd] : (qd == q.dir ? 1.0f : 0.0f);
+      const float dD = fmaf(c_s, dx, fmaf(c_out, dF, vh * fmaf(dc_s, xc, dc_out * F)));
+      if (p.out) p.out[w * n * DIM + qd] = fmaf(c_s, xc, c_out * F);
+      if (q.dout) q.dout[w * n * DIM + qd] = dD;
+      dot = fmaf(xc, dD, dot);
+      if (qd == q.dir) diag = dD;
+    }
+    if (q.dot_out) {
+      const float s = wwave_sum(dot);
+      if (lane == 0) q.dot_out[w * q.dot_stride + q.dot_off] = s;
+    }
+    if (q.diag_acc && q.dir >= 0) {
+      const float s = wwave_sum(diag);
+      if (lane == 0) q.diag_acc[w] += s;
+    }
+    wfence();
+  }
+}
+
+}  // namespace
 }  // namespace pita
 
 using namespace pita;
@@ -375,6 +594,49 @@ extern "C" int pita_egnn_wide_eval(pita_egnn_wide_t* net, int what, const float*
     const unsigned grid = (unsigned)(want < cap ? want : cap);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(waves * 64), per_wave * waves, (hipStream_t)stream, p);
     if (hipGetLastError() != hipSuccess) rc = fail(PITA_EHIP, "pita_egnn_wide_eval: launch failed");
+  }
+  if (switched) (void)hipSetDevice(prev);
+  return rc;
+}
+
+// Forward-mode derivative of the denoiser around the wide backbone (vector-pipe kernel; see egnn_wide_jvp_kernel)
+extern "C" int pita_egnn_wide_jvp(pita_egnn_wide_t* net, const float* h, const float* x, const float* beta, const float* vx,
+                                  int dir, const float* vh, float* out, float* dout, float* dot_out, int64_t dot_stride,
+                                  int64_t dot_off, float* diag_acc, int64_t B, void* stream) {
+  PITA_REQUIRE(net && B >= 0, "pita_egnn_wide_jvp: bad argument");
+  if (B == 0) return PITA_OK;
+  PITA_REQUIRE(h && x, "pita_egnn_wide_jvp: null argument");
+  PITA_REQUIRE(beta || !net->cfg.condition_beta, "pita_egnn_wide_jvp: beta required (condition_beta)");
+  PITA_REQUIRE(dir < net->cfg.n_particles * net->cfg.n_dim, "pita_egnn_wide_jvp: direction %d out of range", dir);
+  PITA_REQUIRE(!diag_acc || (dir >= 0 && !vx), "pita_egnn_wide_jvp: diag_acc needs a unit direction");
+  int prev = -1;
+  bool switched = false;
+  if (net->device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != net->device)
+    switched = hipSetDevice(net->device) == hipSuccess;
+  WideJvpParams q{};
+  WideParams& p = q.base;
+  p.w = net->d_w; p.estatic = net->d_estatic;
+  p.n = net->cfg.n_particles; p.dim = net->cfg.n_dim; p.H = net->cfg.hidden_nf; p.L = net->cfg.n_layers;
+  p.attention = net->cfg.attention; p.tanh_on = net->cfg.tanh; p.has_beta = net->cfg.condition_beta;
+  p.coord_scale = net->cfg.coords_range / (float)net->cfg.n_layers;
+  p.B = B; p.mode = 1; p.x = x; p.t = h; p.beta = beta; p.out = out;
+  q.vx = vx; q.vh = vh; q.dir = vx ? -1 : dir; q.dout = dout; q.dot_out = dot_out; q.dot_stride = dot_stride;
+  q.dot_off = dot_off; q.diag_acc = diag_acc;
+  const size_t per_wave = sizeof(float) * (size_t)(5 * p.n * WIDE_HP + 6 * p.n * 4);
+  int waves = 4;
+  while (waves > 1 && per_wave * waves > 150 * 1024) waves >>= 1;
+  auto kernel = p.H <= 32 ? egnn_wide_jvp_kernel<32> : egnn_wide_jvp_kernel<64>;
+  int rc = PITA_OK;
+  if (per_wave * waves > 150 * 1024) {
+    rc = fail(PITA_EUNSUPPORTED, "pita_egnn_wide_jvp: %d particles need %zu B of LDS per wave", p.n, per_wave);
+  } else if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(per_wave * waves)) != hipSuccess) {
+    rc = fail(PITA_EHIP, "pita_egnn_wide_jvp: cannot reserve %zu B of LDS", per_wave * waves);
+  } else {
+    const long long want = (B + waves - 1) / waves, cap = (long long)net->n_cu * 2;
+    const unsigned grid = (unsigned)(want < cap ? want : cap);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(waves * 64), per_wave * waves, (hipStream_t)stream, q);
+    if (hipGetLastError() != hipSuccess) rc = fail(PITA_EHIP, "pita_egnn_wide_jvp: launch failed");
   }
   if (switched) (void)hipSetDevice(prev);
   return rc;

@@ -125,3 +125,34 @@ class EGNN_dynamics_AD2_cat(nn.Module):
     def edm(self, what, h_t, x_t, beta):
         """what=1: denoiser D_theta, what=2: score (D_theta - x)/h, EDM preconditioning fused (score_net.py:13-43)."""
         return self._eval(what, h_t, x_t, beta)
+
+    def jvp(self, h_t, x_t, beta, vx=None, direction=-1, vh=None, want_primal=True, want_tangent=True, dot_out=None,
+            dot_col=0, diag_acc=None):
+        """(D, dD): the EDM denoiser around this backbone and its forward-mode derivative along ONE direction,
+        dD = J_x D . vx + dD/dh . vh -- same contract as ``EGNN_dynamics.jvp`` (pita_egnn_wide_jvp, fp32 vector-pipe
+        kernel).  With it ``VEReverseSDE(debias_inference=True)`` runs on this backbone: the exact divergence of the
+        score (utils.py:30-51), grad_x E_theta (energy_net.py:51-62) and dE_theta/dt (sdes.py:218) are assembled from
+        dim + 1 such launches per net (sdes.py's forward-mode path)."""
+        x_t = _lib.dev_tensor(x_t, "x_t")
+        B = x_t.shape[0]
+        h_t = _lib.dev_tensor(h_t, "h_t").reshape(-1).expand(B).contiguous()
+        b = None
+        if self.condition_beta:
+            if beta is None:
+                raise ValueError("EGNN_dynamics_AD2_cat(condition_beta=True) needs beta")
+            b = _as_batch(beta, B, x_t.device)
+        if vx is not None:
+            vx = _lib.dev_tensor(vx, "vx")
+        if vh is not None:
+            vh = _lib.dev_tensor(vh, "vh").reshape(-1).expand(B).contiguous()
+        out = torch.empty_like(x_t) if want_primal else None
+        dout = torch.empty_like(x_t) if want_tangent else None
+        stride = 1
+        if dot_out is not None:
+            assert dot_out.is_cuda and dot_out.dtype == torch.float32 and dot_out.is_contiguous()
+            stride = dot_out.shape[1] if dot_out.dim() == 2 else 1
+        _lib.check(_lib.lib().pita_egnn_wide_jvp(self._native(x_t.device), h_t.data_ptr(), x_t.data_ptr(), _lib.ptr(b),
+                                                 _lib.ptr(vx), int(direction), _lib.ptr(vh), _lib.ptr(out), _lib.ptr(dout),
+                                                 _lib.ptr(dot_out), stride, int(dot_col), _lib.ptr(diag_acc), B,
+                                                 _lib.stream_ptr(x_t.device)), "pita_egnn_wide_jvp")
+        return out, dout

@@ -3,7 +3,8 @@
 * ``forward_energy`` -- E_theta(h, x) (energy_net.py:14-49): one backbone forward on the EDM-scaled input
   (``pita_edm_scale_input``), then the per-walker reduction kernel ``pita_energy_theta``.
 * ``forward`` -- grad_x E_theta (autograd in the reference, :51-62): ONE reverse-mode launch of the HIP EGNN
-  (``EGNN_dynamics.vjp``): grad E = ((1 + c_s) x - D - J_x D^T x) / h.
+  (``EGNN_dynamics.vjp``): grad E = ((1 + c_s) x - D - J_x D^T x) / h; backbones with a forward-mode derivative only
+  (``EGNN_dynamics_AD2_cat.jvp``) assemble J_x D^T x from one launch per direction.
 """
 import torch
 from torch import nn
@@ -46,11 +47,18 @@ class EnergyNet(nn.Module):
         return E
 
     def forward(self, ht, xt, beta, pin=False, t=None, energy_function=None):
-        if pin or self.precondition_beta or not hasattr(self.net, "vjp"):
-            raise NotImplementedError("EnergyNet.forward: needs the HIP EGNN backbone, pin=False, precondition_beta=False")
+        if pin or self.precondition_beta or not (hasattr(self.net, "vjp") or hasattr(self.net, "jvp")):
+            raise NotImplementedError("EnergyNet.forward: needs a HIP EGNN backbone, pin=False, precondition_beta=False")
         x = _lib.dev_tensor(xt, "xt")
         h = self._batch(ht, x.shape[0], x.device)
-        Dx, jtx = self.net.vjp(h, x, beta)
+        if hasattr(self.net, "vjp"):
+            Dx, jtx = self.net.vjp(h, x, beta)
+        else:  # forward-mode backbone (EGNN_dynamics_AD2_cat): (J^T x)_k = <x, J e_k>, one launch per direction
+            jtx, Dx = torch.empty_like(x), None
+            for k in range(x.shape[1]):
+                out, _ = self.net.jvp(h, x, beta, direction=k, want_primal=(k == 0), want_tangent=False, dot_out=jtx,
+                                      dot_col=k)
+                Dx = out if k == 0 else Dx
         return (((1 + 1 / (1 + h))[:, None] * x - Dx) - jtx) / h[:, None]
 
     def denoiser(self, h_t, x_t, beta):

@@ -66,10 +66,14 @@ for k, (a, mn, ops) in enumerate(ins):
             tgt = a + 4 + 4 * (off - 65536)
             lo = next(i for i, x in enumerate(addr) if x >= tgt)
             loops.append((lo, k))
-# innermost loops only: drop any loop that contains another
-inner = [l for l in loops if not any(o != l and l[0] <= o[0] and o[1] <= l[1] for o in loops)]
+# innermost loops WITH matrix instructions: drop any such loop that contains another one (short wait / copy loops inside
+# an item loop do not hide it)
+loops = sorted(set(loops))
+has_mfma = lambda l: any(mn.startswith("v_mfma") for _, mn, _ in ins[l[0]:l[1] + 1])
+mloops = [l for l in loops if has_mfma(l)]
+inner = [l for l in mloops if not any(o != l and l[0] <= o[0] and o[1] <= l[1] for o in mloops)]
 print(f"{os.path.relpath(obj, ROOT)}: {name.split('(')[0]}")
-print(f"{len(ins)} instructions, {len(loops)} loops, {len(inner)} innermost\n")
+print(f"{len(ins)} instructions, {len(loops)} loops, {len(inner)} innermost with matrix instructions\n")
 for lo, hi in inner:
     seg = ins[lo:hi + 1]
     h = collections.Counter(classify(mn, ops) for _, mn, ops in seg)
