@@ -89,19 +89,69 @@ __device__ __forceinline__ float dense_mem(const float* __restrict__ wt, int lan
   return acc;
 }
 
+// Broadcast through LDS instead of v_readlane_b32 (PITA_WIDE_READLANE=1 at compile time restores the register form):
+// lane k parks v_k in a 64-float per-wave slot and every lane reads the vector back four k at a time (all lanes the same
+// address: a broadcast ds_read_b128), so a dense layer is 1 store + 16 loads + 64 v_fma instead of 64 v_readlane + 64
+// v_fma.  v_readlane writes a scalar register, and those writes turned out to be the bound of the register form: the
+// kernels issued ~0.5 instructions per cycle and COMPUTE UNIT whatever the number of resident waves.  Same operands in
+// the same k order: bit-identical results.
+#ifndef PITA_WIDE_READLANE
+#define PITA_WIDE_READLANE 0
+#endif
+typedef float wf32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void bc_put(float* bc, int lane, float v) {
+  bc[lane] = v;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+template <int HK>
+__device__ __forceinline__ float dense_reg_b(const float (&row)[WIDE_HP], float* bc, int lane, float v, float acc) {
+#if PITA_WIDE_READLANE
+  return dense_reg<HK>(row, v, acc);
+#else
+  bc_put(bc, lane, v);
+  float a1 = 0.f, a2 = 0.f, a3 = 0.f;  // four partial sums: a 64-long dependent FMA chain per layer was the kernel's bound
+#pragma unroll
+  for (int k = 0; k < HK; k += 4) {
+    const wf32x4 a = *reinterpret_cast<const wf32x4*>(bc + k);
+    acc = fmaf(row[k], a[0], acc); a1 = fmaf(row[k + 1], a[1], a1);
+    a2 = fmaf(row[k + 2], a[2], a2); a3 = fmaf(row[k + 3], a[3], a3);
+  }
+  asm volatile("" ::: "memory");
+  return (acc + a1) + (a2 + a3);
+#endif
+}
+template <int HK>
+__device__ __forceinline__ float dense_mem_b(const float* __restrict__ wt, float* bc, int lane, float v, float acc) {
+#if PITA_WIDE_READLANE
+  return dense_mem<HK>(wt, lane, v, acc);
+#else
+  bc_put(bc, lane, v);
+  float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 4
+  for (int k = 0; k < HK; k += 4) {
+    const wf32x4 a = *reinterpret_cast<const wf32x4*>(bc + k);
+    acc = fmaf(wt[k * WIDE_HP + lane], a[0], acc); a1 = fmaf(wt[(k + 1) * WIDE_HP + lane], a[1], a1);
+    a2 = fmaf(wt[(k + 2) * WIDE_HP + lane], a[2], a2); a3 = fmaf(wt[(k + 3) * WIDE_HP + lane], a[3], a3);
+  }
+  asm volatile("" ::: "memory");
+  return (acc + a1) + (a2 + a3);
+#endif
+}
+
 // HK = hidden width rounded up to 32 (the k extent of every dense layer)
 template <int HK>
-__global__ void __launch_bounds__(256) egnn_wide_kernel(WideParams p) {
+__global__ void __launch_bounds__(256, 2) egnn_wide_kernel(WideParams p) {  // two waves per SIMD: at most 256 registers
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = p.n, DIM = p.dim;
-  const int per_wave = 3 * n * WIDE_HP + 3 * n * 4;
+  const int per_wave = 3 * n * WIDE_HP + 3 * n * 4 + WIDE_HP;
   float* hf = lds + wave * per_wave;     // [n][64] node features
   float* At = hf + n * WIDE_HP;          // [n][64] Wa h_i + b1
   float* Bt = At + n * WIDE_HP;          // [n][64] Wb h_j
   float* pos = Bt + n * WIDE_HP;         // [n][4] positions entering the layer
   float* pos0 = pos + n * 4;             // [n][4] input geometry (frozen edge attribute)
   float* posn = pos0 + n * 4;            // [n][4] positions leaving the layer
+  float* bc = posn + n * 4;              // [64] broadcast slot of the dense layers
   const long long nw = (long long)gridDim.x * waves;
   for (long long w = (long long)blockIdx.x * waves + wave; w < p.B; w += nw) {
     if (p.only_bad) {
@@ -137,8 +187,8 @@ __global__ void __launch_bounds__(256) egnn_wide_kernel(WideParams p) {
       // per-node first-layer terms of the edge MLP: W1 [h_i, h_j, r, e] = Wa h_i + Wb h_j + w_r r + w_e e
       for (int i = 0; i < n; ++i) {
         const float hv = hf[i * WIDE_HP + lane];
-        At[i * WIDE_HP + lane] = dense_mem<HK>(wl + WideLayer::WA, lane, hv, wl[WideLayer::B1 + lane]);
-        Bt[i * WIDE_HP + lane] = dense_mem<HK>(wl + WideLayer::WB, lane, hv, 0.f);
+        At[i * WIDE_HP + lane] = dense_mem_b<HK>(wl + WideLayer::WA, bc, lane, hv, wl[WideLayer::B1 + lane]);
+        Bt[i * WIDE_HP + lane] = dense_mem_b<HK>(wl + WideLayer::WB, bc, lane, hv, 0.f);
       }
       wfence();
       float w2[WIDE_HP], wc1[WIDE_HP];
@@ -166,10 +216,10 @@ __global__ void __launch_bounds__(256) egnn_wide_kernel(WideParams p) {
             ea = fmaf(e0, e0, ea);
           }
           float m = wsilu(fmaf(we, ea, fmaf(wr, radial, Ai + Bt[j * WIDE_HP + lane])));
-          m = wsilu(dense_reg<HK>(w2, m, b2));
+          m = wsilu(dense_reg_b<HK>(w2, bc, lane, m, b2));
           if (p.attention) m *= fast_sigmoid(wwave_sum(watt * m) + batt);
           agg += m;
-          const float c1 = wsilu(dense_reg<HK>(wc1, m, bc1));
+          const float c1 = wsilu(dense_reg_b<HK>(wc1, bc, lane, m, bc1));
           float cs = wwave_sum(wc2 * c1);
           if (p.tanh_on) cs = accurate_tanh(cs) * p.coord_scale;
           const float inv = 1.0f / (sqrtf(radial + 1e-8f) + 1.0f);
@@ -178,9 +228,9 @@ __global__ void __launch_bounds__(256) egnn_wide_kernel(WideParams p) {
         if (lane < DIM) posn[i * 4 + lane] = pi[lane < 3 ? lane : 0] + xacc[lane < 3 ? lane : 0];
         if (!last) {  // node model, recurrent (the last layer's node update is dead: h_final is discarded)
           const float hv = hf[i * WIDE_HP + lane];
-          float z = dense_mem<HK>(wl + WideLayer::WN1A, lane, hv, wl[WideLayer::BN1 + lane]);
-          z = dense_mem<HK>(wl + WideLayer::WN1B, lane, agg, z);
-          const float o = dense_mem<HK>(wl + WideLayer::WN2, lane, wsilu(z), wl[WideLayer::BN2 + lane]);
+          float z = dense_mem_b<HK>(wl + WideLayer::WN1A, bc, lane, hv, wl[WideLayer::BN1 + lane]);
+          z = dense_mem_b<HK>(wl + WideLayer::WN1B, bc, lane, agg, z);
+          const float o = dense_mem_b<HK>(wl + WideLayer::WN2, bc, lane, wsilu(z), wl[WideLayer::BN2 + lane]);
           hf[i * WIDE_HP + lane] = hv + o;  // A / B tables of this layer were built from the old features
         }
       }
@@ -241,21 +291,60 @@ __device__ __forceinline__ float wsilu_d(float z, float& dz) {
 }
 // primal and tangent of one dense layer on the same weight row (registers)
 template <int HK>
-__device__ __forceinline__ void dense_reg2(const float (&row)[WIDE_HP], float v, float dv, float& acc, float& dacc) {
+__device__ __forceinline__ void dense_reg2(const float (&row)[WIDE_HP], float* bc, int lane, float v, float dv, float& acc,
+                                           float& dacc) {
+#if PITA_WIDE_READLANE
 #pragma unroll
   for (int k = 0; k < HK; ++k) {
     acc = fmaf(row[k], wlane(v, k), acc);
     dacc = fmaf(row[k], wlane(dv, k), dacc);
   }
+#else
+  bc[lane] = v;
+  bc_put(bc + WIDE_HP, lane, dv);
+  float pa[4] = {acc, 0.f, 0.f, 0.f}, pd[4] = {dacc, 0.f, 0.f, 0.f};  // same partial sums as dense_reg_b for the primal
+#pragma unroll
+  for (int k = 0; k < HK; k += 4) {
+    const wf32x4 a = *reinterpret_cast<const wf32x4*>(bc + k), b = *reinterpret_cast<const wf32x4*>(bc + WIDE_HP + k);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      pa[e] = fmaf(row[k + e], a[e], pa[e]);
+      pd[e] = fmaf(row[k + e], b[e], pd[e]);
+    }
+  }
+  asm volatile("" ::: "memory");
+  acc = (pa[0] + pa[1]) + (pa[2] + pa[3]);
+  dacc = (pd[0] + pd[1]) + (pd[2] + pd[3]);
+#endif
 }
 template <int HK>
-__device__ __forceinline__ void dense_mem2(const float* __restrict__ wt, int lane, float v, float dv, float& acc, float& dacc) {
+__device__ __forceinline__ void dense_mem2(const float* __restrict__ wt, float* bc, int lane, float v, float dv, float& acc,
+                                           float& dacc) {
+#if PITA_WIDE_READLANE
 #pragma unroll 8
   for (int k = 0; k < HK; ++k) {
     const float w = wt[k * WIDE_HP + lane];
     acc = fmaf(w, wlane(v, k), acc);
     dacc = fmaf(w, wlane(dv, k), dacc);
   }
+#else
+  bc[lane] = v;
+  bc_put(bc + WIDE_HP, lane, dv);
+  float pa[4] = {acc, 0.f, 0.f, 0.f}, pd[4] = {dacc, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int k = 0; k < HK; k += 4) {
+    const wf32x4 a = *reinterpret_cast<const wf32x4*>(bc + k), b = *reinterpret_cast<const wf32x4*>(bc + WIDE_HP + k);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float w = wt[(k + e) * WIDE_HP + lane];
+      pa[e] = fmaf(w, a[e], pa[e]);
+      pd[e] = fmaf(w, b[e], pd[e]);
+    }
+  }
+  asm volatile("" ::: "memory");
+  acc = (pa[0] + pa[1]) + (pa[2] + pa[3]);
+  dacc = (pd[0] + pd[1]) + (pd[2] + pd[3]);
+#endif
 }
 
 template <int HK>
@@ -264,7 +353,7 @@ __global__ void __launch_bounds__(256) egnn_wide_jvp_kernel(WideJvpParams q) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = p.n, DIM = p.dim;
-  const int per_wave = 5 * n * WIDE_HP + 6 * n * 4;
+  const int per_wave = 5 * n * WIDE_HP + 6 * n * 4 + 2 * WIDE_HP;
   float* hf = lds + wave * per_wave;     // [n][64] node features
   float* At = hf + n * WIDE_HP;          // [n][64] Wa h_i + b1
   float* Bt = At + n * WIDE_HP;          // [n][64] Wb h_j
@@ -276,6 +365,7 @@ __global__ void __launch_bounds__(256) egnn_wide_jvp_kernel(WideJvpParams q) {
   float* dpos = posn + n * 4;
   float* dpos0 = dpos + n * 4;
   float* dposn = dpos0 + n * 4;
+  float* bc = dposn + n * 4;             // [2][64] broadcast slots (primal, tangent) of the dense layers
   const long long nw = (long long)gridDim.x * waves;
   for (long long w = (long long)blockIdx.x * waves + wave; w < p.B; w += nw) {
     const float hval = p.t[w];
@@ -306,9 +396,9 @@ __global__ void __launch_bounds__(256) egnn_wide_jvp_kernel(WideJvpParams q) {
       const float* wl = p.w + WIDE_HEAD + (size_t)l * WideLayer::SIZE;
       for (int i = 0; i < n; ++i) {
         const float hv = hf[i * WIDE_HP + lane], dhv = dhf[i * WIDE_HP + lane];
-        At[i * WIDE_HP + lane] = dense_mem<HK>(wl + WideLayer::WA, lane, hv, wl[WideLayer::B1 + lane]);
+        At[i * WIDE_HP + lane] = dense_mem_b<HK>(wl + WideLayer::WA, bc, lane, hv, wl[WideLayer::B1 + lane]);
         float b = 0.f, db = 0.f;
-        dense_mem2<HK>(wl + WideLayer::WB, lane, hv, dhv, b, db);
+        dense_mem2<HK>(wl + WideLayer::WB, bc, lane, hv, dhv, b, db);
         Bt[i * WIDE_HP + lane] = b;
         dBt[i * WIDE_HP + lane] = db;
       }
@@ -325,7 +415,7 @@ __global__ void __launch_bounds__(256) egnn_wide_jvp_kernel(WideJvpParams q) {
       const bool last = (l == p.L - 1);
       for (int i = 0; i < n; ++i) {
         const float Ai = At[i * WIDE_HP + lane];
-        const float dAi = dense_mem<HK>(wl + WideLayer::WA, lane, dhf[i * WIDE_HP + lane], 0.f);
+        const float dAi = dense_mem_b<HK>(wl + WideLayer::WA, bc, lane, dhf[i * WIDE_HP + lane], 0.f);
         float pi[3] = {0.f, 0.f, 0.f}, p0i[3] = {0.f, 0.f, 0.f}, xacc[3] = {0.f, 0.f, 0.f};
         float dpi[3] = {0.f, 0.f, 0.f}, dp0i[3] = {0.f, 0.f, 0.f}, dxacc[3] = {0.f, 0.f, 0.f};
         for (int k = 0; k < DIM; ++k) {
@@ -351,7 +441,7 @@ __global__ void __launch_bounds__(256) egnn_wide_jvp_kernel(WideJvpParams q) {
           const float dz1 = fmaf(we, dea, fmaf(wr, dradial, dAi + dBt[j * WIDE_HP + lane]));
           const float m1 = wsilu_d(z1, g1), dm1 = g1 * dz1;
           float z2 = b2, dz2 = 0.f;
-          dense_reg2<HK>(w2, m1, dm1, z2, dz2);
+          dense_reg2<HK>(w2, bc, lane, m1, dm1, z2, dz2);
           float m = wsilu_d(z2, g2), dm = g2 * dz2;
           if (p.attention) {
             const float a = fast_sigmoid(wwave_sum(watt * m) + batt);
@@ -361,7 +451,7 @@ __global__ void __launch_bounds__(256) egnn_wide_jvp_kernel(WideJvpParams q) {
           }
           agg += m; dagg += dm;
           float zc = bc1, dzc = 0.f;
-          dense_reg2<HK>(wc1, m, dm, zc, dzc);
+          dense_reg2<HK>(wc1, bc, lane, m, dm, zc, dzc);
           const float c1 = wsilu_d(zc, gc), dc1 = gc * dzc;
           float cs = wwave_sum(wc2 * c1), dcs = wwave_sum(wc2 * dc1);
           if (p.tanh_on) {
@@ -385,11 +475,11 @@ __global__ void __launch_bounds__(256) egnn_wide_jvp_kernel(WideJvpParams q) {
         if (!last) {
           const float hv = hf[i * WIDE_HP + lane], dhv = dhf[i * WIDE_HP + lane];
           float z = wl[WideLayer::BN1 + lane], dz = 0.f, gz;
-          dense_mem2<HK>(wl + WideLayer::WN1A, lane, hv, dhv, z, dz);
-          dense_mem2<HK>(wl + WideLayer::WN1B, lane, agg, dagg, z, dz);
+          dense_mem2<HK>(wl + WideLayer::WN1A, bc, lane, hv, dhv, z, dz);
+          dense_mem2<HK>(wl + WideLayer::WN1B, bc, lane, agg, dagg, z, dz);
           const float sz = wsilu_d(z, gz);
           float o = wl[WideLayer::BN2 + lane], d_o = 0.f;
-          dense_mem2<HK>(wl + WideLayer::WN2, lane, sz, gz * dz, o, d_o);
+          dense_mem2<HK>(wl + WideLayer::WN2, bc, lane, sz, gz * dz, o, d_o);
           hf[i * WIDE_HP + lane] = hv + o;
           dhf[i * WIDE_HP + lane] = dhv + d_o;
         }
@@ -579,7 +669,7 @@ extern "C" int pita_egnn_wide_eval(pita_egnn_wide_t* net, int what, const float*
     rc = wide64_launch(net, what, t, x, beta, out, B, (hipStream_t)stream);
     p.only_bad = 1;
   }
-  const size_t per_wave = sizeof(float) * (size_t)(3 * p.n * WIDE_HP + 3 * p.n * 4);
+  const size_t per_wave = sizeof(float) * (size_t)(3 * p.n * WIDE_HP + 3 * p.n * 4 + WIDE_HP);
   int waves = 4;
   while (waves > 1 && per_wave * waves > 72 * 1024) waves >>= 1;  // two blocks per CU inside the 160 KB
   auto kernel = p.H <= 32 ? egnn_wide_kernel<32> : egnn_wide_kernel<64>;
@@ -622,7 +712,7 @@ extern "C" int pita_egnn_wide_jvp(pita_egnn_wide_t* net, const float* h, const f
   p.B = B; p.mode = 1; p.x = x; p.t = h; p.beta = beta; p.out = out;
   q.vx = vx; q.vh = vh; q.dir = vx ? -1 : dir; q.dout = dout; q.dot_out = dot_out; q.dot_stride = dot_stride;
   q.dot_off = dot_off; q.diag_acc = diag_acc;
-  const size_t per_wave = sizeof(float) * (size_t)(5 * p.n * WIDE_HP + 6 * p.n * 4);
+  const size_t per_wave = sizeof(float) * (size_t)(5 * p.n * WIDE_HP + 6 * p.n * 4 + 2 * WIDE_HP);
   int waves = 4;
   while (waves > 1 && per_wave * waves > 150 * 1024) waves >>= 1;
   auto kernel = p.H <= 32 ? egnn_wide_jvp_kernel<32> : egnn_wide_jvp_kernel<64>;
