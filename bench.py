@@ -619,12 +619,22 @@ def main():
         for k in range(2, 10):
             step64(k)
         torch.cuda.synchronize()
-        dt64 = (time.perf_counter() - t0) / 8
+        dt64_steps = (time.perf_counter() - t0) / 8
+        # the same steps as ONE launch (pita_egnn_wide_sampler_run: walkers on chip between the steps)
+        xa = x.clone()
+        tab64 = tab_h[2:52].contiguous().to(dev)
+        net64.sampler_run(xa, tab64[:10].contiguous(), 10, seed=seed, walker_offset=rank * B, step0=2, remove_mean=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        net64.sampler_run(xa, tab64, 50, seed=seed, walker_offset=rank * B, step0=2, remove_mean=True)
+        torch.cuda.synchronize()
+        dt64 = (time.perf_counter() - t0) / 50
         mac = 5 * (n * (n - 1) * ((2 * 64 + 2) * 64 + 2 * 64 * 64 + 2 * 64) + n * 3 * 64 * 64)
         on_mfma = net64.uses_matrix_pipe(dev)
-        ad2cat = {"backbone": "EGNN_dynamics_AD2_cat hidden 64 x 5 layers (pita_egnn_wide_eval, "
+        ad2cat = {"backbone": "EGNN_dynamics_AD2_cat hidden 64 x 5 layers (pita_egnn_wide_sampler_run: 50 steps per launch, "
                               + ("f16 two-piece MFMA, matrix pipe)" if on_mfma else "fp32 vector pipe)"),
                   "walkers": B, "ms_per_step": dt64 * 1e3, "value": B / dt64, "unit": "walker-steps/s",
+                  "ms_per_step_launch_per_step_path": dt64_steps * 1e3,
                   "algorithmic_TFLOPs": 2 * mac * B / dt64 / 1e12,
                   ("frac_of_dense_f16_mfma_peak_2500" if on_mfma else "frac_of_plain_fma_rate_78.6"):
                       2 * mac * B / dt64 / (2500e12 if on_mfma else 78.65e12),

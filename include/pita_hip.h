@@ -147,6 +147,16 @@ int pita_egnn_wide_uses_matrix_pipe(const pita_egnn_wide_t* net);
 int pita_egnn_wide_eval(pita_egnn_wide_t* net, int what, const float* t, const float* x, const float* beta /*nullable*/,
                         float* out, int64_t B, void* stream);
 
+/* Fused sampler on this backbone: n_steps Euler-Maruyama steps of the NOT-debiased reverse VE-SDE in ONE launch, walkers
+ * on chip between the steps -- pita_egnn_sampler_run for EGNN_dynamics_AD2_cat (same step table PITA_ST_*, same Philox
+ * keying by (seed, walker_offset + walker, step0 + step, particle), same stats_out moments; replaces, per step,
+ * sdes.py:117-128,245-251 + sde_integration.py:299-351,148).  Matrix-pipe kernel where the particle system has one,
+ * then the fp32 vector-pipe kernel on exactly the walkers it left non-finite (an activation beyond the f16 range),
+ * restarted from a handle-owned backup. */
+int pita_egnn_wide_sampler_run(pita_egnn_wide_t* net, float* x, int64_t B, const float* step_tab, int n_steps,
+                               const float* noise /*nullable*/, uint64_t seed, uint64_t walker_offset, int64_t step0,
+                               int remove_mean, double* stats_out /*nullable*/, void* stream);
+
 /* Forward-mode derivative of the EDM denoiser D(h, x) = c_s x + c_out F(c_noise(h), c_in(h) x, beta) around this
  * backbone, one tangent direction per launch (arguments as pita_egnn_jvp):  dout = J_x D . vx + dD/dh . vh, out = D
  * (nullable), dot_out[b * dot_stride + dot_off] = <x_b, dD_b>, diag_acc[b] += dD[b, dir].  What the debiased

@@ -85,6 +85,8 @@ _PROTOS = {
     "pita_egnn_wide_destroy": (c_int, [c_void_p]),
     "pita_egnn_wide_uses_matrix_pipe": (c_int, [c_void_p]),
     "pita_egnn_wide_eval": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "pita_egnn_wide_sampler_run": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_uint64, c_uint64,
+                                           c_int64, c_int, c_void_p, c_void_p]),
     "pita_egnn_wide_jvp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "pita_egnn_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),

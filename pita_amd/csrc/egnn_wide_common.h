@@ -15,6 +15,9 @@ struct pita_egnn_wide {
   float* d_vecs64 = nullptr;   // embedding vectors + per-layer vectors, fragment order, f16-path scales folded in
   float* d_est64 = nullptr;    // [n][64] as d_estatic, fragment order
   const void* shape64 = nullptr;
+  // fused sampler on the matrix pipe: backup of the walkers + per-particle bookkeeping for the vector-pipe repair pass
+  void* d_bk = nullptr;
+  size_t bk_bytes = 0;
 };
 
 namespace pita {
@@ -23,5 +26,9 @@ namespace pita {
 int wide64_prepare(pita_egnn_wide* net, const float* w, const float* he);
 int wide64_launch(pita_egnn_wide* net, int what, const float* t, const float* x, const float* beta, float* out,
                   long long B, hipStream_t stream);
+// n_steps fused Euler-Maruyama steps on the matrix-pipe kernel (mode 3 of egnn_wide64_kernel); bad_from: device [B * n]
+int wide64_sampler(pita_egnn_wide* net, float* x, long long B, const float* step_tab, int n_steps, const float* noise,
+                   unsigned long long seed, unsigned long long walker_offset, long long step0, int remove_mean,
+                   double* stats_out, int* bad_from, hipStream_t stream);
 void wide64_release(pita_egnn_wide* net);
 }  // namespace pita

@@ -49,6 +49,17 @@ struct WideParams {
   const float* beta;
   float* out;
   int only_bad;  // recompute only the walkers whose `out` holds a non-finite value (repair pass behind the matrix-pipe kernel)
+  // mode 3: n_steps Euler-Maruyama steps of the not-debiased reverse SDE in one launch (pita_egnn_wide_sampler_run)
+  float* xs;               // [B, n*dim] walkers, in place
+  const float* x_backup;   // only_bad: the walkers as they were before the matrix-pipe launch
+  const float* step_tab;   // [n_steps][PITA_STEP_STRIDE]
+  int n_steps;
+  const float* noise;      // nullable [n_steps, B, n*dim]
+  unsigned long long seed, walker_offset;
+  long long step0;
+  int remove_mean;
+  double* stats_out;       // nullable [n_steps][4]
+  const int* bad_from;     // only_bad: [B*n] first step whose moments the matrix-pipe launch left to this one
 };
 
 namespace {
@@ -144,35 +155,58 @@ __global__ void __launch_bounds__(256, 2) egnn_wide_kernel(WideParams p) {  // t
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = p.n, DIM = p.dim;
-  const int per_wave = 3 * n * WIDE_HP + 3 * n * 4 + WIDE_HP;
+  const int per_wave = 3 * n * WIDE_HP + 4 * n * 4 + WIDE_HP;
   float* hf = lds + wave * per_wave;     // [n][64] node features
   float* At = hf + n * WIDE_HP;          // [n][64] Wa h_i + b1
   float* Bt = At + n * WIDE_HP;          // [n][64] Wb h_j
   float* pos = Bt + n * WIDE_HP;         // [n][4] positions entering the layer
   float* pos0 = pos + n * 4;             // [n][4] input geometry (frozen edge attribute)
   float* posn = pos0 + n * 4;            // [n][4] positions leaving the layer
-  float* bc = posn + n * 4;              // [64] broadcast slot of the dense layers
+  float* xw = posn + n * 4;              // [n][4] the walker's unscaled coordinates (sampler mode: across the steps)
+  float* bc = xw + n * 4;                // [64] broadcast slot of the dense layers
+  const bool smp = p.mode == 3;
   const long long nw = (long long)gridDim.x * waves;
   for (long long w = (long long)blockIdx.x * waves + wave; w < p.B; w += nw) {
     if (p.only_bad) {
       bool bad = false;
-      for (int q = lane; q < n * DIM; q += 64) bad = bad || !__builtin_isfinite(p.out[w * n * DIM + q]);
+      const float* res = smp ? p.xs : p.out;
+      for (int q = lane; q < n * DIM; q += 64) bad = bad || !__builtin_isfinite(res[w * n * DIM + q]);
       if (!__any(bad)) continue;  // wave-uniform
     }
-    const float tv = p.t[w];
-    const float bet = p.has_beta ? p.beta[w] : 0.f;
-    float c_s = 0.f, c_in = 1.f, c_out = 1.f, tfeat = tv, hval = 1.f;
-    if (p.mode != 0) {  // score_net.py:26-29
-      hval = tv;
-      c_s = 1.0f / (1.0f + tv);
-      c_in = 1.0f / sqrtf(1.0f + tv);
-      c_out = sqrtf(tv) * c_in;
-      tfeat = 0.125f * logf(tv);
+    {
+      const float* src = smp ? (p.only_bad ? p.x_backup : p.xs) : p.x;
+      for (int q = lane; q < n * DIM; q += 64) {
+        const int i = q / DIM, k = q - i * DIM;
+        xw[i * 4 + k] = src[w * n * DIM + q];
+      }
+    }
+    wfence();
+    const int nsteps = smp ? p.n_steps : 1;
+    for (int step = 0; step < nsteps; ++step) {
+    float tv, bet, c_s = 0.f, c_in = 1.f, c_out = 1.f, tfeat, hval = 1.f;
+    float g2 = 0.f, gamma = 0.f, dt = 0.f, noise_scale = 0.f, sqrt_dt = 0.f;
+    if (smp) {  // per-step scalars of the host table (sde_integration.py: build_step_table), as the matrix-pipe kernel
+      const float* st = p.step_tab + (size_t)step * PITA_STEP_STRIDE;
+      c_s = st[PITA_ST_CS]; c_in = st[PITA_ST_CIN]; c_out = st[PITA_ST_COUT]; tfeat = st[PITA_ST_CNOISE];
+      hval = st[PITA_ST_H]; bet = p.has_beta ? st[PITA_ST_BETA] : 0.f; tv = hval;
+      g2 = st[PITA_ST_G2]; gamma = st[PITA_ST_GAMMA]; dt = st[PITA_ST_DT];
+      noise_scale = st[PITA_ST_NOISE_SCALE]; sqrt_dt = st[PITA_ST_SQRT_DT];
+    } else {
+      tv = p.t[w];
+      bet = p.has_beta ? p.beta[w] : 0.f;
+      tfeat = tv;
+      if (p.mode != 0) {  // score_net.py:26-29
+        hval = tv;
+        c_s = 1.0f / (1.0f + tv);
+        c_in = 1.0f / sqrtf(1.0f + tv);
+        c_out = sqrtf(tv) * c_in;
+        tfeat = 0.125f * logf(tv);
+      }
     }
     // scaled input coordinates
     for (int q = lane; q < n * DIM; q += 64) {
       const int i = q / DIM, k = q - i * DIM;
-      const float v = c_in * p.x[w * n * DIM + q];
+      const float v = c_in * xw[i * 4 + k];
       pos[i * 4 + k] = v;
       pos0[i * 4 + k] = v;
     }
@@ -245,16 +279,70 @@ __global__ void __launch_bounds__(256, 2) egnn_wide_kernel(WideParams p) {  // t
       for (int i = 0; i < n; ++i) s += pos[i * 4 + k] - pos0[i * 4 + k];
       mean[k] = s / (float)n;
     }
-    for (int q = lane; q < n * DIM; q += 64) {
-      const int i = q / DIM, k = q - i * DIM;
-      const float F = (pos[i * 4 + k] - pos0[i * 4 + k]) - mean[k];
-      float o = F;
-      if (p.mode != 0) {
-        const float xc = p.x[w * n * DIM + q];
-        o = c_s * xc + c_out * F;
-        if (p.mode == 2) o = (o - xc) / hval;
+    if (!smp) {
+      for (int q = lane; q < n * DIM; q += 64) {
+        const int i = q / DIM, k = q - i * DIM;
+        const float F = (pos[i * 4 + k] - pos0[i * 4 + k]) - mean[k];
+        float o = F;
+        if (p.mode != 0) {
+          const float xc = xw[i * 4 + k];
+          o = c_s * xc + c_out * F;
+          if (p.mode == 2) o = (o - xc) / hval;
+        }
+        p.out[w * n * DIM + q] = o;
       }
-      p.out[w * n * DIM + q] = o;
+    } else {
+      // reverse-SDE Euler-Maruyama update + remove_mean: the arithmetic of egnn_wide64_kernel's sampler mode
+      float st_d = 0.f, st_d2 = 0.f, st_n = 0.f, st_n2 = 0.f;
+      for (int i = lane; i < n; i += 64) {
+        float xi[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.noise) {
+          for (int k = 0; k < DIM; ++k) xi[k] = p.noise[((size_t)step * p.B * n + (size_t)(w * n + i)) * DIM + k];
+        } else {
+          philox_normal4(p.seed, p.walker_offset + (unsigned long long)w, p.step0 + step, (uint32_t)i, xi);
+        }
+        const bool take = !p.only_bad || !p.bad_from || step >= p.bad_from[w * n + i];
+        for (int k = 0; k < DIM; ++k) {
+          const float F = (pos[i * 4 + k] - pos0[i * 4 + k]) - mean[k];
+          const float xc = xw[i * 4 + k];
+          const float Dth = c_s * xc + c_out * F;
+          const float drift = gamma * (((Dth - xc) / hval) * g2);
+          const float dif = noise_scale * xi[k];
+          if (p.stats_out && take) {
+            st_d += drift; st_d2 = fmaf(drift, drift, st_d2);
+            st_n += dif; st_n2 = fmaf(dif, dif, st_n2);
+          }
+          posn[i * 4 + k] = xc + (drift * dt + (dif * sqrt_dt));
+        }
+      }
+      if (p.stats_out) {
+        double m4[4] = {(double)st_d, (double)st_d2, (double)st_n, (double)st_n2};
+        for (int qq = 0; qq < 4; ++qq) {
+          for (int o = 32; o > 0; o >>= 1) m4[qq] += __shfl_xor(m4[qq], o, 64);
+          if (lane == 0) atomicAdd(p.stats_out + (size_t)step * 4 + qq, m4[qq]);
+        }
+      }
+      wfence();
+      float mu[3] = {0.f, 0.f, 0.f};
+      if (p.remove_mean) {
+        for (int k = 0; k < DIM; ++k) {
+          float sum = 0.f;
+          for (int i = 0; i < n; ++i) sum += posn[i * 4 + k];
+          mu[k] = sum / (float)n;
+        }
+      }
+      for (int q = lane; q < n * DIM; q += 64) {
+        const int i = q / DIM, k = q - i * DIM;
+        xw[i * 4 + k] = posn[i * 4 + k] - mu[k];
+      }
+    }
+    wfence();
+    }  // steps
+    if (smp) {
+      for (int q = lane; q < n * DIM; q += 64) {
+        const int i = q / DIM, k = q - i * DIM;
+        p.xs[w * n * DIM + q] = xw[i * 4 + k];
+      }
     }
     wfence();
   }
@@ -669,7 +757,7 @@ extern "C" int pita_egnn_wide_eval(pita_egnn_wide_t* net, int what, const float*
     rc = wide64_launch(net, what, t, x, beta, out, B, (hipStream_t)stream);
     p.only_bad = 1;
   }
-  const size_t per_wave = sizeof(float) * (size_t)(3 * p.n * WIDE_HP + 3 * p.n * 4 + WIDE_HP);
+  const size_t per_wave = sizeof(float) * (size_t)(3 * p.n * WIDE_HP + 4 * p.n * 4 + WIDE_HP);
   int waves = 4;
   while (waves > 1 && per_wave * waves > 72 * 1024) waves >>= 1;  // two blocks per CU inside the 160 KB
   auto kernel = p.H <= 32 ? egnn_wide_kernel<32> : egnn_wide_kernel<64>;
@@ -727,6 +815,75 @@ extern "C" int pita_egnn_wide_jvp(pita_egnn_wide_t* net, const float* h, const f
     const unsigned grid = (unsigned)(want < cap ? want : cap);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(waves * 64), per_wave * waves, (hipStream_t)stream, q);
     if (hipGetLastError() != hipSuccess) rc = fail(PITA_EHIP, "pita_egnn_wide_jvp: launch failed");
+  }
+  if (switched) (void)hipSetDevice(prev);
+  return rc;
+}
+
+// Fused sampler on the wide backbone: n_steps Euler-Maruyama steps of the NOT-debiased reverse VE-SDE in one launch
+// (arguments and step table as pita_egnn_sampler_run).  Matrix-pipe kernel where the particle system has one, followed by
+// the vector-pipe kernel on exactly the walkers that came out non-finite (restarted from a backup of the walkers, all
+// steps in fp32; the per-step moments are partitioned between the two launches per particle); the vector-pipe kernel
+// alone for every other shape.
+extern "C" int pita_egnn_wide_sampler_run(pita_egnn_wide_t* net, float* x, int64_t B, const float* step_tab, int n_steps,
+                                          const float* noise, uint64_t seed, uint64_t walker_offset, int64_t step0,
+                                          int remove_mean, double* stats_out, void* stream) {
+  PITA_REQUIRE(net && B >= 0 && n_steps >= 0, "pita_egnn_wide_sampler_run: bad argument");
+  if (B == 0 || n_steps == 0) return PITA_OK;
+  PITA_REQUIRE(x && step_tab, "pita_egnn_wide_sampler_run: null argument");
+  int prev = -1;
+  bool switched = false;
+  if (net->device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != net->device)
+    switched = hipSetDevice(net->device) == hipSuccess;
+  hipStream_t st = (hipStream_t)stream;
+  WideParams p{};
+  p.w = net->d_w; p.estatic = net->d_estatic;
+  p.n = net->cfg.n_particles; p.dim = net->cfg.n_dim; p.H = net->cfg.hidden_nf; p.L = net->cfg.n_layers;
+  p.attention = net->cfg.attention; p.tanh_on = net->cfg.tanh; p.has_beta = net->cfg.condition_beta;
+  p.coord_scale = net->cfg.coords_range / (float)net->cfg.n_layers;
+  p.B = B; p.mode = 3; p.xs = x; p.step_tab = step_tab; p.n_steps = n_steps; p.noise = noise; p.seed = seed;
+  p.walker_offset = walker_offset; p.step0 = step0; p.remove_mean = remove_mean; p.stats_out = stats_out;
+  int rc = PITA_OK;
+  const size_t nx = (size_t)B * p.n * p.dim;
+  if (pita_egnn_wide_uses_matrix_pipe(net)) {
+    const size_t need = sizeof(float) * nx + sizeof(int) * (size_t)B * p.n;
+    if (need > net->bk_bytes) {
+      hipError_t e = hipStreamSynchronize(st);  // an earlier launch may still use the old buffer
+      (void)hipFree(net->d_bk);
+      net->d_bk = nullptr;
+      net->bk_bytes = 0;
+      if (e == hipSuccess) e = hipMalloc(&net->d_bk, need);
+      if (e != hipSuccess) rc = fail(PITA_EHIP, "pita_egnn_wide_sampler_run: backup buffer: %s", hipGetErrorString(e));
+      else net->bk_bytes = need;
+    }
+    if (rc == PITA_OK) {
+      float* xb = static_cast<float*>(net->d_bk);
+      int* bad_from = reinterpret_cast<int*>(xb + nx);
+      if (hipMemcpyAsync(xb, x, sizeof(float) * nx, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        rc = fail(PITA_EHIP, "pita_egnn_wide_sampler_run: backup copy failed");
+      if (rc == PITA_OK)
+        rc = wide64_sampler(net, x, B, step_tab, n_steps, noise, seed, walker_offset, step0, remove_mean, stats_out,
+                            bad_from, st);
+      p.only_bad = 1;
+      p.x_backup = xb;
+      p.bad_from = bad_from;
+    }
+  }
+  const size_t per_wave = sizeof(float) * (size_t)(3 * p.n * WIDE_HP + 4 * p.n * 4 + WIDE_HP);
+  int waves = 4;
+  while (waves > 1 && per_wave * waves > 72 * 1024) waves >>= 1;
+  auto kernel = p.H <= 32 ? egnn_wide_kernel<32> : egnn_wide_kernel<64>;
+  if (rc != PITA_OK) {
+  } else if (per_wave * waves > 150 * 1024) {
+    rc = fail(PITA_EUNSUPPORTED, "pita_egnn_wide_sampler_run: %d particles need %zu B of LDS per wave", p.n, per_wave);
+  } else if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(per_wave * waves)) != hipSuccess) {
+    rc = fail(PITA_EHIP, "pita_egnn_wide_sampler_run: cannot reserve %zu B of LDS", per_wave * waves);
+  } else {
+    const long long want = (B + waves - 1) / waves, cap = (long long)net->n_cu * 8;
+    const unsigned grid = (unsigned)(want < cap ? want : cap);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(waves * 64), per_wave * waves, st, p);
+    if (hipGetLastError() != hipSuccess) rc = fail(PITA_EHIP, "pita_egnn_wide_sampler_run: launch failed");
   }
   if (switched) (void)hipSetDevice(prev);
   return rc;

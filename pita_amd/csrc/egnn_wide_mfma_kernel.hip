@@ -42,6 +42,16 @@ struct Wide64Params {
   const float* t;
   const float* beta;
   float* out;
+  // mode 3: n_steps Euler-Maruyama steps of the not-debiased reverse SDE in one launch (pita_egnn_wide_sampler_run)
+  float* xs;               // [B, N*DIM] walkers, in place
+  const float* step_tab;   // [n_steps][PITA_STEP_STRIDE]
+  int n_steps;
+  const float* noise;      // nullable [n_steps, B, N*DIM]
+  unsigned long long seed, walker_offset;
+  long long step0;
+  int remove_mean;
+  double* stats_out;       // nullable [n_steps][4]
+  int* bad_from;           // [B*N]: first step whose moments this launch left out for the particle (INT_MAX: none)
 };
 
 template <int N, int DIM, int G, int WAVES>
@@ -51,7 +61,7 @@ struct Wide64Cfg {
   static constexpr int NCOLP = NT * 32;
   static constexpr int PB_F = NCOLP * W64_PBS;
   static constexpr int POS_F = NCOLP * DIM;
-  static constexpr int WAVE_F = PB_F + 3 * POS_F;  // partner table, pos[2], pos0
+  static constexpr int WAVE_F = PB_F + 4 * POS_F;  // partner table, pos[2], pos0, the walkers' unscaled coordinates
   static __host__ __device__ constexpr int vec_f(int L) { return ((W64_HEAD_F + L * W64_LAYER_F) + 3) & ~3; }
   static __host__ __device__ constexpr size_t lds_bytes(int L) {
     return sizeof(float) * (size_t)(vec_f(L) + N * 64 + WAVES * WAVE_F);
@@ -141,6 +151,8 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_wide64_kernel(Wide64Params
   float* pos0 = posbuf1 + C::POS_F;
   const f32x16 zero16 = {0};
 
+  float* xbuf = pos0 + C::POS_F;  // the walkers' unscaled coordinates (parked in LDS across the layers and the steps)
+  const bool smp = p.mode == 3;
   const long long ngroups = (p.B + G - 1) / G;
   for (long long g = (long long)blockIdx.x * WAVES + wave; g < ngroups; g += (long long)gridDim.x * WAVES) {
     const long long walker0 = g * G;
@@ -149,30 +161,57 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_wide64_kernel(Wide64Params
     const int ntile = (ncol + 31) >> 5;
     int col[NT], nodei[NT];
     bool valid[NT];
-    float xin[NT][DIM], c_s[NT], c_out[NT], hval[NT];
-    f32x16 hfeat[NT][2];
+    int bad_from[NT];
 #pragma unroll
     for (int T = 0; T < NT; ++T) {
       col[T] = T * 32 + cl;
       const int w = col[T] / N;
       nodei[T] = col[T] - w * N;
       valid[T] = col[T] < ncol;
-      const long long wid = valid[T] ? walker0 + w : p.B - 1;
-      const float tv = p.t[wid];
-      const float bet = p.has_beta ? p.beta[wid] : 0.f;
-      float c_in = 1.f, tfeat = tv;
+      bad_from[T] = 0x7fffffff;
+      const float* src = smp ? p.xs : p.x;
+#pragma unroll
+      for (int k = 0; k < DIM; ++k)
+        if (hh == 0) xbuf[col[T] * DIM + k] = valid[T] ? src[(walker0 * N + col[T]) * DIM + k] : 0.f;
+    }
+    wave_lds_fence();
+    const int nsteps = smp ? p.n_steps : 1;
+    for (int step = 0; step < nsteps; ++step) {
+    float c_s[NT], c_out[NT], hval[NT];
+    f32x16 hfeat[NT][2];
+    float g2 = 0.f, gamma = 0.f, dt = 0.f, noise_scale = 0.f, sqrt_dt = 0.f;
+    if (smp) {  // wave-uniform per-step scalars through SGPRs (sde_integration.py: build_step_table)
+      const float* st = p.step_tab + (size_t)step * PITA_STEP_STRIDE;
+      auto uni = [&](int i) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, st[i]))); };
+      g2 = uni(PITA_ST_G2); gamma = uni(PITA_ST_GAMMA); dt = uni(PITA_ST_DT);
+      noise_scale = uni(PITA_ST_NOISE_SCALE); sqrt_dt = uni(PITA_ST_SQRT_DT);
+    }
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+      float c_in = 1.f, tfeat, bet;
       c_s[T] = 0.f; c_out[T] = 1.f; hval[T] = 1.f;
-      if (p.mode != 0) {  // score_net.py:26-29
-        hval[T] = tv;
-        c_s[T] = 1.0f / (1.0f + tv);
-        c_in = 1.0f / sqrtf(1.0f + tv);
-        c_out[T] = sqrtf(tv) * c_in;
-        tfeat = 0.125f * logf(tv);
+      if (smp) {
+        const float* st = p.step_tab + (size_t)step * PITA_STEP_STRIDE;
+        auto uni = [&](int i) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, st[i]))); };
+        c_s[T] = uni(PITA_ST_CS); c_in = uni(PITA_ST_CIN); c_out[T] = uni(PITA_ST_COUT);
+        tfeat = uni(PITA_ST_CNOISE); hval[T] = uni(PITA_ST_H); bet = p.has_beta ? uni(PITA_ST_BETA) : 0.f;
+      } else {
+        const int w = col[T] / N;
+        const long long wid = valid[T] ? walker0 + w : p.B - 1;
+        const float tv = p.t[wid];
+        bet = p.has_beta ? p.beta[wid] : 0.f;
+        tfeat = tv;
+        if (p.mode != 0) {  // score_net.py:26-29
+          hval[T] = tv;
+          c_s[T] = 1.0f / (1.0f + tv);
+          c_in = 1.0f / sqrtf(1.0f + tv);
+          c_out[T] = sqrtf(tv) * c_in;
+          tfeat = 0.125f * logf(tv);
+        }
       }
 #pragma unroll
       for (int k = 0; k < DIM; ++k) {
-        xin[T][k] = valid[T] ? p.x[(walker0 * N + col[T]) * DIM + k] : 0.f;
-        const float ps = c_in * xin[T][k];
+        const float ps = c_in * xbuf[col[T] * DIM + k];
         if (hh == 0) {
           pos0[col[T] * DIM + k] = ps;
           posbuf0[col[T] * DIM + k] = ps;
@@ -318,12 +357,102 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_wide64_kernel(Wide64Params
       for (int k = 0; k < DIM; ++k) {
         float s = 0.f;
         for (int q = 0; q < N; ++q) s += scr[(cb + q) * DIM + k];
-        float o = F[T][k] - s / (float)N;
-        if (p.mode != 0) {
-          o = c_s[T] * xin[T][k] + c_out[T] * o;             // denoiser (score_net.py:31-33)
-          if (p.mode == 2) o = (o - xin[T][k]) / hval[T];    // score (:19)
+        F[T][k] -= s / (float)N;
+      }
+    }
+    wave_lds_fence();
+    if (!smp) {
+#pragma unroll
+      for (int T = 0; T < NT; ++T)
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          float o = F[T][k];
+          if (p.mode != 0) {
+            const float xc = xbuf[col[T] * DIM + k];
+            o = c_s[T] * xc + c_out[T] * o;             // denoiser (score_net.py:31-33)
+            if (p.mode == 2) o = (o - xc) / hval[T];    // score (:19)
+          }
+          if (valid[T] && hh == 0) p.out[(walker0 * N + col[T]) * DIM + k] = o;
         }
-        if (valid[T] && hh == 0) p.out[(walker0 * N + col[T]) * DIM + k] = o;
+    } else {
+      // ---- reverse-SDE Euler-Maruyama update (sdes.py:119-122,250; sde_integration.py:347-348): the arithmetic of
+      // ScoreNet's score + the integrator's drift + pita_em_step, so the fused and the per-step path agree to rounding
+      float xn[NT][DIM];
+      float st_d = 0.f, st_d2 = 0.f, st_n = 0.f, st_n2 = 0.f;
+#pragma unroll
+      for (int T = 0; T < NT; ++T) {
+        float xi[4] = {0.f, 0.f, 0.f, 0.f};
+        const int w = col[T] / N;
+        if (p.noise) {
+#pragma unroll
+          for (int k = 0; k < DIM; ++k)
+            xi[k] = valid[T] ? p.noise[((size_t)step * p.B * N + (size_t)(walker0 * N + col[T])) * DIM + k] : 0.f;
+        } else {
+          philox_normal4(p.seed, p.walker_offset + (unsigned long long)(valid[T] ? walker0 + w : p.B - 1), p.step0 + step,
+                         (uint32_t)nodei[T], xi);
+        }
+        // moments: a particle whose drift is not finite (an activation beyond the f16 range) is left to the repair
+        // launch from this step on -- decided per particle, all components together (as egnn_kernel does)
+        bool take = true;
+        float drift[DIM];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          const float xc = xbuf[col[T] * DIM + k];
+          const float Dth = c_s[T] * xc + c_out[T] * F[T][k];
+          drift[k] = gamma * (((Dth - xc) / hval[T]) * g2);
+          take = take && __builtin_isfinite(drift[k]);
+        }
+        take = take && bad_from[T] == 0x7fffffff;
+        if (!take && bad_from[T] == 0x7fffffff) bad_from[T] = step;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          const float xc = xbuf[col[T] * DIM + k];
+          const float dif = noise_scale * xi[k];
+          if (p.stats_out && valid[T] && hh == 0 && take) {
+            st_d += drift[k]; st_d2 = fmaf(drift[k], drift[k], st_d2);
+            st_n += dif; st_n2 = fmaf(dif, dif, st_n2);
+          }
+          xn[T][k] = xc + (drift[k] * dt + (dif * sqrt_dt));
+          if (hh == 0) scr[col[T] * DIM + k] = xn[T][k];
+        }
+      }
+      if (p.stats_out) {
+        double m4[4] = {(double)st_d, (double)st_d2, (double)st_n, (double)st_n2};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          for (int o = 32; o > 0; o >>= 1) m4[q] += __shfl_xor(m4[q], o, 64);
+          if (lane == 0) atomicAdd(p.stats_out + (size_t)step * 4 + q, m4[q]);
+        }
+      }
+      if (p.remove_mean) {
+        wave_lds_fence();
+#pragma unroll
+        for (int T = 0; T < NT; ++T) {
+          const int cb = (col[T] < ncol) ? col[T] - nodei[T] : 0;
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) {
+            float s = 0.f;
+            for (int q = 0; q < N; ++q) s += scr[(cb + q) * DIM + k];
+            xn[T][k] -= s / (float)N;
+          }
+        }
+        wave_lds_fence();
+      }
+#pragma unroll
+      for (int T = 0; T < NT; ++T)
+#pragma unroll
+        for (int k = 0; k < DIM; ++k)
+          if (hh == 0) xbuf[col[T] * DIM + k] = xn[T][k];
+    }
+    wave_lds_fence();
+    }  // steps
+    if (smp) {
+#pragma unroll
+      for (int T = 0; T < NT; ++T) {
+#pragma unroll
+        for (int k = 0; k < DIM; ++k)
+          if (valid[T] && hh == 0) p.xs[(walker0 * N + col[T]) * DIM + k] = xbuf[col[T] * DIM + k];
+        if (p.bad_from && valid[T] && hh == 0) p.bad_from[walker0 * N + col[T]] = bad_from[T];
       }
     }
     wave_lds_fence();
@@ -473,22 +602,42 @@ void wide64_release(pita_egnn_wide* net) {
   (void)hipFree(net->d_m16h);
   (void)hipFree(net->d_vecs64);
   (void)hipFree(net->d_est64);
+  (void)hipFree(net->d_bk);
+  net->d_bk = nullptr;
+  net->bk_bytes = 0;
   net->d_m16h = nullptr;
   net->d_vecs64 = nullptr;
   net->d_est64 = nullptr;
   net->shape64 = nullptr;
 }
 
+static int wide64_run(pita_egnn_wide* net, Wide64Params& p, hipStream_t stream);
+
 int wide64_launch(pita_egnn_wide* net, int what, const float* t, const float* x, const float* beta, float* out,
                   long long B, hipStream_t stream) {
+  Wide64Params p{};
+  p.B = B; p.mode = what; p.x = x; p.t = t; p.beta = beta; p.out = out;
+  return wide64_run(net, p, stream);
+}
+
+int wide64_sampler(pita_egnn_wide* net, float* x, long long B, const float* step_tab, int n_steps, const float* noise,
+                   unsigned long long seed, unsigned long long walker_offset, long long step0, int remove_mean,
+                   double* stats_out, int* bad_from, hipStream_t stream) {
+  Wide64Params p{};
+  p.B = B; p.mode = 3; p.xs = x; p.step_tab = step_tab; p.n_steps = n_steps; p.noise = noise; p.seed = seed;
+  p.walker_offset = walker_offset; p.step0 = step0; p.remove_mean = remove_mean; p.stats_out = stats_out;
+  p.bad_from = bad_from;
+  return wide64_run(net, p, stream);
+}
+
+static int wide64_run(pita_egnn_wide* net, Wide64Params& p, hipStream_t stream) {
+  const long long B = p.B;
   const Wide64Shape* s = static_cast<const Wide64Shape*>(net->shape64);
   for (const auto& t : kWide64Small)  // small batch: the one-walker mapping when the regular one fills under 3/4 of the SIMDs
     if (t.n == s->n && t.dim == s->dim && (B + s->G - 1) / s->G < (long long)net->n_cu * 3) s = &t;
-  Wide64Params p{};
   p.m16h = net->d_m16h; p.vecs = net->d_vecs64; p.est = net->d_est64;
   p.L = net->cfg.n_layers; p.attention = net->cfg.attention; p.tanh_on = net->cfg.tanh; p.has_beta = net->cfg.condition_beta;
   p.coord_scale = net->cfg.coords_range / (float)net->cfg.n_layers;
-  p.B = B; p.mode = what; p.x = x; p.t = t; p.beta = beta; p.out = out;
   const long long ngroups = (B + s->G - 1) / s->G;
   const long long want = (ngroups + s->waves - 1) / s->waves, cap = net->n_cu;  // one 4-wave block per CU
   const unsigned grid = (unsigned)(want < cap ? want : cap);

@@ -126,6 +126,27 @@ class EGNN_dynamics_AD2_cat(nn.Module):
         """what=1: denoiser D_theta, what=2: score (D_theta - x)/h, EDM preconditioning fused (score_net.py:13-43)."""
         return self._eval(what, h_t, x_t, beta)
 
+    def can_fuse(self, n_particles, n_dim):
+        return int(n_particles) == self._n_particles and int(n_dim) == self._n_dimensions
+
+    def sampler_run(self, x, step_tab, n_steps, noise=None, seed=0, walker_offset=0, step0=0, remove_mean=True,
+                    drift_out=None, n_particles=None, n_dim=None, stats_out=None):
+        """In-place fused Euler-Maruyama steps of the not-debiased reverse SDE (pita_egnn_wide_sampler_run): the whole
+        stretch between two resampling events in ONE launch, like ``EGNN_dynamics.sampler_run``; x: [B, n*d] device
+        tensor, ``step_tab`` from ``sde_integration.build_step_table`` (its beta column conditions the net)."""
+        if drift_out is not None:
+            raise NotImplementedError("EGNN_dynamics_AD2_cat.sampler_run: drift_out")
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        if stats_out is not None:
+            assert stats_out.is_cuda and stats_out.dtype == torch.float64 and stats_out.is_contiguous()
+            assert stats_out.numel() >= 4 * int(n_steps)
+        assert step_tab.is_cuda and step_tab.dtype == torch.float32 and step_tab.is_contiguous()
+        _lib.check(_lib.lib().pita_egnn_wide_sampler_run(
+            self._native(x.device), x.data_ptr(), x.shape[0], step_tab.data_ptr(), int(n_steps), _lib.ptr(noise),
+            int(seed) & 0xFFFFFFFFFFFFFFFF, int(walker_offset), int(step0), int(bool(remove_mean)), _lib.ptr(stats_out),
+            _lib.stream_ptr(x.device)), "pita_egnn_wide_sampler_run")
+        return x
+
     def jvp(self, h_t, x_t, beta, vx=None, direction=-1, vh=None, want_primal=True, want_tangent=True, dot_out=None,
             dot_col=0, diag_acc=None):
         """(D, dD): the EDM denoiser around this backbone and its forward-mode derivative along ONE direction,

@@ -428,6 +428,92 @@ def test_debiased_regime_on_the_ad2cat_backbone_vs_oracle(pa, golden):
         assert rel(got, gE) < 2e-4, tv
 
 
+def test_egnn_ad2cat_fused_sampler(pa, golden, monkeypatch):
+    """pita_egnn_wide_sampler_run (all steps of the not-debiased SDE in one launch on EGNN_dynamics_AD2_cat, hidden 64 x 5,
+    22 atoms): against the launch-per-step path of the integrator (ScoreNet's fused EDM evaluation + pita_em_step: the
+    same arithmetic up to the EDM coefficients, which the fused kernel takes from the host's step table), with the
+    sampler's own Philox noise and with injected noise; per-step moments equal to the per-step path's; bitwise
+    independent of how the steps are cut into launches and of how the walkers are sharded; the vector-pipe kernel alone
+    (PITA_WIDE_NO_MFMA) within fp32 rounding; walkers whose activations leave the f16 range come back from the repair
+    pass with exactly the vector-pipe kernel's values, their neighbours untouched, every walker's moments counted once."""
+    from pita_amd.egnn_dynamics_ad2_cat import EGNN_dynamics_AD2_cat
+
+    g = golden("egnn_ad2cat_h64_fwd.npz")
+    w = {k[2:]: T(v) for k, v in g.items() if k.startswith("w.")}
+    net = EGNN_dynamics_AD2_cat(22, 3, hidden_nf=64, n_layers=5, tanh=True, attention=True, condition_beta=True)
+    net.load_state_dict(w)
+    sched, gam = pa.ElucidatingNoiseSchedule(sigma_min=0.01, sigma_max=80.0, rho=7), pa.ConstantAnnealingFactorSchedule(4 / 3)
+    sde = pa.VEReverseSDE(noise_schedule=sched, score_net=pa.ScoreNet(net), debias_inference=False)
+    N, B = 8, 41  # ragged: ten groups of four walkers + one
+
+    class Geo:
+        n_particles, n_spatial_dim, is_molecule = 22, 3, True
+
+    gen = torch.Generator().manual_seed(21)
+    x1 = O.remove_mean(torch.randn(B, 66, generator=gen) * 60.0, 22, 3).cuda()
+    noise = torch.randn(N, B, 66, generator=gen).cuda()
+    mk = lambda **kw: pa.WeightedSDEIntegrator(sde=sde, num_integration_steps=N, start_resampling_step=0,
+                                               end_resampling_step=N, resampling_interval=-1, num_negative_time_steps=0,
+                                               post_mcmc_steps=0, seed=5, **kw)
+    for nz in (None, noise):
+        xf, _, _, tf, _ = mk().integrate_sde(x1, Geo(), gam, inverse_temperature=1.3, noise=nz)
+        xs, _, _, ts, _ = mk(record_terms=True).integrate_sde(x1, Geo(), gam, inverse_temperature=1.3, noise=nz)
+        assert torch.isfinite(xf).all() and rel(xf, xs) < 2e-5, rel(xf, xs)
+        assert len(tf) == N and len(ts) == N
+        for k in range(N):  # device-reduced moments of the fused launch == statistics of the per-step tensors
+            assert abs(float(tf[k].drift_X.std()) - float(ts[k].drift_X.std())) < 2e-5 * float(ts[k].drift_X.std())
+    # the C entry point directly: chunking and sharding invariance, bit for bit
+    tab = pa.sde_integration.build_step_table(sched, gam, torch.linspace(1.0, 0.0, N + 1)[:-1], 1.0 / N, 1.0, 1.3).cuda()
+    # (walkers inside the f16 range: a walker the repair pass takes over is computed on the vector pipe for the steps of
+    # THAT launch, so across a cut it would agree only to the two kernels' rounding difference, checked further down)
+    x3 = (x1 * 0.05).contiguous()
+    tab = pa.sde_integration.build_step_table(sched, gam, torch.linspace(0.3, 0.0, N + 1)[:-1], 0.3 / N, 1.0, 1.3).cuda()
+    st = torch.zeros(N, 4, dtype=torch.float64, device="cuda")
+    whole = net.sampler_run(x3.clone(), tab, N, seed=9, stats_out=st)
+    for cut in (1, 3, 7):
+        parts = x3.clone()
+        net.sampler_run(parts, tab[:cut].contiguous(), cut, seed=9)
+        net.sampler_run(parts, tab[cut:].contiguous(), N - cut, seed=9, step0=cut)
+        assert torch.equal(whole, parts), cut
+    lo, hi = x3[:17].clone(), x3[17:].clone()
+    net.sampler_run(lo, tab, N, seed=9)
+    net.sampler_run(hi, tab, N, seed=9, walker_offset=17)
+    assert torch.equal(whole, torch.cat([lo, hi]))
+    assert float(whole.reshape(B, 22, 3).mean(1).abs().max()) < 2e-4  # remove_mean every step
+    monkeypatch.setenv("PITA_WIDE_NO_MFMA", "1")
+    try:
+        stv = torch.zeros(N, 4, dtype=torch.float64, device="cuda")
+        vec = net.sampler_run(x3.clone(), tab, N, seed=9, stats_out=stv)
+        vparts = x3.clone()
+        net.sampler_run(vparts, tab[:3].contiguous(), 3, seed=9)
+        net.sampler_run(vparts, tab[3:].contiguous(), N - 3, seed=9, step0=3)
+        assert torch.equal(vec, vparts)
+    finally:
+        monkeypatch.delenv("PITA_WIDE_NO_MFMA")
+    assert rel(whole, vec) < 1e-5 and not torch.equal(whole, vec)
+    np.testing.assert_allclose(st.cpu().numpy()[:, [1, 3]], stv.cpu().numpy()[:, [1, 3]], rtol=1e-5)
+    # out-of-range walkers (pair distances ~1e4: edge pre-activations beyond the f16 range from the first layer on)
+    x2 = x1.clone()
+    hot = torch.tensor([2, 3, 20, 40])
+    x2[hot.cuda()] *= 400.0
+    tab2 = pa.sde_integration.build_step_table(sched, gam, torch.linspace(0.05, 0.0, N + 1)[:-1], 0.05 / N, 1.0, 1.3).cuda()
+    sa, sb = (torch.zeros(N, 4, dtype=torch.float64, device="cuda") for _ in range(2))
+    a = net.sampler_run(x2.clone(), tab2, N, seed=9, stats_out=sa)
+    monkeypatch.setenv("PITA_WIDE_NO_MFMA", "1")
+    try:
+        b = net.sampler_run(x2.clone(), tab2, N, seed=9, stats_out=sb)
+    finally:
+        monkeypatch.delenv("PITA_WIDE_NO_MFMA")
+    assert torch.isfinite(b[hot]).all(), "the vector-pipe kernel handles this range in fp32"
+    assert torch.equal(a[hot], b[hot])
+    keep = torch.ones(B, dtype=torch.bool)
+    keep[hot] = False
+    plain = net.sampler_run(x2[keep.cuda()].clone(), tab2, N, seed=9)  # (Philox keys follow the position in the batch)
+    assert plain.shape[0] == B - 4 and rel(a[keep], b[keep]) < 1e-5
+    sah, sbh = sa.cpu().numpy(), sb.cpu().numpy()
+    np.testing.assert_allclose(sah[:, [1, 3]], sbh[:, [1, 3]], rtol=1e-5)
+
+
 @pytest.mark.parametrize("n", [13, 22, 33, 42, 55])
 def test_egnn_ad2cat_other_particle_counts(pa, n, monkeypatch):
     """Every instantiation of the matrix-pipe kernel -- the particle counts EGNN_dynamics_AD2_cat knows node features for
