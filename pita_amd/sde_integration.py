@@ -153,6 +153,24 @@ class _Comm:
         return recv[pos[torch.cumsum(fl.to(torch.int64), 0) - 1]]
 
 
+def _count_distinct(ids):
+    """Number of distinct parents of a systematic resampling, as a 0-dim DEVICE tensor (no host synchronisation).  The
+    ids are non-decreasing up to the cyclic rotation by the event's uniform (utils.py:111-120), so every distinct parent
+    is one cyclic run: distinct = max(1, number of positions whose cyclic predecessor differs).  The reference takes
+    ``len(np.unique(choice))`` on the host every step (sde_integration.py:295)."""
+    return (ids != torch.roll(ids, 1)).sum().clamp_min(1)
+
+
+def _host_counts(counts):
+    """The list ``num_unique_idxs`` of the reference (python ints): one transfer for all the events of a run."""
+    dev = [(k, c) for k, c in enumerate(counts) if isinstance(c, torch.Tensor)]
+    if dev:
+        vals = torch.stack([c for _, c in dev]).tolist()
+        for (k, _), v in zip(dev, vals):
+            counts[k] = int(v)
+    return counts
+
+
 def _terms_from_stats(st4, st8, n_elem, n_walk, computed, debiased):
     """N light SDETerms from the per-step moment buffers (host copies happen once, here).  st4: [N, 4] drift_X /
     diffusion moments; st8: [N, 8] drift_A, divergence_score, cross_term, dUt_dt moments (debiased regime only)."""
@@ -289,7 +307,7 @@ class WeightedSDEIntegrator:
                 a = torch.zeros(comm.world * Bl, device=dev)  # drift_A = 0 in the not-debiased regime
                 u = comm.shared_uniform(next(u_iter) if u_iter is not None else None)
                 ids, _ = sample_cat_sys(a.shape[0], a, u)
-                num_unique_idxs[stop] = int(torch.unique(ids).numel())
+                num_unique_idxs[stop] = _count_distinct(ids)
                 x = comm.exchange_rows(x, ids, Bl)
                 if mean_free:
                     x = remove_mean(x, n, d)
@@ -315,7 +333,7 @@ class WeightedSDEIntegrator:
             x, acceptance_rate_list = fn(x, energy_function, return_acceptance_rate=True, walker_offset=off, comm=comm,
                                          noise=self._mala_draws[0], uniforms=self._mala_draws[1], **kw)
         x = self._gather_final(x, comm, Bl)  # X1: the only collective on the resampling-free path
-        return x, logweights, num_unique_idxs, sde_terms_all, acceptance_rate_list
+        return x, logweights, _host_counts(num_unique_idxs), sde_terms_all, acceptance_rate_list
 
     # ------------------------------------------------------------------ debiased regime (per step; section 8(f) N1)
     def _integrate_debiased(self, x, comm, tab_h, times, noise, key, off, Bl, Bg, n, d, mean_free, energy_function,
@@ -364,7 +382,7 @@ class WeightedSDEIntegrator:
                 ag = comm.all_gather(a)
                 u = comm.shared_uniform(next(u_iter) if u_iter is not None else None)
                 ids, _ = sample_cat_sys(ag.shape[0], ag, u)
-                n_unique = int(torch.unique(ids).numel())
+                n_unique = _count_distinct(ids)
                 x = comm.exchange_rows(x, ids, Bl)
                 a = torch.zeros_like(a)
             if mean_free:
@@ -392,7 +410,7 @@ class WeightedSDEIntegrator:
             kw = dict(dt_init=self.dt_negative_time) if self.adaptive_mcmc else {}
             x, acceptance_rate_list = fn(x, energy_function, return_acceptance_rate=True, walker_offset=off, comm=comm,
                                          noise=self._mala_draws[0], uniforms=self._mala_draws[1], **kw)
-        return self._gather_final(x, comm, Bl), logweights, num_unique_idxs, sde_terms_all, acceptance_rate_list
+        return self._gather_final(x, comm, Bl), logweights, _host_counts(num_unique_idxs), sde_terms_all, acceptance_rate_list
 
     def _gather_final(self, x, comm, Bl):
         """All-gather of the final shards.  After MALA every shard is [its valid walkers, its set-aside walkers]; the
@@ -426,7 +444,7 @@ class WeightedSDEIntegrator:
         u = comm.shared_uniform(next(u_iter) if u_iter is not None else None)
         ids, _ = sample_cat_sys(a_next.shape[0], a_next, u)
         x = comm.exchange_rows(x, ids, Bl)
-        return x, a_next, int(torch.unique(ids).numel())
+        return x, a_next, _count_distinct(ids)
 
     # ------------------------------------------------------------------ A2-A4 steps [s0, s1)
     def _run_steps(self, model, x, tab, tab_h, s0, s1, noise, key, off, n, d, mean_free, beta, sde_terms_all, st4=None):

@@ -125,3 +125,27 @@ def test_committed_bench_lines_follow_survey_8d():
         under = json.loads([ln for ln in open(os.path.join(prof, f"r03_bench_under_rocprof_{cfg}.json")) if ln.startswith("{")][-1])
         ev_ms = under["roofline"]["ms_per_launch"]
         assert abs(avg_ms - ev_ms) < 0.03 * ev_ms, (cfg, avg_ms, ev_ms)
+
+
+def test_count_distinct_parents_without_host_unique():
+    """num_unique_idxs (sde_integration.py:295: len(np.unique(choice))) from the structure of systematic-resampling ids --
+    non-decreasing up to the cyclic rotation by the event's uniform -- as one device reduction: equal to np.unique on
+    reference-shaped id vectors, including the constant vector and a run that wraps around the end."""
+    import numpy as np
+    import torch
+
+    from oracle import pita_oracle as O
+    from pita_amd.sde_integration import _count_distinct, _host_counts
+
+    gen = torch.Generator().manual_seed(3)
+    cases = [torch.zeros(17, dtype=torch.int64), torch.arange(9), torch.tensor([3, 3, 4, 7, 7, 0, 0, 3]),
+             torch.tensor([5, 5, 5, 1, 1, 5])]
+    for B in (1, 2, 64, 1000):
+        for spread in (0.1, 3.0, 30.0):
+            logits = torch.randn(B, generator=gen) * spread
+            for u0 in (0.0, 0.37, 0.999):
+                cases.append(torch.from_numpy(O.sample_cat_sys(logits, u0)))
+    counts = [_count_distinct(c) for c in cases]
+    assert all(isinstance(c, torch.Tensor) and c.dim() == 0 for c in counts)
+    got = _host_counts([7] + counts)  # python ints pass through, device scalars are fetched in one transfer
+    assert got[0] == 7 and got[1:] == [len(np.unique(c.numpy())) for c in cases]
