@@ -1,5 +1,5 @@
-/* Host-side sanitizer probe of the C ABI (tests/test_abi.py::test_host_glue_under_address_and_ub_sanitizers): linked
- * against a build of pita_amd/csrc/ whose HOST code is compiled with -fsanitize=address,undefined (the device code is
+/* Host-side sanitizer probe of the C ABI (tests/test_sanitizers_cpu.py): linked
+ * against a build of pita_amd/csrc/ whose HOST code is compiled with the address and undefined-behaviour sanitizers (the device code is
  * not instrumented: GPU sanitizers are unavailable on this pool).  Walks the argument-validation paths of the launch
  * wrappers and the create / destroy paths of every handle type; no kernel is launched, so it runs without a GPU (every
  * valid creation then fails at its first HIP call and must release what it allocated -- LeakSanitizer checks that). */
