@@ -61,6 +61,30 @@ def test_lj_golden(pa, golden, n):
     assert rel(f[:nphys], g["force_ef0.5"][:nphys]) < 1e-5
 
 
+def test_lj13_ring_instantiation_golden(pa, golden, monkeypatch):
+    """The lane-per-particle instantiation of the LJ13 target (Ring<13, 3>: a walker on a DPP row of 16 lanes, four
+    walkers per wave; PITA_LJ13_RING=1 -- the round-4 experiment of DESIGN 4.2, slower than the lane-per-walker kernels at
+    every batch size and therefore not the route) against the same reference goldens, ragged batch sizes included."""
+    g = golden("lj13_logp_force.npz")
+    nphys = int(g["n_cold"]) + int(g["n_warm"])
+    x = cu(g["x"])
+    e = pa.LennardJonesEnergy(39, 13, 3)
+    lp0, f0 = e(x, return_force=True)
+    monkeypatch.setenv("PITA_LJ13_RING", "1")
+    lp, f = e(x, return_force=True)
+    assert not torch.equal(f, f0)  # a different kernel really ran
+    np.testing.assert_allclose(lp.cpu().numpy()[:nphys], g["logp_T1.0"][:nphys], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(lp.cpu().numpy()[nphys:], g["logp_T1.0"][nphys:], rtol=2e-5)
+    assert rel(f[:nphys], g["force_T1.0"][:nphys]) < 1e-5 and rel(f[nphys:], g["force_T1.0"][nphys:]) < 1e-4
+    for n in (1, 3, 4, 5, 63):
+        lpn, fn = e(x[:n].contiguous(), return_force=True)
+        assert torch.equal(lpn, lp[:n]) and torch.equal(fn, f[:n]), n
+    big = x[:nphys].repeat(700, 1)[:40001].contiguous()  # more groups than resident waves: the prefetching loop
+    lpb, fb = e(big, return_force=True)
+    idx = (torch.arange(40001) % nphys).cuda()
+    assert torch.equal(lpb, lp[idx]) and torch.equal(fb, f[idx])
+
+
 def test_lj13_against_reference_held_energy2(pa, golden):
     """A12 against reference-held code only: ``energy2`` of sampling/sample_lj13.py:24-30 executed as shipped in
     make_golden.py (torch.pdist, no distance eps; force by autograd).  The HIP kernel with the bgflow eps of 1e-6 is

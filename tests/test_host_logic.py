@@ -91,7 +91,7 @@ def test_alp_energy_facade_and_system_xml_fixture():
 
 
 def test_committed_bench_lines_follow_survey_8d():
-    """The committed round-3 bench lines (profiles/r03_bench_<config>.json) can be recomputed from their own fields by
+    """The committed bench lines (profiles/r03_bench_<config>.json, r04_bench_lj13.json) can be recomputed from their own fields by
     SURVEY 8(d)'s formulas: roofline.achieved = algorithmic flops per launch / launch time, frac = achieved / peak,
     value = walkers x steps / (steps x ms_per_step), PMC traffic >= algorithmic bytes; and the rocprofv3 kernel-stats
     summary of the same command (profiles/r03_kernel_stats_<config>.csv) agrees with the HIP-event launch time."""
@@ -101,8 +101,8 @@ def test_committed_bench_lines_follow_survey_8d():
 
     prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     alg = {"lj13": 4196608.0, "dw4": None, "aldp22": None, "lj55": None}  # LJ13: 2 098 304 MAC x 2
-    for cfg in ("lj13", "dw4", "aldp22", "lj55"):
-        path = os.path.join(prof, f"r03_bench_{cfg}.json")
+    for rnd, cfg in (("r03", "lj13"), ("r03", "dw4"), ("r03", "aldp22"), ("r03", "lj55"), ("r04", "lj13")):
+        path = os.path.join(prof, f"{rnd}_bench_{cfg}.json")
         line = json.loads([ln for ln in open(path) if ln.startswith("{")][-1])
         r = line["roofline"]
         B, c = line["config"]["walkers_per_gpu"], r["steps_per_launch"]
@@ -118,11 +118,11 @@ def test_committed_bench_lines_follow_survey_8d():
         cb = line["cpu_baseline"]
         assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
         # rocprofv3 --kernel-trace --stats of the same command (200 + 100 steps in 100-step launches)
-        rows = list(csv.DictReader(open(os.path.join(prof, f"r03_kernel_stats_{cfg}.csv"))))
+        rows = list(csv.DictReader(open(os.path.join(prof, f"{rnd}_kernel_stats_{cfg}.csv"))))
         samp = [x for x in rows if "egnn_kernel" in x["Name"] and ", 2, true," in x["Name"]]
         assert samp, cfg
         avg_ms = float(max(samp, key=lambda x: float(x["TotalDurationNs"]))["AverageNs"]) * 1e-6
-        under = json.loads([ln for ln in open(os.path.join(prof, f"r03_bench_under_rocprof_{cfg}.json")) if ln.startswith("{")][-1])
+        under = json.loads([ln for ln in open(os.path.join(prof, f"{rnd}_bench_under_rocprof_{cfg}.json")) if ln.startswith("{")][-1])
         ev_ms = under["roofline"]["ms_per_launch"]
         assert abs(avg_ms - ev_ms) < 0.03 * ev_ms, (cfg, avg_ms, ev_ms)
 
