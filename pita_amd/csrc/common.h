@@ -38,6 +38,21 @@ inline int fail(int code, const char* fmt, ...) {
 
 constexpr int kWave = 64;  // CDNA wavefront
 
+// Launch state that HIP keeps PER DEVICE -- the dynamic-LDS opt-in of a kernel (hipFuncSetAttribute), occupancy and CU
+// counts -- is cached per device: a process that drives several GPUs (handles carry their device, PitaDeviceGuard) must
+// not reuse the first device's answers on the second.
+constexpr int kMaxDevices = 32;
+inline int current_device_slot() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0;
+  return d % kMaxDevices;
+}
+template <class T>
+struct PerDevice {
+  T v[kMaxDevices] = {};
+  T& get() { return v[current_device_slot()]; }
+};
+
 // ---- device math with explicit accuracy choices
 // exp2/rcp map to single v_exp_f32 / v_rcp_f32 (about 1 ulp); used where the reference applies
 // sigmoid-family activations (relative error ~1e-7, no cancellation).

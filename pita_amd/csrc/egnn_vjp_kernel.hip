@@ -593,7 +593,8 @@ extern "C" int pita_egnn_vjp(pita_egnn_t* net, const float* h, const float* x, c
   p.B = B; p.h = h; p.x = x; p.beta = beta; p.cot = cot; p.out = out; p.vjp = vjp; p.dot_h = dot_h;
   const size_t lds = s->lds_bytes(p.n_layers);
   const auto kernel = s->kernel[(p.attention && p.tanh_on && dot_h) ? 1 : 0];
-  static thread_local const void* configured = nullptr;
+  static thread_local PerDevice<const void*> configured_on;  // the opt-in is per device
+  const void*& configured = configured_on.get();
   if (configured != (const void*)kernel) {
     PITA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -18,6 +18,8 @@ struct pita_egnn_wide {
   // fused sampler on the matrix pipe: backup of the walkers + per-particle bookkeeping for the vector-pipe repair pass
   void* d_bk = nullptr;
   size_t bk_bytes = 0;
+  int* d_flag = nullptr;  // set by the matrix-pipe kernel when a walker comes out non-finite: the repair pass returns at once otherwise
+  bool vec_attr[2] = {false, false};  // dynamic-LDS opt-in of the vector-pipe kernel done (evaluation / sampler instantiation)
 };
 
 namespace pita {

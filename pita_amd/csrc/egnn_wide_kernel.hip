@@ -60,6 +60,7 @@ struct WideParams {
   int remove_mean;
   double* stats_out;       // nullable [n_steps][4]
   const int* bad_from;     // only_bad: [B*n] first step whose moments the matrix-pipe launch left to this one
+  const int* bad_flag;     // only_bad, nullable: 0 = the matrix-pipe launch left nothing non-finite, return at once
 };
 
 namespace {
@@ -149,22 +150,24 @@ __device__ __forceinline__ float dense_mem_b(const float* __restrict__ wt, float
 #endif
 }
 
-// HK = hidden width rounded up to 32 (the k extent of every dense layer)
-template <int HK>
+// HK = hidden width rounded up to 32 (the k extent of every dense layer); SMP: the all-steps sampler (mode 3) as its own
+// instantiation, so that the evaluation modes do not carry the step loop's state through the layers (it spilled there)
+template <int HK, bool SMP>
 __global__ void __launch_bounds__(256, 2) egnn_wide_kernel(WideParams p) {  // two waves per SIMD: at most 256 registers
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = p.n, DIM = p.dim;
-  const int per_wave = 3 * n * WIDE_HP + 4 * n * 4 + WIDE_HP;
+  const int per_wave = 3 * n * WIDE_HP + (SMP ? 4 : 3) * n * 4 + WIDE_HP;
   float* hf = lds + wave * per_wave;     // [n][64] node features
   float* At = hf + n * WIDE_HP;          // [n][64] Wa h_i + b1
   float* Bt = At + n * WIDE_HP;          // [n][64] Wb h_j
   float* pos = Bt + n * WIDE_HP;         // [n][4] positions entering the layer
   float* pos0 = pos + n * 4;             // [n][4] input geometry (frozen edge attribute)
   float* posn = pos0 + n * 4;            // [n][4] positions leaving the layer
-  float* xw = posn + n * 4;              // [n][4] the walker's unscaled coordinates (sampler mode: across the steps)
-  float* bc = xw + n * 4;                // [64] broadcast slot of the dense layers
-  const bool smp = p.mode == 3;
+  float* xw = posn + n * 4;              // [n][4] the walker's unscaled coordinates across the steps (sampler mode only)
+  float* bc = SMP ? xw + n * 4 : xw;     // [64] broadcast slot of the dense layers
+  constexpr bool smp = SMP;
+  if (p.only_bad && p.bad_flag && *p.bad_flag == 0) return;  // nothing to repair: no pass over the results at all
   const long long nw = (long long)gridDim.x * waves;
   for (long long w = (long long)blockIdx.x * waves + wave; w < p.B; w += nw) {
     if (p.only_bad) {
@@ -173,14 +176,14 @@ __global__ void __launch_bounds__(256, 2) egnn_wide_kernel(WideParams p) {  // t
       for (int q = lane; q < n * DIM; q += 64) bad = bad || !__builtin_isfinite(res[w * n * DIM + q]);
       if (!__any(bad)) continue;  // wave-uniform
     }
-    {
-      const float* src = smp ? (p.only_bad ? p.x_backup : p.xs) : p.x;
+    if (smp) {  // (the evaluation modes read the walker from memory where they need it: no table, no extra live state)
+      const float* src = p.only_bad ? p.x_backup : p.xs;
       for (int q = lane; q < n * DIM; q += 64) {
         const int i = q / DIM, k = q - i * DIM;
         xw[i * 4 + k] = src[w * n * DIM + q];
       }
+      wfence();
     }
-    wfence();
     const int nsteps = smp ? p.n_steps : 1;
     for (int step = 0; step < nsteps; ++step) {
     float tv, bet, c_s = 0.f, c_in = 1.f, c_out = 1.f, tfeat, hval = 1.f;
@@ -206,7 +209,7 @@ __global__ void __launch_bounds__(256, 2) egnn_wide_kernel(WideParams p) {  // t
     // scaled input coordinates
     for (int q = lane; q < n * DIM; q += 64) {
       const int i = q / DIM, k = q - i * DIM;
-      const float v = c_in * xw[i * 4 + k];
+      const float v = c_in * (smp ? xw[i * 4 + k] : p.x[w * n * DIM + q]);
       pos[i * 4 + k] = v;
       pos0[i * 4 + k] = v;
     }
@@ -285,7 +288,7 @@ __global__ void __launch_bounds__(256, 2) egnn_wide_kernel(WideParams p) {  // t
         const float F = (pos[i * 4 + k] - pos0[i * 4 + k]) - mean[k];
         float o = F;
         if (p.mode != 0) {
-          const float xc = xw[i * 4 + k];
+          const float xc = p.x[w * n * DIM + q];
           o = c_s * xc + c_out * F;
           if (p.mode == 2) o = (o - xc) / hval;
         }
@@ -756,15 +759,17 @@ extern "C" int pita_egnn_wide_eval(pita_egnn_wide_t* net, int what, const float*
   if (pita_egnn_wide_uses_matrix_pipe(net)) {
     rc = wide64_launch(net, what, t, x, beta, out, B, (hipStream_t)stream);
     p.only_bad = 1;
+    p.bad_flag = net->d_flag;
   }
-  const size_t per_wave = sizeof(float) * (size_t)(3 * p.n * WIDE_HP + 4 * p.n * 4 + WIDE_HP);
+  const size_t per_wave = sizeof(float) * (size_t)(3 * p.n * WIDE_HP + 3 * p.n * 4 + WIDE_HP);
   int waves = 4;
   while (waves > 1 && per_wave * waves > 72 * 1024) waves >>= 1;  // two blocks per CU inside the 160 KB
-  auto kernel = p.H <= 32 ? egnn_wide_kernel<32> : egnn_wide_kernel<64>;
+  auto kernel = p.H <= 32 ? egnn_wide_kernel<32, false> : egnn_wide_kernel<64, false>;
   if (rc != PITA_OK) {
   } else if (per_wave * waves > 150 * 1024) {
     rc = fail(PITA_EUNSUPPORTED, "pita_egnn_wide_eval: %d particles need %zu B of LDS per wave", p.n, per_wave);
-  } else if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+  } else if (!net->vec_attr[0] &&
+             hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(per_wave * waves)) != hipSuccess) {
     rc = fail(PITA_EHIP, "pita_egnn_wide_eval: cannot reserve %zu B of LDS", per_wave * waves);
   } else {
@@ -772,6 +777,7 @@ extern "C" int pita_egnn_wide_eval(pita_egnn_wide_t* net, int what, const float*
     const unsigned grid = (unsigned)(want < cap ? want : cap);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(waves * 64), per_wave * waves, (hipStream_t)stream, p);
     if (hipGetLastError() != hipSuccess) rc = fail(PITA_EHIP, "pita_egnn_wide_eval: launch failed");
+    else net->vec_attr[0] = true;
   }
   if (switched) (void)hipSetDevice(prev);
   return rc;
@@ -867,16 +873,18 @@ extern "C" int pita_egnn_wide_sampler_run(pita_egnn_wide_t* net, float* x, int64
       p.only_bad = 1;
       p.x_backup = xb;
       p.bad_from = bad_from;
+      p.bad_flag = net->d_flag;
     }
   }
   const size_t per_wave = sizeof(float) * (size_t)(3 * p.n * WIDE_HP + 4 * p.n * 4 + WIDE_HP);
   int waves = 4;
   while (waves > 1 && per_wave * waves > 72 * 1024) waves >>= 1;
-  auto kernel = p.H <= 32 ? egnn_wide_kernel<32> : egnn_wide_kernel<64>;
+  auto kernel = p.H <= 32 ? egnn_wide_kernel<32, true> : egnn_wide_kernel<64, true>;
   if (rc != PITA_OK) {
   } else if (per_wave * waves > 150 * 1024) {
     rc = fail(PITA_EUNSUPPORTED, "pita_egnn_wide_sampler_run: %d particles need %zu B of LDS per wave", p.n, per_wave);
-  } else if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+  } else if (!net->vec_attr[1] &&
+             hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(per_wave * waves)) != hipSuccess) {
     rc = fail(PITA_EHIP, "pita_egnn_wide_sampler_run: cannot reserve %zu B of LDS", per_wave * waves);
   } else {
@@ -884,6 +892,7 @@ extern "C" int pita_egnn_wide_sampler_run(pita_egnn_wide_t* net, float* x, int64
     const unsigned grid = (unsigned)(want < cap ? want : cap);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(waves * 64), per_wave * waves, st, p);
     if (hipGetLastError() != hipSuccess) rc = fail(PITA_EHIP, "pita_egnn_wide_sampler_run: launch failed");
+    else net->vec_attr[1] = true;
   }
   if (switched) (void)hipSetDevice(prev);
   return rc;

@@ -52,6 +52,7 @@ struct Wide64Params {
   int remove_mean;
   double* stats_out;       // nullable [n_steps][4]
   int* bad_from;           // [B*N]: first step whose moments this launch left out for the particle (INT_MAX: none)
+  int* flag;               // nullable: set to 1 when a result of this launch is not finite (the repair pass has work)
 };
 
 template <int N, int DIM, int G, int WAVES>
@@ -372,7 +373,10 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_wide64_kernel(Wide64Params
             o = c_s[T] * xc + c_out[T] * o;             // denoiser (score_net.py:31-33)
             if (p.mode == 2) o = (o - xc) / hval[T];    // score (:19)
           }
-          if (valid[T] && hh == 0) p.out[(walker0 * N + col[T]) * DIM + k] = o;
+          if (valid[T] && hh == 0) {
+            p.out[(walker0 * N + col[T]) * DIM + k] = o;
+            if (p.flag && !__builtin_isfinite(o)) *p.flag = 1;
+          }
         }
     } else {
       // ---- reverse-SDE Euler-Maruyama update (sdes.py:119-122,250; sde_integration.py:347-348): the arithmetic of
@@ -451,7 +455,11 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_wide64_kernel(Wide64Params
       for (int T = 0; T < NT; ++T) {
 #pragma unroll
         for (int k = 0; k < DIM; ++k)
-          if (valid[T] && hh == 0) p.xs[(walker0 * N + col[T]) * DIM + k] = xbuf[col[T] * DIM + k];
+          if (valid[T] && hh == 0) {
+            const float v = xbuf[col[T] * DIM + k];
+            p.xs[(walker0 * N + col[T]) * DIM + k] = v;
+            if (p.flag && !__builtin_isfinite(v)) *p.flag = 1;
+          }
         if (p.bad_from && valid[T] && hh == 0) p.bad_from[walker0 * N + col[T]] = bad_from[T];
       }
     }
@@ -577,6 +585,7 @@ int wide64_prepare(pita_egnn_wide* net, const float* w, const float* he) {
   hipError_t e = hipMalloc(&net->d_m16h, n_m * sizeof(unsigned));
   if (e == hipSuccess) e = hipMalloc(&net->d_vecs64, n_v * sizeof(float));
   if (e == hipSuccess) e = hipMalloc(&net->d_est64, (size_t)n * 64 * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&net->d_flag, sizeof(int));
   if (e == hipSuccess) e = hipMemcpy(net->d_m16h, hm, n_m * sizeof(unsigned), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(net->d_vecs64, hv, n_v * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(net->d_est64, hes, (size_t)n * 64 * sizeof(float), hipMemcpyHostToDevice);
@@ -603,6 +612,8 @@ void wide64_release(pita_egnn_wide* net) {
   (void)hipFree(net->d_vecs64);
   (void)hipFree(net->d_est64);
   (void)hipFree(net->d_bk);
+  (void)hipFree(net->d_flag);
+  net->d_flag = nullptr;
   net->d_bk = nullptr;
   net->bk_bytes = 0;
   net->d_m16h = nullptr;
@@ -638,6 +649,8 @@ static int wide64_run(pita_egnn_wide* net, Wide64Params& p, hipStream_t stream) 
   p.m16h = net->d_m16h; p.vecs = net->d_vecs64; p.est = net->d_est64;
   p.L = net->cfg.n_layers; p.attention = net->cfg.attention; p.tanh_on = net->cfg.tanh; p.has_beta = net->cfg.condition_beta;
   p.coord_scale = net->cfg.coords_range / (float)net->cfg.n_layers;
+  p.flag = net->d_flag;
+  if (p.flag) PITA_HIP_CHECK(hipMemsetAsync(p.flag, 0, sizeof(int), stream));
   const long long ngroups = (B + s->G - 1) / s->G;
   const long long want = (ngroups + s->waves - 1) / s->waves, cap = net->n_cu;  // one 4-wave block per CU
   const unsigned grid = (unsigned)(want < cap ? want : cap);

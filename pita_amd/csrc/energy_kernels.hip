@@ -1099,7 +1099,8 @@ extern "C" int pita_lj_logp_force(const float* x, float* logp, float* force, int
     const bool unit = p.rm2 == 1.0f;
     hipStream_t s = (hipStream_t)stream;
     if (!two && !getenv("PITA_LJ13_NO_STREAM")) {  // persistent blocks with the next tile in flight
-      static int per_cu = 0, n_cu = 0;
+      static PerDevice<int> per_cu_on, n_cu_on;
+      int &per_cu = per_cu_on.get(), &n_cu = n_cu_on.get();
       if (per_cu == 0) {
         int dev = 0, v = 0;
         hipDeviceProp_t prop;
@@ -1236,7 +1237,8 @@ extern "C" int pita_lj_mala(float* x, float* logp, const float* noise, const flo
   }
   const long long nblk = (B + 127) / 128;
   const bool unit = p.rm2 == 1.0f;
-  static int capacity = 0;  // co-resident blocks of the chain kernel on this device
+  static PerDevice<int> capacity_on;  // co-resident blocks of the chain kernel, per device
+  int& capacity = capacity_on.get();
   if (capacity == 0) {
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;

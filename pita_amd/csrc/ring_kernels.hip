@@ -556,7 +556,8 @@ template <int N, int DIM, int KIND>
 struct RingLaunch {
   using R = Ring<N, DIM>;
   static int cus() {
-    static int n = 0;
+    static PerDevice<int> n_on;
+    int& n = n_on.get();
     if (n == 0) {
       int dev = 0;
       hipDeviceProp_t prop;
@@ -581,12 +582,13 @@ struct RingLaunch {
   }
   static int energy(const float* x, float* logp, float* force, long long B, const PairParams& p, hipStream_t s) {
     const size_t lds = sizeof(float) * 4 * R::TAB_F;
-    static int occ[2] = {0, 0};
+    static PerDevice<int> occ_on[2];
+    int* occ[2] = {&occ_on[0].get(), &occ_on[1].get()};
     if (KIND == E_LJ && p.rm2 == 1.0f) {
-      const unsigned grid = grid_for(B, resident(ring_energy_kernel<N, DIM, KIND, true>, lds, occ[1]));
+      const unsigned grid = grid_for(B, resident(ring_energy_kernel<N, DIM, KIND, true>, lds, *occ[1]));
       hipLaunchKernelGGL((ring_energy_kernel<N, DIM, KIND, true>), dim3(grid), dim3(256), lds, s, x, logp, force, B, p);
     } else {
-      const unsigned grid = grid_for(B, resident(ring_energy_kernel<N, DIM, KIND, false>, lds, occ[0]));
+      const unsigned grid = grid_for(B, resident(ring_energy_kernel<N, DIM, KIND, false>, lds, *occ[0]));
       hipLaunchKernelGGL((ring_energy_kernel<N, DIM, KIND, false>), dim3(grid), dim3(256), lds, s, x, logp, force, B, p);
     }
     PITA_LAUNCH_CHECK();
@@ -594,12 +596,13 @@ struct RingLaunch {
   }
   static int descent(float* x, const float* noise, long long B, const PairParams& p, const DescentParams& q, hipStream_t s) {
     const size_t lds = sizeof(float) * 4 * R::TAB_F;
-    static int occ[2] = {0, 0};
+    static PerDevice<int> occ_on[2];
+    int* occ[2] = {&occ_on[0].get(), &occ_on[1].get()};
     if (KIND == E_LJ && p.rm2 == 1.0f) {
-      const unsigned grid = grid_for(B, resident(ring_descent_kernel<N, DIM, KIND, true>, lds, occ[1]));
+      const unsigned grid = grid_for(B, resident(ring_descent_kernel<N, DIM, KIND, true>, lds, *occ[1]));
       hipLaunchKernelGGL((ring_descent_kernel<N, DIM, KIND, true>), dim3(grid), dim3(256), lds, s, x, noise, B, p, q);
     } else {
-      const unsigned grid = grid_for(B, resident(ring_descent_kernel<N, DIM, KIND, false>, lds, occ[0]));
+      const unsigned grid = grid_for(B, resident(ring_descent_kernel<N, DIM, KIND, false>, lds, *occ[0]));
       hipLaunchKernelGGL((ring_descent_kernel<N, DIM, KIND, false>), dim3(grid), dim3(256), lds, s, x, noise, B, p, q);
     }
     PITA_LAUNCH_CHECK();
@@ -608,15 +611,16 @@ struct RingLaunch {
   static int mala(float* x, float* logp, long long B, const PairParams& p, const MalaParams& q, hipStream_t s) {
     const size_t lds = sizeof(float) * 4 * 2 * R::TAB_F;
     const bool unit = KIND == E_LJ && p.rm2 == 1.0f;
-    static int per_cu[2] = {0, 0};  // co-resident blocks per CU of the chain kernel
-    if (per_cu[unit] == 0) {
+    static PerDevice<int> per_cu_on[2];  // co-resident blocks per CU of the chain kernel, per device
+    int& slot = per_cu_on[unit ? 1 : 0].get();
+    if (slot == 0) {
       int v = 0;
       if (unit) PITA_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, ring_mala_kernel<N, DIM, KIND, true>, 256, lds));
       else PITA_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, ring_mala_kernel<N, DIM, KIND, false>, 256, lds));
       PITA_REQUIRE(v > 0, "ring_mala: the chain kernel does not fit a compute unit");
-      per_cu[unit] = v;
+      slot = v;
     }
-    const unsigned grid = grid_for(B, per_cu[unit]);
+    const unsigned grid = grid_for(B, slot);
     if (unit) hipLaunchKernelGGL((ring_mala_kernel<N, DIM, KIND, true>), dim3(grid), dim3(256), lds, s, x, logp, B, p, q);
     else hipLaunchKernelGGL((ring_mala_kernel<N, DIM, KIND, false>), dim3(grid), dim3(256), lds, s, x, logp, B, p, q);
     PITA_LAUNCH_CHECK();

@@ -79,7 +79,7 @@ def test_lj13_ring_instantiation_golden(pa, golden, monkeypatch):
     for n in (1, 3, 4, 5, 63):
         lpn, fn = e(x[:n].contiguous(), return_force=True)
         assert torch.equal(lpn, lp[:n]) and torch.equal(fn, f[:n]), n
-    big = x[:nphys].repeat(700, 1)[:40001].contiguous()  # more groups than resident waves: the prefetching loop
+    big = x[:nphys].repeat(720, 1)[:40001].contiguous()  # more groups than resident waves: the prefetching loop
     lpb, fb = e(big, return_force=True)
     idx = (torch.arange(40001) % nphys).cuda()
     assert torch.equal(lpb, lp[idx]) and torch.equal(fb, f[idx])
