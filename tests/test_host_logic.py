@@ -101,7 +101,7 @@ def test_committed_bench_lines_follow_survey_8d():
 
     prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     alg = {"lj13": 4196608.0, "dw4": None, "aldp22": None, "lj55": None}  # LJ13: 2 098 304 MAC x 2
-    for rnd, cfg in (("r03", "lj13"), ("r03", "dw4"), ("r03", "aldp22"), ("r03", "lj55"), ("r04", "lj13")):
+    for rnd, cfg in (("r03", "lj13"), ("r03", "dw4"), ("r03", "aldp22"), ("r03", "lj55"), ("r04", "lj13"), ("r04", "dw4"), ("r04", "aldp22"), ("r04", "lj55")):
         path = os.path.join(prof, f"{rnd}_bench_{cfg}.json")
         line = json.loads([ln for ln in open(path) if ln.startswith("{")][-1])
         r = line["roofline"]
