@@ -442,6 +442,21 @@ def egnn_ad2_cat_h_initial(n: int) -> Tensor:
     return torch.nn.functional.one_hot(torch.tensor(at)).to(torch.float32)
 
 
+def egnn_aldp_h_initial(n: int) -> Tensor:
+    """Static node features of ``egnn_aldp.EGNN_dynamics.get_h_initial`` (egnn_aldp.py:51-78): as
+    ``egnn_ad2_cat_h_initial`` except for the methyl grouping of the 22-atom system ([1, 2, 3] instead of [0, 2, 3]).
+    The module's forward (:131-158) is ``egnn_ad2_cat_forward`` with this table."""
+    groups = {22: [([1, 2, 3], 2), ([19, 20, 21], 20), ([11, 12, 13], 12)],
+              33: [([1, 2, 3], 2), ([9, 10, 11], 10), ([19, 20, 21], 18), ([29, 30, 31], 31)],
+              42: [([1, 2, 3], 2), ([11, 12, 13], 12), ([21, 22, 23], 22), ([31, 32, 33], 32), ([39, 40, 41], 40)]}
+    if n in (13, 55):
+        return torch.zeros(n, 1)
+    at = np.arange(n)
+    for idx, v in groups[n]:
+        at[idx] = v
+    return torch.nn.functional.one_hot(torch.tensor(at)).to(torch.float32)
+
+
 def egnn_ad2_cat_forward(p: Dict[str, Tensor], t: Tensor, x: Tensor, beta: Optional[Tensor], n: int, d: int,
                          n_layers: int = 5, tanh: bool = True, attention: bool = True,
                          h_initial: Optional[Tensor] = None) -> Tensor:

@@ -319,6 +319,37 @@ def gen_egnn_ad2cat_sizes():
     save("egnn_ad2cat_sizes.npz", **out)
 
 
+def gen_egnn_aldp():
+    """``egnn_aldp.EGNN_dynamics`` (egnn_aldp.py:8-197: the other peptide EGNN of the reference -- hidden 64 x 4 layers,
+    no attention gate, no tanh bound by default, one-hot atom types with ITS OWN methyl grouping for 22 atoms, t and beta
+    as two more node features): the reference module's output on seeded inputs for 22 atoms with the class defaults +
+    temperature conditioning, and for a 33-atom net with attention / tanh switched on; weights and static features."""
+    from src.models.components import egnn_aldp
+
+    out = {}
+    for tag, n, kw in (("n22", 22, dict(condition_temperature=True)),
+                       ("n33", 33, dict(condition_temperature=True, attention=True, tanh=True, n_layers=2, hidden_nf=32))):
+        torch.manual_seed(1357 + n)
+        net = egnn_aldp.EGNN_dynamics(n_particles=n, n_dimension=3, **kw)
+        L = kw.get("n_layers", 4)
+        with torch.no_grad():
+            for l in range(L):
+                getattr(net.egnn, f"gcl_{l}").coord_mlp[2].weight.mul_(300.0)
+            for p in net.parameters():
+                p.add_(0.02 * torch.randn_like(p))
+        gen = torch.Generator().manual_seed(n)
+        B = 8
+        x = lattice_cluster(n, 3, B, gen, spacing=1.1, jitter=0.1) + 0.3 * torch.randn(B, n * 3, generator=gen)
+        t = torch.rand(B, generator=gen) - 0.5
+        betas = torch.tensor([1.0, 1.33, 4.0])[torch.arange(B) % 3]
+        with torch.no_grad():
+            F = net(t, x, betas)
+        out.update({f"x_{tag}": x.numpy(), f"t_{tag}": t.numpy(), f"beta_{tag}": betas.numpy(), f"F_{tag}": F.numpy(),
+                    f"h_initial_{tag}": net.h_initial.numpy().astype(np.float32)})
+        out.update({f"w_{tag}." + k: v for k, v in sd_np(net).items()})
+    save("egnn_aldp_fwd.npz", **out)
+
+
 # ----------------------------------------------------------------------------- MLP
 def gen_mlp():
     torch.manual_seed(12345)
@@ -865,7 +896,7 @@ def gen_traj_gmm():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "lj", "lj_smooth", "gmm", "egnn", "egnn_ad2cat", "egnn_ad2cat_sizes", "mlp", "prior", "resample", "traj_nodebias", "traj_1000",
+    which = sys.argv[1:] or ["schedules", "lj", "lj_smooth", "gmm", "egnn", "egnn_ad2cat", "egnn_ad2cat_sizes", "egnn_aldp", "mlp", "prior", "resample", "traj_nodebias", "traj_1000",
                              "traj_debias", "traj_debias_end", "traj_debias_long", "debias_variants", "post", "post55", "traj_1000_lj55", "traj_gmm"]
     for w in which:
         globals()["gen_" + w]()

@@ -538,6 +538,34 @@ def test_egnn_ad2cat_fused_sampler(pa, golden, monkeypatch):
     np.testing.assert_allclose(sah[:, [1, 3]], sbh[:, [1, 3]], rtol=1e-5)
 
 
+def test_egnn_aldp_golden(pa, golden):
+    """``pita_amd.egnn_aldp.EGNN_dynamics`` (egnn_aldp.py:8-197 on the wide-backbone kernels) against the reference
+    module's output: class defaults at 22 atoms (hidden 64 x 4 layers, no gate, no tanh: the matrix-pipe kernel) and a
+    33-atom hidden-32 net with gate and tanh; beta is ignored unless the net is temperature conditioned."""
+    from pita_amd.egnn_aldp import EGNN_dynamics
+
+    g = golden("egnn_aldp_fwd.npz")
+    for tag, n, kw in (("n22", 22, dict(n_layers=4, tanh=False, attention=False)),
+                       ("n33", 33, dict(n_layers=2, tanh=True, attention=True))):
+        w = {k[len(f"w_{tag}."):]: T(v) for k, v in g.items() if k.startswith(f"w_{tag}.")}
+        H = w["egnn.embedding.weight"].shape[0]
+        net = EGNN_dynamics(n, 3, hidden_nf=H, condition_temperature=True, **kw)
+        net.load_state_dict(w)
+        x, t, beta = cu(g[f"x_{tag}"]), cu(g[f"t_{tag}"]), cu(g[f"beta_{tag}"])
+        F = net(t, x, beta)
+        wd = {k: v.double() for k, v in w.items()}
+        F64 = O.egnn_ad2_cat_forward(wd, T(g[f"t_{tag}"]).double(), T(g[f"x_{tag}"]).double(), T(g[f"beta_{tag}"]).double(),
+                                     n, 3, h_initial=O.egnn_aldp_h_initial(n).double(), **kw)
+        err_ref, err_hip = rel(g[f"F_{tag}"], F64), rel(F, F64)
+        print(f"[egnn_aldp/{tag}] err_hip_vs_fp64={err_hip:.3e} err_ref_vs_fp64={err_ref:.3e}")
+        assert err_hip < max(4 * err_ref, 2e-6) and rel(F, g[f"F_{tag}"]) < max(2e-5, 6 * err_ref)
+        if H == 64:
+            assert net.uses_matrix_pipe("cuda:0")
+    plain = EGNN_dynamics(22, 3)  # not temperature conditioned: beta is accepted and ignored, like the reference's forward
+    xs = cu(g["x_n22"])
+    assert torch.equal(plain(cu(g["t_n22"]), xs, cu(g["beta_n22"])), plain(cu(g["t_n22"]), xs, None))
+
+
 @pytest.mark.parametrize("n", [13, 22, 33, 42, 55])
 def test_egnn_ad2cat_other_particle_counts(pa, n, monkeypatch):
     """Every instantiation of the matrix-pipe kernel -- the particle counts EGNN_dynamics_AD2_cat knows node features for

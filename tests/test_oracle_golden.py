@@ -226,6 +226,34 @@ def test_resample(golden, case):
     np.testing.assert_array_equal(torch.quantile(lg[torch.isfinite(lg)], 0.9).numpy(), g[f"q90_{case}"])
 
 
+def test_egnn_aldp(golden):
+    """``egnn_aldp.EGNN_dynamics`` (the reference's other peptide EGNN, egnn_aldp.py:8-197): its static node features
+    and its output for the class defaults (22 atoms, hidden 64 x 4, no gate, no tanh, temperature conditioned) and for a
+    33-atom net with gate and tanh, against the REFERENCE module's own output; and the pita_amd mirror builds the same
+    feature table and parameter names."""
+    from pita_amd.egnn_aldp import EGNN_dynamics
+
+    g = golden("egnn_aldp_fwd.npz")
+    for tag, n, kw in (("n22", 22, dict(n_layers=4, tanh=False, attention=False)),
+                       ("n33", 33, dict(n_layers=2, tanh=True, attention=True))):
+        w = {k[len(f"w_{tag}."):]: T(v) for k, v in g.items() if k.startswith(f"w_{tag}.")}
+        hi = O.egnn_aldp_h_initial(n)
+        np.testing.assert_array_equal(hi.numpy(), g[f"h_initial_{tag}"])
+        x, t, beta = T(g[f"x_{tag}"]), T(g[f"t_{tag}"]), T(g[f"beta_{tag}"])
+        F = O.egnn_ad2_cat_forward(w, t, x, beta, n, 3, h_initial=hi, **kw)
+        F64 = O.egnn_ad2_cat_forward({k: v.double() for k, v in w.items()}, t.double(), x.double(), beta.double(), n, 3,
+                                     h_initial=hi.double(), **kw)
+        err_ref = rel(g[f"F_{tag}"], F64.numpy())
+        assert rel(F.numpy(), g[f"F_{tag}"]) < max(2e-5, 6 * err_ref)
+        H = w["egnn.embedding.weight"].shape[0]
+        net = EGNN_dynamics(n, 3, hidden_nf=H, condition_temperature=True, **kw)
+        np.testing.assert_array_equal(net.h_initial.numpy().astype(np.float32), g[f"h_initial_{tag}"])
+        assert list(net.state_dict().keys()) == list(w.keys())
+        net.load_state_dict(w)  # shapes agree
+    with pytest.raises(NotImplementedError):
+        EGNN_dynamics(53, 3)  # node features from a topology file
+
+
 def _lj13_backbone(golden):
     w = {k: T(v) for k, v in golden("egnn_weights_trainedlike.npz").items()}
     return lambda cn, xs, b: O.egnn_forward(w, cn, xs, b, 13, 3)
