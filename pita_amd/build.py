@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpita_hip.so")
-SOURCES = ["abi.hip", "energy_kernels.hip", "ring_kernels.hip", "ff_kernel.hip", "egnn_kernel.hip", "egnn_wide_kernel.hip", "egnn_wide_mfma_kernel.hip", "egnn_jvp_kernel.hip", "egnn_vjp_kernel.hip", "egnn_div_kernel.hip", "fk_kernels.hip", "mlp_kernel.hip", "sampler_kernels.hip"]
+SOURCES = ["abi.hip", "energy_kernels.hip", "ring_kernels.hip", "ff_kernel.hip", "egnn_kernel.hip", "egnn_wide_kernel.hip", "egnn_wide_mfma_kernel.hip", "egnn_wide_mfma_jvp_kernel.hip", "egnn_jvp_kernel.hip", "egnn_vjp_kernel.hip", "egnn_div_kernel.hip", "fk_kernels.hip", "mlp_kernel.hip", "sampler_kernels.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          # no implicit FMA contraction: every fused multiply-add is an explicit fmaf, so results are bitwise
@@ -16,6 +16,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", 
 # compiler's default AGPR form) save ~100 v_accvgpr moves per edge there: 16.4 -> 14.8 ms per 65 536 forwards.  (No
 # effect on the other kernels: measured on the debiased and the fused-sampler bench legs.)
 PER_FILE_FLAGS = {"egnn_wide_mfma_kernel.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+                  "egnn_wide_mfma_jvp_kernel.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                   # reverse-mode kernel (one wave per SIMD, resident weight fragments parked in AGPRs): 5.74 -> 5.22 ms
                   "egnn_vjp_kernel.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 # (egnn_div_kernel.hip: the same treatment gained 4 % on the LJ55 trace, nothing on LJ13, and ONE instantiation --

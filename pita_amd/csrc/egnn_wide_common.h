@@ -19,6 +19,9 @@ struct pita_egnn_wide {
   void* d_bk = nullptr;
   size_t bk_bytes = 0;
   int* d_flag = nullptr;  // set by the matrix-pipe kernel when a walker comes out non-finite: the repair pass returns at once otherwise
+  int* d_jbad = nullptr;    // [B] flags of the matrix-pipe forward-mode kernel (walkers left to the vector-pipe kernel)
+  size_t jbad_bytes = 0;
+  bool jvp64_attr = false;  // dynamic-LDS opt-in of the matrix-pipe forward-mode kernel done
   bool vec_attr[2] = {false, false};  // dynamic-LDS opt-in of the vector-pipe kernel done (evaluation / sampler instantiation)
 };
 
@@ -32,5 +35,10 @@ int wide64_launch(pita_egnn_wide* net, int what, const float* t, const float* x,
 int wide64_sampler(pita_egnn_wide* net, float* x, long long B, const float* step_tab, int n_steps, const float* noise,
                    unsigned long long seed, unsigned long long walker_offset, long long step0, int remove_mean,
                    double* stats_out, int* bad_from, hipStream_t stream);
+// forward-mode derivative on the matrix pipe (egnn_wide_mfma_jvp_kernel.hip); returns 1 when the particle system has no
+// instantiation; bad: device [B] ints, zeroed by the caller, set to 1 for walkers left to the vector-pipe kernel
+int wide64_jvp(pita_egnn_wide* net, const float* h, const float* x, const float* beta, const float* vx, int dir,
+               const float* vh, float* out, float* dout, float* dot_out, long long dot_stride, long long dot_off,
+               float* diag_acc, int* bad, long long B, hipStream_t stream);
 void wide64_release(pita_egnn_wide* net);
 }  // namespace pita

@@ -370,6 +370,7 @@ struct WideJvpParams {
   float* dot_out;        // nullable: dot_out[b * dot_stride + dot_off] = <x_b, dD_b>
   long long dot_stride, dot_off;
   float* diag_acc;       // nullable: diag_acc[b] += dD[b, dir]
+  const int* only_bad;   // nullable [B]: process only the walkers the matrix-pipe kernel flagged (egnn_wide_mfma_jvp_kernel.hip)
 };
 
 namespace {
@@ -459,6 +460,7 @@ __global__ void __launch_bounds__(256) egnn_wide_jvp_kernel(WideJvpParams q) {
   float* bc = dposn + n * 4;             // [2][64] broadcast slots (primal, tangent) of the dense layers
   const long long nw = (long long)gridDim.x * waves;
   for (long long w = (long long)blockIdx.x * waves + wave; w < p.B; w += nw) {
+    if (q.only_bad && q.only_bad[w] == 0) continue;  // wave-uniform
     const float hval = p.t[w];
     const float bet = p.has_beta ? p.beta[w] : 0.f;
     const float vh = q.vh ? q.vh[w] : 0.f;
@@ -806,12 +808,36 @@ extern "C" int pita_egnn_wide_jvp(pita_egnn_wide_t* net, const float* h, const f
   p.B = B; p.mode = 1; p.x = x; p.t = h; p.beta = beta; p.out = out;
   q.vx = vx; q.vh = vh; q.dir = vx ? -1 : dir; q.dout = dout; q.dot_out = dot_out; q.dot_stride = dot_stride;
   q.dot_off = dot_off; q.diag_acc = diag_acc;
+  int rc = PITA_OK;
+  // matrix-pipe kernel first where the particle system has one (PITA_WIDE_NO_MFMA: the vector-pipe kernel alone); it
+  // flags the walkers whose primal or tangent left the f16 range and the vector-pipe kernel below computes exactly those
+  if (pita_egnn_wide_uses_matrix_pipe(net)) {
+    const size_t need = sizeof(int) * (size_t)B;
+    if (need > net->jbad_bytes) {
+      hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+      (void)hipFree(net->d_jbad);
+      net->d_jbad = nullptr;
+      net->jbad_bytes = 0;
+      if (e == hipSuccess) e = hipMalloc(&net->d_jbad, need);
+      if (e != hipSuccess) rc = fail(PITA_EHIP, "pita_egnn_wide_jvp: flag buffer: %s", hipGetErrorString(e));
+      else net->jbad_bytes = need;
+    }
+    if (rc == PITA_OK && hipMemsetAsync(net->d_jbad, 0, need, (hipStream_t)stream) != hipSuccess)
+      rc = fail(PITA_EHIP, "pita_egnn_wide_jvp: memset failed");
+    if (rc == PITA_OK) {
+      const int r64 = wide64_jvp(net, h, x, beta, vx, dir, vh, out, dout, dot_out, dot_stride, dot_off, diag_acc, net->d_jbad,
+                                 B, (hipStream_t)stream);
+      if (r64 == PITA_OK) q.only_bad = net->d_jbad;
+      else if (r64 != 1) rc = r64;
+    }
+  }
   const size_t per_wave = sizeof(float) * (size_t)(5 * p.n * WIDE_HP + 6 * p.n * 4 + 2 * WIDE_HP);
   int waves = 4;
   while (waves > 1 && per_wave * waves > 150 * 1024) waves >>= 1;
   auto kernel = p.H <= 32 ? egnn_wide_jvp_kernel<32> : egnn_wide_jvp_kernel<64>;
-  int rc = PITA_OK;
-  if (per_wave * waves > 150 * 1024) {
+  
+  if (rc != PITA_OK) {
+  } else if (per_wave * waves > 150 * 1024) {
     rc = fail(PITA_EUNSUPPORTED, "pita_egnn_wide_jvp: %d particles need %zu B of LDS per wave", p.n, per_wave);
   } else if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(per_wave * waves)) != hipSuccess) {

@@ -356,8 +356,9 @@ def test_egnn_ad2cat_golden(pa, golden, tag, L, tanh, att):
 
 
 @pytest.mark.parametrize("tag,L,tanh,att", [("h64", 5, True, True), ("h48", 2, False, False)])
-def test_egnn_ad2cat_forward_mode_vs_oracle_jacobian(pa, golden, tag, L, tanh, att):
-    """pita_egnn_wide_jvp (forward mode through EGNN_dynamics_AD2_cat, hidden 64 x 5 and the padded hidden-48 net) on the
+def test_egnn_ad2cat_forward_mode_vs_oracle_jacobian(pa, golden, tag, L, tanh, att, monkeypatch):
+    """pita_egnn_wide_jvp (forward mode through EGNN_dynamics_AD2_cat, hidden 64 x 5 and the padded hidden-48 net; 22 atoms:
+    the matrix-pipe kernel egnn_wide64_jvp_kernel with the vector-pipe kernel as its out-of-range repair) on the
     inputs of the reference golden: the denoiser, J_x D e_k for unit directions, J_x D v for a dense direction, dD/dh, the
     in-kernel reductions <x, dD> and the diagonal accumulator -- against vmap(jacrev) of the fp64 oracle (the reference's
     utils.py:30-51 on its own module), rel 5e-5 like the h32 kernels."""
@@ -404,6 +405,24 @@ def test_egnn_ad2cat_forward_mode_vs_oracle_jacobian(pa, golden, tag, L, tanh, a
                                atol=2e-4 * float((x.double() * want).sum(-1).abs().mean()))
     _, dh = net.jvp(hc, xc, bc, direction=-1, vh=torch.ones(B).cuda(), want_primal=False)
     assert rel(dh, Jh) < 5e-5
+    # the two kernels behind pita_egnn_wide_jvp: the matrix-pipe kernel (22 atoms; f16 two-piece split) served the calls
+    # above; the fp32 vector-pipe kernel alone (PITA_WIDE_NO_MFMA) agrees to rounding, and takes over -- bit for bit --
+    # exactly the walkers whose activations leave the f16 range (beta = 1e7), their neighbours untouched
+    assert net.uses_matrix_pipe("cuda:0")
+    _, dm = net.jvp(hc, xc, bc, direction=7, want_primal=False)
+    bhot = bc.clone()
+    bhot[1] = 1.0e7
+    _, dm_hot = net.jvp(hc, xc, bhot, direction=7, want_primal=False)
+    monkeypatch.setenv("PITA_WIDE_NO_MFMA", "1")
+    try:
+        _, dv = net.jvp(hc, xc, bc, direction=7, want_primal=False)
+        _, dv_hot = net.jvp(hc, xc, bhot, direction=7, want_primal=False)
+    finally:
+        monkeypatch.delenv("PITA_WIDE_NO_MFMA")
+    assert rel(dm, dv) < 5e-6 and not torch.equal(dm, dv)
+    assert torch.equal(dm_hot[1].view(torch.int32), dv_hot[1].view(torch.int32))
+    keep = torch.arange(B) != 1
+    assert torch.equal(dm_hot[keep], dm[keep])
     # batch edges: empty batch; more walkers than resident waves give the same bits per walker
     assert net.jvp(hc[:0], xc[:0], bc[:0], direction=3)[1].shape == (0, 66)
     reps = 400
