@@ -629,12 +629,30 @@ def main():
         net64.sampler_run(xa, tab64, 50, seed=seed, walker_offset=rank * B, step0=2, remove_mean=True)
         torch.cuda.synchronize()
         dt64 = (time.perf_counter() - t0) / 50
+        # the debiased (Feynman-Kac) regime with this backbone as score AND energy net: 2 x (dim + 1) forward-mode
+        # launches per step (pita_egnn_wide_jvp: matrix-pipe kernel for 22 atoms), assembly, clamp
+        import copy as _copy
+
+        from pita_amd.energy_net import EnergyNet as _EnergyNet
+
+        sde64 = pita_amd.VEReverseSDE(noise_schedule=sched, score_net=sn64, energy_net=_EnergyNet(_copy.deepcopy(net64)),
+                                      debias_inference=True)
+        xd = pita_amd.Prior(scale=3.0, n_particles=n, spatial_dim=d, device=dev, seed=7).sample(B)
+        td = torch.tensor(0.5, device=dev)
+        sde64.f(td, xd, 1.0, gam, None, None, clamp_chunk=512)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sde64.f(td, xd, 1.0, gam, None, None, clamp_chunk=512)
+        torch.cuda.synchronize()
+        dt64_deb = time.perf_counter() - t0
         mac = 5 * (n * (n - 1) * ((2 * 64 + 2) * 64 + 2 * 64 * 64 + 2 * 64) + n * 3 * 64 * 64)
         on_mfma = net64.uses_matrix_pipe(dev)
         ad2cat = {"backbone": "EGNN_dynamics_AD2_cat hidden 64 x 5 layers (pita_egnn_wide_sampler_run: 50 steps per launch, "
                               + ("f16 two-piece MFMA, matrix pipe)" if on_mfma else "fp32 vector pipe)"),
                   "walkers": B, "ms_per_step": dt64 * 1e3, "value": B / dt64, "unit": "walker-steps/s",
                   "ms_per_step_launch_per_step_path": dt64_steps * 1e3,
+                  "debiased": {"ms_per_step": dt64_deb * 1e3, "value": B / dt64_deb, "unit": "walker-steps/s",
+                               "launches_per_step": f"2 x {n * d + 1} forward-mode launches (pita_egnn_wide_jvp) + assembly + clamp"},
                   "algorithmic_TFLOPs": 2 * mac * B / dt64 / 1e12,
                   ("frac_of_dense_f16_mfma_peak_2500" if on_mfma else "frac_of_plain_fma_rate_78.6"):
                       2 * mac * B / dt64 / (2500e12 if on_mfma else 78.65e12),
