@@ -580,6 +580,21 @@ def test_egnn_aldp_golden(pa, golden):
         assert err_hip < max(4 * err_ref, 2e-6) and rel(F, g[f"F_{tag}"]) < max(2e-5, 6 * err_ref)
         if H == 64:
             assert net.uses_matrix_pipe("cuda:0")
+        if n == 22:  # forward mode through this class too (no gate, no tanh: the other instantiation of the JVP kernels)
+            from torch.func import jacrev, vmap
+
+            hq = torch.tensor([0.05, 0.7, 3.0, 40.0])
+            xq = T(g[f"x_{tag}"][:4]) * (1 + hq.sqrt())[:, None]
+            bq = T(g[f"beta_{tag}"][:4])
+            bb = lambda cn, xs, b: O.egnn_ad2_cat_forward(wd, cn, xs, b, n, 3, h_initial=O.egnn_aldp_h_initial(n).double(), **kw)
+            one = lambda hh, xx, b: O.denoiser(bb, hh[None], xx[None], b[None])[0]
+            J = vmap(jacrev(one, argnums=1))(hq.double(), xq.double(), bq.double())
+            acc = torch.zeros(4, device="cuda")
+            for k in (0, 17, 40, 65):
+                _, dk = net.jvp(hq.cuda(), xq.cuda(), bq.cuda(), direction=k, want_primal=False, diag_acc=acc)
+                assert rel(dk, J[:, :, k]) < 5e-5, k
+            want = sum(J[:, k, k] for k in (0, 17, 40, 65))
+            np.testing.assert_allclose(acc.cpu().numpy(), want.numpy(), rtol=5e-5, atol=5e-5 * float(want.abs().mean() + 1))
     plain = EGNN_dynamics(22, 3)  # not temperature conditioned: beta is accepted and ignored, like the reference's forward
     xs = cu(g["x_n22"])
     assert torch.equal(plain(cu(g["t_n22"]), xs, cu(g["beta_n22"])), plain(cu(g["t_n22"]), xs, None))
