@@ -600,6 +600,60 @@ def test_egnn_aldp_golden(pa, golden):
     assert torch.equal(plain(cu(g["t_n22"]), xs, cu(g["beta_n22"])), plain(cu(g["t_n22"]), xs, None))
 
 
+def test_default_regime_end_to_end_on_the_ad2cat_backbone(pa, golden):
+    """integrate_sde with the reference's default regime on the alanine-dipeptide backbone end to end: debiased drift
+    (forward-mode launches), an event after every step, two clamp chunks, resample_at_end (EnergyNet.forward_energy on
+    the wide net) -- against the oracle's integrator on the same noise and uniforms: parent counts, log-weights and
+    walkers after 3 steps."""
+    import copy
+
+    from pita_amd.egnn_dynamics_ad2_cat import EGNN_dynamics_AD2_cat
+    from pita_amd.energy_net import EnergyNet
+
+    g = golden("egnn_ad2cat_h64_fwd.npz")
+    w = {k[2:]: T(v) for k, v in g.items() if k.startswith("w.")}
+    net = EGNN_dynamics_AD2_cat(22, 3, hidden_nf=64, n_layers=5, tanh=True, attention=True, condition_beta=True)
+    net.load_state_dict(w)
+    sched = pa.ElucidatingNoiseSchedule(sigma_min=0.01, sigma_max=80.0, rho=7)
+    sde = pa.VEReverseSDE(noise_schedule=sched, score_net=pa.ScoreNet(net), energy_net=EnergyNet(copy.deepcopy(net)),
+                          debias_inference=True)
+    gam = pa.ConstantAnnealingFactorSchedule(4 / 3)
+    N, B, chunk = 3, 4, 2
+    gen = torch.Generator().manual_seed(31)
+    x1 = O.remove_mean(torch.randn(B, 66, generator=gen) * 2.0, 22, 3)
+    noise = torch.randn(N, B, 66, generator=gen)
+    us = [0.21, 0.77, 0.48]
+
+    class Target:  # a cheap analytic target with the energy-function interface (harmonic well)
+        n_particles, n_spatial_dim, is_molecule = 22, 3, True
+
+        def __call__(self, x, return_force=False):
+            lp = -0.5 * (x * x).sum(-1)
+            return (lp, -x) if return_force else lp
+
+    integ = pa.WeightedSDEIntegrator(sde=sde, num_integration_steps=N, start_resampling_step=0, end_resampling_step=2,
+                                     resampling_interval=1, num_negative_time_steps=0, post_mcmc_steps=0, batch_size=chunk,
+                                     resample_at_end=True, time_range=0.3)
+    x, logw, uniq, terms, _ = integ.integrate_sde(x1.cuda(), Target(), gam, inverse_temperature=1.25, noise=noise.cuda(),
+                                                  resample_u=us)
+    wd = {k: v.double() for k, v in w.items()}
+    bb = lambda cn, xs, b: O.egnn_ad2_cat_forward(wd, cn, xs, b, 22, 3, n_layers=5, tanh=True, attention=True)
+    osched, ogam = O.Elucidating(0.01, 80.0, 7), O.GammaConstant(4 / 3)
+    cfg = O.IntegratorConfig(num_integration_steps=N, start_resampling_step=0, end_resampling_step=2, resampling_interval=1,
+                             batch_size=chunk, time_range=0.3)
+    drift = lambda t, xc: O.f_debiased(bb, bb, osched, ogam, t, xc, 1.25)
+    ref = O.integrate_sde(cfg, x1.double(), drift, osched.g, lambda i, shp: noise[i // 2][(i % 2) * chunk:(i % 2 + 1) * chunk].double(),
+                          22, 3, uniform_fn=lambda s_: us[s_])
+    t_end = torch.linspace(0.3, 0.0, N + 1)[:-1][2].double()
+    xr, a_next, nu = O.resample_at_end(ref["x"], ref["logweights"][-1], t_end, lambda xx: -0.5 * (xx * xx).sum(-1),
+                                       lambda tb, xx: O.energy_theta(bb, osched.h(tb), xx, 1.25), 4 / 3, us[2])
+    assert uniq[:N] == ref["num_unique"] and uniq[N] == nu
+    np.testing.assert_allclose(logw[:N].cpu().numpy(), ref["logweights"].numpy(), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(logw[N].cpu().numpy(), a_next.numpy(), rtol=2e-3, atol=2e-3 * float(a_next.abs().mean()))
+    assert rel(x, xr) < 2e-3
+    assert len(terms) == N
+
+
 @pytest.mark.parametrize("n", [13, 22, 33, 42, 55])
 def test_egnn_ad2cat_other_particle_counts(pa, n, monkeypatch):
     """Every instantiation of the matrix-pipe kernel -- the particle counts EGNN_dynamics_AD2_cat knows node features for
