@@ -1268,7 +1268,10 @@ struct DivShrCfg {
   static constexpr int POS_F = NCOLP * DIM;
   static constexpr int WAVE_F = K * PB_F + 3 * K * POS_F;   // dPB[K]; dpos[K][2], dpos0[K]
   static constexpr int RES_G = 32;                           // groups between result flushes
-  static constexpr int MAX_P = 128 * NW;                     // pieces of one group's sequence (two table registers per wave)
+  // piece table of one group's sequence: one entry per piece, or -- systems whose sequence is longer (LJ55: 189 items)
+  // -- two words per ITEM (every item is [weight pieces | cache pieces | padding]: first piece and count of each run)
+  static constexpr bool COMPACT = NT * (N - 1) > 48;
+  static constexpr int MAX_P = COMPACT ? 768 : 128 * NW;
   // pos, pos0; c_s, cc; comb; res, walker0; piece table (+ count)
   static constexpr int SHARED_F = 2 * POS_F + 2 * NCOLP + NW * G + RES_G * G + RES_G + MAX_P + 4;
   static constexpr int LMAX = SHR_LMAX;
@@ -1356,40 +1359,58 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
   const size_t group_f = CA::group_f(L);
   if (threadIdx.x == 0) {  // the pieces of one group's sweep, item by item (every item padded to S pieces)
     int np = 0;
-    auto add = [&](int kind, long long first_piece, int n) {
-      for (int q = 0; q < n && np < C::MAX_P; ++q) ptab[np++] = (int)((kind ? 0x80000000u : 0u) | (unsigned)(first_piece + q));
+    auto add = [&](int kind, long long first_piece, int n) {  // kind 0: cache, 1: weight blocks, 2: padding (re-reads weight piece 0)
+      if constexpr (C::COMPACT) {
+        if (kind == 0 && n > 0 && np + 1 < C::MAX_P) ptab[np + 1] = (int)(((unsigned)n << 26) | (unsigned)first_piece);
+        if (kind == 1 && n > 0 && np < C::MAX_P) ptab[np] = (int)(((unsigned)n << 24) | (unsigned)first_piece);
+      } else {
+        for (int q = 0; q < n && np < C::MAX_P; ++q) ptab[np++] = (int)((kind ? 0x80000000u : 0u) | (unsigned)(first_piece + q));
+      }
+    };
+    auto open_item = [&]() {
+      if constexpr (C::COMPACT)
+        if (np + 1 < C::MAX_P) { ptab[np] = 0; ptab[np + 1] = 0; }
+    };
+    auto close_item = [&]() {
+      if constexpr (C::COMPACT) np += 2;
     };
     for (int l = 0; l < L; ++l) {
       const bool first = (l == 0), last = (l == L - 1) && !first;
       int n = 0;
+      open_item();
       if (!first) {  // Wa, Wb[, W2]: consecutive blocks of the layer's matrices
         n = last ? 8 : 12;
         add(1, ((long long)l * M_COUNT + M_WA) * 4, n);
       }
       const long long lo = (long long)(CA::layer_off(l, L) / 256);
       add(0, lo, CA::POSF / 256);
-      add(1, 0, S - n - CA::POSF / 256);
+      add(2, 0, S - n - CA::POSF / 256);
+      close_item();
       const int ep = (int)(CA::edge_f(l, L) / 256), epi = S / ep;
       for (int T = 0; T < NT; ++T) {
         const long long to = lo + CA::POSF / 256 + (long long)T * (long long)(CA::tile_f(l, L) / 256);
         for (int q = 0; q < N - 1; q += epi) {
           const int nrec = (N - 1 - q) < epi ? (N - 1 - q) : epi;
+          open_item();
           add(0, to + (long long)q * ep, nrec * ep);
-          add(1, 0, S - nrec * ep);
+          add(2, 0, S - nrec * ep);
+          close_item();
         }
         n = 0;
+        open_item();
         if (l != L - 1) {  // [Wn1a,] Wn1b, Wn2
           n = first ? 8 : 12;
           add(1, ((long long)l * M_COUNT + (first ? M_WN1B : M_WN1A)) * 4, n);
         }
         add(0, to + (long long)(CA::gn_off(l, L) / 256), 4);
-        add(1, 0, S - n - 4);
+        add(2, 0, S - n - 4);
+        close_item();
       }
     }
     ptab[C::MAX_P] = np;
   }
   __syncthreads();
-  const int IPG = ptab[C::MAX_P] / S;  // items per group (host: fits MAX_P)
+  const int IPG = ptab[C::MAX_P] / (C::COMPACT ? 2 : S);  // items per group (host: fits MAX_P)
   const int ngroups_i = (int)total_groups, gpw_i = (int)gpw, nblk = (int)gridDim.x;  // host: total_groups < 2^31
   auto group_walkers = [&](int g, long long& w0) -> int {
     const int wg = g / gpw_i, lg = g - wg * gpw_i;
@@ -1417,7 +1438,15 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
     if (rgrp >= ngroups_i) return;
     const int d = wave - rt;
     if ((unsigned)d < (unsigned)D) {
-      const int ents = ptab[ri * S + d * PPW + (lane < PPW ? lane : 0)];
+      int ents;
+      if constexpr (C::COMPACT) {
+        const unsigned ew = (unsigned)ptab[2 * ri], ec = (unsigned)ptab[2 * ri + 1];
+        const int nw_ = (int)(ew >> 24), nc_ = (int)(ec >> 26), q = d * PPW + (lane < PPW ? lane : 0);
+        ents = q < nw_ ? (int)(0x80000000u | ((ew & 0xffffffu) + (unsigned)q))
+                       : (q < nw_ + nc_ ? (int)((ec & 0x3ffffffu) + (unsigned)(q - nw_)) : (int)0x80000000u);
+      } else {
+        ents = ptab[ri * S + d * PPW + (lane < PPW ? lane : 0)];
+      }
       const unsigned dst = ring_byte + (unsigned)(rs * S + d * PPW) * 1024u;
 #pragma unroll
       for (int q = 0; q < PPW; ++q) {
@@ -1865,7 +1894,7 @@ static bool divshr_fits(int L) {
     const int epi = SHR_S / (int)(CA::edge_f(l, L) / 256);
     items += 1 + (long long)C::NT * ((N - 1 + epi - 1) / epi + 1);
   }
-  return items * SHR_S <= C::MAX_P;
+  return items * (C::COMPACT ? 2 : SHR_S) <= C::MAX_P;
 }
 template <int N, int DIM, int G, int NW, int K>
 static size_t divshr_lds_of(int L) { return DivShrCfg<N, DIM, G, NW, K>::lds_bytes(L); }
@@ -1887,28 +1916,29 @@ static const DivTanShape kDivTan[] = {
     PITA_DIVTAN_SHAPE(4, 2, 8, 4, 5),
     PITA_DIVSHR_SHAPE(13, 3, 2, 8, 2),
     PITA_DIVSHR_SHAPE(22, 3, 1, 8, 2),
-    PITA_DIVTAN_SHAPE(55, 3, 1, 4, 3),
+    PITA_DIVSHR_SHAPE(55, 3, 1, 8, 1),
 };
 // wave-owned kernels for the systems above that default to the block-shared one (networks deeper than its LDS budget
 // is sized for; PITA_DIV_TAN_ALT=1 selects them for A/B runs), then experiments (PITA_DIV_TAN_ALT=<index + 1>)
+constexpr int kDivTanOwned = 3;  // the first kDivTanOwned entries are the wave-owned fallbacks
 static const DivTanShape kDivTanAlt[] = {PITA_DIVTAN_SHAPE(13, 3, 2, 4, 4), PITA_DIVTAN_SHAPE(22, 3, 1, 4, 4),
-                                         PITA_DIVSHR_SHAPE(13, 3, 2, 12, 1)};
+                                         PITA_DIVTAN_SHAPE(55, 3, 1, 4, 3), PITA_DIVSHR_SHAPE(13, 3, 2, 12, 1)};
 static const DivTanShape* find_div_tan_shape(int n, int dim, int n_layers) {
   static const bool off = getenv("PITA_DIV_NOCACHE") != nullptr;  // development aid: A/B against the cache-free path
   if (off) return nullptr;
   static const int alt = getenv("PITA_DIV_TAN_ALT") ? atoi(getenv("PITA_DIV_TAN_ALT")) : 0;
   const int nalt = (int)(sizeof(kDivTanAlt) / sizeof(kDivTanAlt[0]));
   if (alt == 1) {
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < kDivTanOwned; ++i)
       if (kDivTanAlt[i].n == n && kDivTanAlt[i].dim == dim) return &kDivTanAlt[i];
-  } else if (alt >= 2 && alt <= nalt) {
+  } else if (alt > kDivTanOwned && alt <= nalt) {
     const auto& c = kDivTanAlt[alt - 1];
     if (c.n == n && c.dim == dim && (!c.shared || c.fits(n_layers))) return &c;
   }
   for (const auto& c : kDivTan)
     if (c.n == n && c.dim == dim) {
       if (!c.shared || c.fits(n_layers)) return &c;
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < kDivTanOwned; ++i)
         if (kDivTanAlt[i].n == n && kDivTanAlt[i].dim == dim) return &kDivTanAlt[i];
       return nullptr;
     }

@@ -1662,7 +1662,7 @@ def test_jacobian_trace_multi_direction(pa, golden):
             np.testing.assert_allclose(tr.cpu().numpy(), want.numpy(), rtol=5e-5, atol=5e-5 * scale)
 
 
-@pytest.mark.parametrize("n,B", [(13, 40003), (22, 4099)])
+@pytest.mark.parametrize("n,B", [(13, 40003), (22, 4099), (55, 1031)])
 def test_jacobian_trace_large_batches_block_shared_stream(pa, golden, n, B):
     """At production batch sizes every block of the block-shared tangent kernel sweeps MANY walker groups: the LDS ring
     wraps thousands of times, the parked results are flushed every 32 groups, the last group of a wave's quota is ragged.
