@@ -406,7 +406,9 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_kernel(DivParams p) {
 // ≈180 KB per walker (12 GB at 65 536 walkers: HBM capacity is what this GPU has to spare), streamed once per launch in
 // 1 KB wave-loads.  Layout per walker group g (a wave's G walkers) and layer l, in floats:
 //   [pos: POSF] then per tile T: [edge dd = 1..N-1: nv(l) x 1024 vectors | 8 x 64 scalars] [gn: 1024]
-// scalar slots: 0 cs, 1 dcs_f (incl. the tangent scales), 2 att, 3 att (1 - att), 4 vcdmu | qr, 5 qe.  The position
+// scalar slots: 0 cs, 1 dcs_f (incl. the tangent scales), 2 att, 3 att (1 - att), 4 vcdmu | qr, 5 qe.  Middle-layer
+// records (round 4): vector 1 is att (g2 o .) -- the gate folded into the cached SiLU derivative --, slot 3 is 1 - att,
+// and slots 4..7 hold the edge's geometry as [column 32][df[3], inv, e0[3], hsq] so that no tangent wave recomputes it.  The position
 // block carries, behind the NT x 32 x DIM positions, c_skip and c_out c_in of every column (layer 0's block is the one
 // read).  Every item is a whole number of 1 KB chunks and a group's items lie in the order the tangent sweep consumes
 // them, so the block-shared tangent kernel can stream a group as plain 1 KB pieces.
@@ -726,7 +728,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) egnn_div_fast_kernel(DivParam
             cscal[lane] = cs;
             cscal[64 + lane] = dcs_f;
             cscal[128 + lane] = att;
-            cscal[192 + lane] = datt_f;
+            cscal[192 + lane] = (first || last) ? datt_f : (p.attention ? 1.0f - att : 0.0f);  // middle: the gate rides in g2
           }
           float dcs[K];
           if (first) {
@@ -780,9 +782,16 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) egnn_div_fast_kernel(DivParam
             const f32x16 g2s = g2 * F16_UNSCALE;
             if (crec) {
               cache_store16(crec, lane, g1);
-              cache_store16(crec + 1024, lane, g2s);
+              cache_store16(crec + 1024, lane, g2s * att);  // dm2 arrives gated: att (g2 o W2 dm1)
               cache_store16(crec + 2048, lane, m2);
               cache_store16(crec + 3072, lane, vc);
+              // the edge's geometry, once for every wave and direction that streams this record: [column][df | inv ||
+              // e0 | hsq] in the four scalar slots the middle layers leave free
+              f32x4 gq = {0.f, 0.f, 0.f, hh ? hsq : inv};
+              gq.x = hh ? e0[0] : df[0];
+              gq.y = hh ? e0[1] : df[1];
+              if (DIM > 2) gq.z = hh ? e0[DIM > 2 ? 2 : 0] : df[DIM > 2 ? 2 : 0];
+              *reinterpret_cast<f32x4*>(cscal + 256 + cl * 8 + hh * 4) = gq;
             }
 #pragma unroll
             for (int d = 0; d < K; ++d) {
@@ -1075,15 +1084,27 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_tangent_kernel(DivPara
           const float* crec = ctile + (size_t)(dd - 1) * CA::edge_f(l, L);
           const float* cscal = crec + (size_t)CA::nvec(l, L) * 1024;
           const float cs = cscal[lane], dcs_f = cscal[64 + lane];
-          float df[DIM], e0[DIM], radial = 0.f;
+          float df[DIM], e0[DIM], inv, hsq;
+          if (!first && !last) {  // middle-layer records carry the edge's geometry
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(cscal + 256 + cl * 8);
+            const f32x4 gb = *reinterpret_cast<const f32x4*>(cscal + 256 + cl * 8 + 4);
+            df[0] = ga.x; e0[0] = gb.x;
+            df[1] = ga.y; e0[1] = gb.y;
+            if constexpr (DIM > 2) { df[DIM - 1] = ga.z; e0[DIM - 1] = gb.z; }
+            inv = ga.w;
+            hsq = gb.w;
+          } else {
+            float radial = 0.f;
 #pragma unroll
-          for (int k = 0; k < DIM; ++k) {
-            df[k] = pown[k] - posc[cj * DIM + k];
-            radial = fmaf(df[k], df[k], radial);
-            e0[k] = p0own[k] - pos0[cj * DIM + k];
+            for (int k = 0; k < DIM; ++k) {
+              df[k] = pown[k] - posc[cj * DIM + k];
+              radial = fmaf(df[k], df[k], radial);
+              e0[k] = p0own[k] - pos0[cj * DIM + k];
+            }
+            const float sq = __builtin_amdgcn_sqrtf(radial + 1e-8f);
+            inv = __builtin_amdgcn_rcpf(sq + 1.0f);
+            hsq = 0.5f * __builtin_amdgcn_rcpf(sq);
           }
-          const float sq = __builtin_amdgcn_sqrtf(radial + 1e-8f), inv = __builtin_amdgcn_rcpf(sq + 1.0f);
-          const float hsq = 0.5f * __builtin_amdgcn_rcpf(sq);
           float u[DIM];
 #pragma unroll
           for (int k = 0; k < DIM; ++k) u[k] = df[k] * inv;
@@ -1125,7 +1146,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_tangent_kernel(DivPara
           } else {
             const f32x16 g1 = cache_load16(crec, lane), g2s = cache_load16(crec + 1024, lane);
             const f32x16 m2 = cache_load16(crec + 2048, lane), vc = cache_load16(crec + 3072, lane);
-            const float att = cscal[128 + lane], datt_f = cscal[192 + lane];
+            const float datt_f = cscal[192 + lane];  // 1 - att: the record's g2 carries the gate
             const f32x16 v_watt = lds_vec16(lds + VEC_EMB_F + l * VEC_LAYER_F + hh * 16 + V_WATT * EH);
 #pragma unroll
             for (int d = 0; d < K; ++d) {
@@ -1133,8 +1154,8 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_tangent_kernel(DivPara
               dz = __builtin_amdgcn_mfma_f32_32x32x2f32(a_re, DIV_ST * (hh ? dea[d] : dradial[d]), dz, 0, 0, 0);
               dz *= g1;
               dz = w2f.mul(dz, zero16);
-              dz *= g2s;  // dm2
-              f32x16 dm = dz * att;
+              dz *= g2s;  // att dm2
+              f32x16 dm = dz;
               if (p.attention) {
                 const float datt = datt_f * xhalf_sum(dot16(v_watt, dz));
 #pragma unroll
@@ -1606,15 +1627,27 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
             const int cj = (col[T] < ncol) ? cbase + j : col[T];
             const float* sc = rec + nv * 1024;
             const float cs = sc[lane], dcs_f = sc[64 + lane];
-            float df[DIM], e0[DIM], radial = 0.f;
+            float df[DIM], e0[DIM], inv, hsq;
+            if constexpr (KIND == 1) {  // middle-layer records carry the edge's geometry (written once by the primal launch)
+              const f32x4 ga = *reinterpret_cast<const f32x4*>(sc + 256 + cl * 8);
+              const f32x4 gb = *reinterpret_cast<const f32x4*>(sc + 256 + cl * 8 + 4);
+              df[0] = ga.x; e0[0] = gb.x;
+              df[1] = ga.y; e0[1] = gb.y;
+              if constexpr (DIM > 2) { df[DIM - 1] = ga.z; e0[DIM - 1] = gb.z; }
+              inv = ga.w;
+              hsq = gb.w;
+            } else {
+              float radial = 0.f;
 #pragma unroll
-            for (int k = 0; k < DIM; ++k) {
-              df[k] = posc[col[T] * DIM + k] - posc[cj * DIM + k];
-              radial = fmaf(df[k], df[k], radial);
-              e0[k] = pos0[col[T] * DIM + k] - pos0[cj * DIM + k];
+              for (int k = 0; k < DIM; ++k) {
+                df[k] = posc[col[T] * DIM + k] - posc[cj * DIM + k];
+                radial = fmaf(df[k], df[k], radial);
+                e0[k] = pos0[col[T] * DIM + k] - pos0[cj * DIM + k];
+              }
+              const float sq = __builtin_amdgcn_sqrtf(radial + 1e-8f);
+              inv = __builtin_amdgcn_rcpf(sq + 1.0f);
+              hsq = 0.5f * __builtin_amdgcn_rcpf(sq);
             }
-            const float sq = __builtin_amdgcn_sqrtf(radial + 1e-8f), inv = __builtin_amdgcn_rcpf(sq + 1.0f);
-            const float hsq = 0.5f * __builtin_amdgcn_rcpf(sq);
             float u[DIM];
 #pragma unroll
             for (int k = 0; k < DIM; ++k) u[k] = df[k] * inv;
@@ -1654,7 +1687,7 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
                 dcs[d] = dcs_f * fmaf(qr, dradial[d], fmaf(qe, dea[d], sdot));
               }
             } else {
-              const float att = sc[128 + lane], datt_f = sc[192 + lane];
+              const float datt_f = sc[192 + lane];  // 1 - att: the record's g2 carries the gate
               const float* wattp = vecs + VEC_EMB_F + l * VEC_LAYER_F + hh * 16 + V_WATT * EH;
               // the K chains side by side: each record vector is read from the ring once, the chains' matrix
               // instructions and LDS latencies overlap
@@ -1676,7 +1709,7 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
               {
                 const f32x16 g2s = slot_vec16(rec, 1, lane);
 #pragma unroll
-                for (int d = 0; d < K; ++d) dz[d] *= g2s;  // dm2
+                for (int d = 0; d < K; ++d) dz[d] *= g2s;  // att dm2: dm without the gate's own tangent
               }
               float datt[K];
               if (p.attention) {
@@ -1684,8 +1717,6 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
 #pragma unroll
                 for (int d = 0; d < K; ++d) datt[d] = datt_f * xhalf_sum(dot16(v_watt, dz[d]));
               }
-#pragma unroll
-              for (int d = 0; d < K; ++d) dz[d] *= att;  // dm without the gate's own tangent
               if (p.attention) {
                 const f32x16 m2 = slot_vec16(rec, 2, lane);
 #pragma unroll
