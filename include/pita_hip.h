@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PITA_ABI_VERSION 6
+#define PITA_ABI_VERSION 7
 
 enum {
   PITA_OK = 0,
@@ -167,6 +167,15 @@ int pita_egnn_wide_jvp(pita_egnn_wide_t* net, const float* h, const float* x, co
                        const float* vx /*nullable*/, int dir, const float* vh /*nullable*/, float* out /*nullable*/,
                        float* dout /*nullable*/, float* dot_out /*nullable*/, int64_t dot_stride, int64_t dot_off,
                        float* diag_acc /*nullable*/, int64_t B, void* stream);
+
+/* Reverse-mode derivative of the same denoiser (arguments as pita_egnn_vjp): vjp = J_x D(h, x)^T cot for a per-walker
+ * cotangent (null: x itself -- grad_x E_theta = ((1 + c_s) x - D - J_x D^T x)/h, which the reference takes from autograd,
+ * pita/src/models/components/energy_net.py:51-62), out = D (nullable), dot_h (nullable) = <cot, dD/dh> (the h-derivative
+ * term of dE_theta/dt, sdes.py:218) -- ONE launch instead of dim + 1 forward-mode launches.  fp32 vector-pipe kernel
+ * with per-layer checkpoints in a handle-owned scratch (csrc/egnn_wide_kernel.hip: egnn_wide_vjp_kernel). */
+int pita_egnn_wide_vjp(pita_egnn_wide_t* net, const float* h, const float* x, const float* beta /*nullable*/,
+                       const float* cot /*nullable*/, float* out /*nullable*/, float* vjp, float* dot_h /*nullable*/,
+                       int64_t B, void* stream);
 
 /* Diagonal Gaussian mixture with equal weights.
  * replaces GMM.__call__ (pita/src/energies/gmm_energy.py:87-90) ->

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpita_hip.so")
 
 STEP_STRIDE = 16
-ABI_VERSION = 6
+ABI_VERSION = 7
 ST_CS, ST_CIN, ST_COUT, ST_CNOISE, ST_H, ST_G2, ST_GAMMA, ST_DT, ST_NOISE_SCALE, ST_SQRT_DT, ST_BETA = range(11)
 
 
@@ -89,6 +89,7 @@ _PROTOS = {
                                            c_int64, c_int, c_void_p, c_void_p]),
     "pita_egnn_wide_jvp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "pita_egnn_wide_vjp": (c_int, [c_void_p] * 8 + [c_int64, c_void_p]),
     "pita_egnn_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "pita_egnn_edm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "pita_egnn_jvp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

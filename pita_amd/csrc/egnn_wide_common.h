@@ -21,6 +21,8 @@ struct pita_egnn_wide {
   int* d_flag = nullptr;  // set by the matrix-pipe kernel when a walker comes out non-finite: the repair pass returns at once otherwise
   int* d_jbad = nullptr;    // [B] flags of the matrix-pipe forward-mode kernel (walkers left to the vector-pipe kernel)
   size_t jbad_bytes = 0;
+  float* d_vjp_ws = nullptr;  // reverse-mode kernel (vector pipe): per-wave checkpoints of the forward sweep
+  size_t vjp_ws_bytes = 0;
   bool jvp64_attr = false;  // dynamic-LDS opt-in of the matrix-pipe forward-mode kernel done
   bool vec_attr[2] = {false, false};  // dynamic-LDS opt-in of the vector-pipe kernel done (evaluation / sampler instantiation)
 };

@@ -33,7 +33,12 @@ struct WideLayer {
   static constexpr int VEC = 7 * MAT;  // then vectors of 64: wr, we, b1, b2, watt, batt (lane 0), bc1, wc2, bn1, bn2
   static constexpr int WR = VEC, WE = VEC + 64, B1 = VEC + 128, B2 = VEC + 192, WATT = VEC + 256, BATT = VEC + 320,
                        BC1 = VEC + 384, WC2 = VEC + 448, BN1 = VEC + 512, BN2 = VEC + 576;
-  static constexpr int SIZE = VEC + 640;
+  // behind the vectors: the same seven matrices in NATURAL order, [f][64]: lane k reads W[f][k] at f*64+k -- the operand
+  // layout of the TRANSPOSED products y_k = sum_f W[f][k] v_f of the reverse-mode kernel (egnn_wide_vjp_kernel)
+  static constexpr int NAT = VEC + 640;
+  static constexpr int WAN = NAT, WBN = NAT + MAT, W2N = NAT + 2 * MAT, WC1N = NAT + 3 * MAT, WN1AN = NAT + 4 * MAT,
+                       WN1BN = NAT + 5 * MAT, WN2N = NAT + 6 * MAT;
+  static constexpr int SIZE = NAT + 7 * MAT;
 };
 constexpr int WIDE_HEAD = 128;  // emb_t[64], emb_beta[64] in front of the layers
 
@@ -613,6 +618,283 @@ __global__ void __launch_bounds__(256) egnn_wide_jvp_kernel(WideJvpParams q) {
 }
 
 }  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+// Reverse mode: vjp = J_x D^T cot for a per-walker cotangent (default: x itself, what grad_x E_theta needs --
+// energy_net.py:51-62 gets it from autograd) and <cot, dD/dh> (the h-derivative term of dE_theta/dt, sdes.py:218) from ONE
+// sweep, instead of dim + 1 forward-mode launches.  Same mapping as the kernels above (one wavefront = one walker, lane =
+// hidden feature).  Forward sweep with per-layer checkpoints (features and positions entering the layer, the node
+// model's pre-activation) in a per-wave global scratch; backward sweep layer by layer: a node's own adjoint sums stay in
+// registers, what an edge sends to its partner j (the W_b path, the position and edge-attribute adjoints) is added into
+// per-wave LDS tables -- edges are swept one at a time by the whole wave, so those read-modify-writes never collide.
+// Every edge is recomputed with its SiLU derivatives; the transposed products read the natural-order weight copies
+// (W2^T and Wc1^T rows in registers beside the forward rows: one wave per SIMD).
+struct WideVjpParams {
+  WideParams base;   // x, t (= h), beta, out (nullable: the denoiser)
+  const float* cot;  // nullable [B, n*dim]: cotangent (null: x)
+  float* vjp;        // [B, n*dim]
+  float* dot_h;      // nullable [B]
+  float* ws;         // checkpoints: [wave slot][L][2 n 64 + n 4]
+};
+
+namespace {
+
+template <int HK>
+__global__ void __launch_bounds__(256, 1) egnn_wide_vjp_kernel(WideVjpParams q) {
+  const WideParams& p = q.base;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = p.n, DIM = p.dim;
+  const int per_wave = 5 * n * WIDE_HP + 6 * n * 4 + WIDE_HP;
+  float* hf = lds + wave * per_wave;     // [n][64] features entering the layer
+  float* At = hf + n * WIDE_HP;          // [n][64] Wa h_i + b1
+  float* Bt = At + n * WIDE_HP;          // [n][64] Wb h_j
+  float* hb = Bt + n * WIDE_HP;          // [n][64] adjoint of the features leaving the layer (then: entering it)
+  float* TB = hb + n * WIDE_HP;          // [n][64] adjoint of Bt, summed over the edges that read row j
+  float* pos = TB + n * WIDE_HP;         // [n][4] positions entering the layer
+  float* pos0 = pos + n * 4;             // [n][4] input geometry
+  float* posn = pos0 + n * 4;            // [n][4] positions leaving the layer (forward sweep)
+  float* pb = posn + n * 4;              // [n][4] adjoint of the positions leaving the layer
+  float* pbn = pb + n * 4;               // [n][4] adjoint of the positions entering it (being summed)
+  float* p0b = pbn + n * 4;              // [n][4] adjoint of the input geometry (edge attribute of every layer, and -u)
+  float* bc = p0b + n * 4;               // [64] broadcast slot of the dense layers
+  const size_t ck_layer = (size_t)2 * n * WIDE_HP + (size_t)n * 4;
+  float* ws = q.ws + (size_t)(blockIdx.x * waves + wave) * p.L * ck_layer;
+  const bool want_h = q.dot_h != nullptr;
+  const long long nw = (long long)gridDim.x * waves;
+  for (long long w = (long long)blockIdx.x * waves + wave; w < p.B; w += nw) {
+    const float hval = p.t[w];
+    const float bet = p.has_beta ? p.beta[w] : 0.f;
+    const float c_s = 1.0f / (1.0f + hval), c_in = 1.0f / sqrtf(1.0f + hval), sh = sqrtf(hval);
+    const float c_out = sh * c_in, tfeat = 0.125f * logf(hval);
+    const float dc_s = -c_s * c_s, dc_in = -0.5f * c_in * c_s, dc_out = 0.5f * c_in / sh + sh * dc_in;
+    for (int qd = lane; qd < n * 4; qd += 64) { pos[qd] = 0.f; pos0[qd] = 0.f; pb[qd] = 0.f; pbn[qd] = 0.f; p0b[qd] = 0.f; }
+    wfence();
+    for (int qd = lane; qd < n * DIM; qd += 64) {
+      const int i = qd / DIM, k = qd - i * DIM;
+      const float v = c_in * p.x[w * n * DIM + qd];
+      pos[i * 4 + k] = v;
+      pos0[i * 4 + k] = v;
+    }
+    const float et = p.w[lane], eb = p.w[64 + lane];
+    for (int i = 0; i < n; ++i) {
+      hf[i * WIDE_HP + lane] = fmaf(et, tfeat, fmaf(eb, bet, p.estatic[i * WIDE_HP + lane]));
+      hb[i * WIDE_HP + lane] = 0.f;
+    }
+    wfence();
+    // ------------------------------------------------------------------ forward sweep, checkpoints
+    for (int l = 0; l < p.L; ++l) {
+      const float* wl = p.w + WIDE_HEAD + (size_t)l * WideLayer::SIZE;
+      float* ck = ws + (size_t)l * ck_layer;
+      for (int i = 0; i < n; ++i) {
+        const float hv = hf[i * WIDE_HP + lane];
+        ck[i * WIDE_HP + lane] = hv;
+        At[i * WIDE_HP + lane] = dense_mem_b<HK>(wl + WideLayer::WA, bc, lane, hv, wl[WideLayer::B1 + lane]);
+        Bt[i * WIDE_HP + lane] = dense_mem_b<HK>(wl + WideLayer::WB, bc, lane, hv, 0.f);
+      }
+      for (int qd = lane; qd < n * 4; qd += 64) ck[2 * n * WIDE_HP + qd] = pos[qd];
+      wfence();
+      float w2[WIDE_HP], wc1[WIDE_HP];
+#pragma unroll
+      for (int k = 0; k < HK; ++k) {
+        w2[k] = wl[WideLayer::W2 + k * WIDE_HP + lane];
+        wc1[k] = wl[WideLayer::WC1 + k * WIDE_HP + lane];
+      }
+      const float wr = wl[WideLayer::WR + lane], we = wl[WideLayer::WE + lane], b2 = wl[WideLayer::B2 + lane];
+      const float watt = wl[WideLayer::WATT + lane], batt = wl[WideLayer::BATT], bc1 = wl[WideLayer::BC1 + lane];
+      const float wc2 = wl[WideLayer::WC2 + lane];
+      const bool last = (l == p.L - 1);
+      for (int i = 0; i < n; ++i) {
+        const float Ai = At[i * WIDE_HP + lane];
+        float pi[3] = {0.f, 0.f, 0.f}, p0i[3] = {0.f, 0.f, 0.f}, xacc[3] = {0.f, 0.f, 0.f};
+        for (int k = 0; k < DIM; ++k) { pi[k] = pos[i * 4 + k]; p0i[k] = pos0[i * 4 + k]; }
+        float agg = 0.f;
+        for (int j = 0; j < n; ++j) {
+          if (j == i) continue;
+          float df[3] = {0.f, 0.f, 0.f}, radial = 0.f, ea = 0.f;
+          for (int k = 0; k < DIM; ++k) {
+            df[k] = pi[k] - pos[j * 4 + k];
+            radial = fmaf(df[k], df[k], radial);
+            const float e0 = p0i[k] - pos0[j * 4 + k];
+            ea = fmaf(e0, e0, ea);
+          }
+          float m = wsilu(fmaf(we, ea, fmaf(wr, radial, Ai + Bt[j * WIDE_HP + lane])));
+          m = wsilu(dense_reg_b<HK>(w2, bc, lane, m, b2));
+          if (p.attention) m *= fast_sigmoid(wwave_sum(watt * m) + batt);
+          agg += m;
+          const float c1 = wsilu(dense_reg_b<HK>(wc1, bc, lane, m, bc1));
+          float cs = wwave_sum(wc2 * c1);
+          if (p.tanh_on) cs = accurate_tanh(cs) * p.coord_scale;
+          const float inv = 1.0f / (sqrtf(radial + 1e-8f) + 1.0f);
+          for (int k = 0; k < DIM; ++k) xacc[k] = fmaf(df[k] * inv, cs, xacc[k]);
+        }
+        if (lane < DIM) posn[i * 4 + lane] = pi[lane < 3 ? lane : 0] + xacc[lane < 3 ? lane : 0];
+        if (!last) {
+          const float hv = hf[i * WIDE_HP + lane];
+          float z = dense_mem_b<HK>(wl + WideLayer::WN1A, bc, lane, hv, wl[WideLayer::BN1 + lane]);
+          z = dense_mem_b<HK>(wl + WideLayer::WN1B, bc, lane, agg, z);
+          ck[(n + i) * WIDE_HP + lane] = z;
+          const float o = dense_mem_b<HK>(wl + WideLayer::WN2, bc, lane, wsilu(z), wl[WideLayer::BN2 + lane]);
+          hf[i * WIDE_HP + lane] = hv + o;
+        }
+      }
+      wfence();
+      for (int qd = lane; qd < n * 4; qd += 64) pos[qd] = posn[qd];
+      wfence();
+    }
+    // F = (pos^L - pos0) - mean;  D = c_s x + c_out F;  adjoint of u = pos^L - pos0:  c_out (cot - mean_i cot)
+    float mean[3] = {0.f, 0.f, 0.f}, cmean[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < DIM; ++k) {
+      float s = 0.f, sc = 0.f;
+      for (int i = 0; i < n; ++i) {
+        s += pos[i * 4 + k] - pos0[i * 4 + k];
+        sc += q.cot ? q.cot[(w * n + i) * DIM + k] : p.x[(w * n + i) * DIM + k];
+      }
+      mean[k] = s / (float)n;
+      cmean[k] = sc / (float)n;
+    }
+    float hpart = 0.f;  // this lane's share of <cot, dD/dh>
+    for (int qd = lane; qd < n * DIM; qd += 64) {
+      const int i = qd / DIM, k = qd - i * DIM;
+      const float F = (pos[i * 4 + k] - pos0[i * 4 + k]) - mean[k];
+      const float xc = p.x[w * n * DIM + qd];
+      const float ct = q.cot ? q.cot[w * n * DIM + qd] : xc;
+      if (p.out) p.out[w * n * DIM + qd] = fmaf(c_s, xc, c_out * F);
+      hpart = fmaf(ct, fmaf(dc_s, xc, dc_out * F), hpart);
+      const float u = c_out * (ct - cmean[k]);
+      pb[i * 4 + k] = u;
+      p0b[i * 4 + k] = -u;
+    }
+    wfence();
+    // ------------------------------------------------------------------ backward sweep
+    for (int l = p.L - 1; l >= 0; --l) {
+      const float* wl = p.w + WIDE_HEAD + (size_t)l * WideLayer::SIZE;
+      const float* ck = ws + (size_t)l * ck_layer;
+      const bool last = (l == p.L - 1);
+      const bool need_h = (l > 0) || want_h;  // h^0 does not depend on x (but on h, through the time feature)
+      for (int qd = lane; qd < n * 4; qd += 64) { pos[qd] = ck[2 * n * WIDE_HP + qd]; pbn[qd] = 0.f; }
+      for (int i = 0; i < n; ++i) hf[i * WIDE_HP + lane] = ck[i * WIDE_HP + lane];
+      wfence();
+      for (int i = 0; i < n; ++i) {
+        const float hv = hf[i * WIDE_HP + lane];
+        At[i * WIDE_HP + lane] = dense_mem_b<HK>(wl + WideLayer::WA, bc, lane, hv, wl[WideLayer::B1 + lane]);
+        Bt[i * WIDE_HP + lane] = dense_mem_b<HK>(wl + WideLayer::WB, bc, lane, hv, 0.f);
+        TB[i * WIDE_HP + lane] = 0.f;
+      }
+      wfence();
+      float w2[WIDE_HP], wc1[WIDE_HP], w2t[WIDE_HP], wc1t[WIDE_HP];
+#pragma unroll
+      for (int k = 0; k < HK; ++k) {
+        w2[k] = wl[WideLayer::W2 + k * WIDE_HP + lane];
+        wc1[k] = wl[WideLayer::WC1 + k * WIDE_HP + lane];
+        w2t[k] = wl[WideLayer::W2N + k * WIDE_HP + lane];
+        wc1t[k] = wl[WideLayer::WC1N + k * WIDE_HP + lane];
+      }
+      const float wr = wl[WideLayer::WR + lane], we = wl[WideLayer::WE + lane], b2 = wl[WideLayer::B2 + lane];
+      const float watt = wl[WideLayer::WATT + lane], batt = wl[WideLayer::BATT], bc1 = wl[WideLayer::BC1 + lane];
+      const float wc2 = wl[WideLayer::WC2 + lane];
+      for (int i = 0; i < n; ++i) {
+        const float Ai = At[i * WIDE_HP + lane];
+        // node model backward: h' = h + Wn2 silu(zn) + bn2, zn = Wn1a h + Wn1b agg + bn1
+        float hbi = hb[i * WIDE_HP + lane], aggb = 0.f;
+        if (!last) {
+          float gz;
+          (void)wsilu_d(ck[(n + i) * WIDE_HP + lane], gz);
+          const float znb = gz * dense_mem_b<HK>(wl + WideLayer::WN2N, bc, lane, hbi, 0.f);
+          aggb = dense_mem_b<HK>(wl + WideLayer::WN1BN, bc, lane, znb, 0.f);
+          if (need_h) hbi = dense_mem_b<HK>(wl + WideLayer::WN1AN, bc, lane, znb, hbi);
+        }
+        float pi[3] = {0.f, 0.f, 0.f}, p0i[3] = {0.f, 0.f, 0.f}, X[3] = {0.f, 0.f, 0.f};
+        float pacc[3] = {0.f, 0.f, 0.f}, p0acc[3] = {0.f, 0.f, 0.f};
+        for (int k = 0; k < DIM; ++k) { pi[k] = pos[i * 4 + k]; p0i[k] = pos0[i * 4 + k]; X[k] = pb[i * 4 + k]; }
+        float S = 0.f;
+        for (int j = 0; j < n; ++j) {
+          if (j == i) continue;
+          float df[3] = {0.f, 0.f, 0.f}, e0[3] = {0.f, 0.f, 0.f}, radial = 0.f, ea = 0.f, t = 0.f;
+          for (int k = 0; k < DIM; ++k) {
+            df[k] = pi[k] - pos[j * 4 + k];
+            radial = fmaf(df[k], df[k], radial);
+            e0[k] = p0i[k] - pos0[j * 4 + k];
+            ea = fmaf(e0[k], e0[k], ea);
+            t = fmaf(df[k], X[k], t);
+          }
+          // the edge again, with derivative factors
+          float g1, g2, gc;
+          const float m1 = wsilu_d(fmaf(we, ea, fmaf(wr, radial, Ai + Bt[j * WIDE_HP + lane])), g1);
+          const float m2 = wsilu_d(dense_reg_b<HK>(w2, bc, lane, m1, b2), g2);
+          float a = 1.0f, m = m2;
+          if (p.attention) {
+            a = fast_sigmoid(wwave_sum(watt * m2) + batt);
+            m = m2 * a;
+          }
+          const float c1 = wsilu_d(dense_reg_b<HK>(wc1, bc, lane, m, bc1), gc);
+          float cs = wwave_sum(wc2 * c1), dcs = 1.0f;
+          if (p.tanh_on) {
+            const float th = accurate_tanh(cs);
+            dcs = p.coord_scale * fmaf(-th, th, 1.0f);
+            cs = th * p.coord_scale;
+          }
+          const float sq = sqrtf(radial + 1e-8f), inv = 1.0f / (sq + 1.0f);
+          // backward: pos'_i += df inv cs
+          const float csb = (inv * t) * dcs, invb = cs * t;
+          float mb = dense_reg_b<HK>(wc1t, bc, lane, gc * (wc2 * csb), aggb);  // adjoint of the gated message
+          if (p.attention) {
+            const float sb = (a * (1.0f - a)) * wwave_sum(mb * m2);
+            mb = fmaf(mb, a, watt * sb);
+          }
+          const float z1b = g1 * dense_reg_b<HK>(w2t, bc, lane, g2 * mb, 0.f);
+          if (need_h) {
+            S += z1b;
+            TB[j * WIDE_HP + lane] += z1b;
+          }
+          const float radb = fmaf(invb, -(inv * inv) * (0.5f / sq), wwave_sum(wr * z1b));
+          const float eab = wwave_sum(we * z1b);
+          const float ic = inv * cs;
+          for (int k = 0; k < DIM; ++k) {
+            const float dfb = fmaf(ic, X[k], 2.0f * radb * df[k]);
+            const float e0b = 2.0f * eab * e0[k];
+            pacc[k] += dfb;
+            p0acc[k] += e0b;
+            if (lane == 0) {
+              pbn[j * 4 + k] -= dfb;
+              p0b[j * 4 + k] -= e0b;
+            }
+          }
+        }
+        hb[i * WIDE_HP + lane] = need_h ? dense_mem_b<HK>(wl + WideLayer::WAN, bc, lane, S, hbi) : hbi;
+        if (lane == 0)
+          for (int k = 0; k < DIM; ++k) {
+            pbn[i * 4 + k] += X[k] + pacc[k];
+            p0b[i * 4 + k] += p0acc[k];
+          }
+      }
+      wfence();
+      if (need_h)
+        for (int j = 0; j < n; ++j)
+          hb[j * WIDE_HP + lane] = dense_mem_b<HK>(wl + WideLayer::WBN, bc, lane, TB[j * WIDE_HP + lane], hb[j * WIDE_HP + lane]);
+      for (int qd = lane; qd < n * 4; qd += 64) pb[qd] = pbn[qd];
+      wfence();
+    }
+    // pos^0 = pos0 = c_in x
+    for (int qd = lane; qd < n * DIM; qd += 64) {
+      const int i = qd / DIM, k = qd - i * DIM;
+      const float yb = pb[i * 4 + k] + p0b[i * 4 + k];
+      const float xc = p.x[w * n * DIM + qd];
+      const float ct = q.cot ? q.cot[w * n * DIM + qd] : xc;
+      q.vjp[w * n * DIM + qd] = fmaf(c_s, ct, c_in * yb);
+      hpart = fmaf(dc_in * yb, xc, hpart);
+    }
+    if (want_h) {
+      float tb = 0.f;  // through the time feature ln(h)/8 of every node's embedding
+      for (int i = 0; i < n; ++i) tb = fmaf(hb[i * WIDE_HP + lane], et, tb);
+      const float s = wwave_sum(fmaf(tb, 0.125f / hval, hpart));
+      if (lane == 0) q.dot_h[w] = s;
+    }
+    wfence();
+  }
+}
+
+}  // namespace
 }  // namespace pita
 
 using namespace pita;
@@ -657,6 +939,10 @@ extern "C" int pita_egnn_wide_create(pita_egnn_wide_t** out, const pita_egnn_wid
     for (int k = 0; k < H; ++k)
       for (int f = 0; f < H; ++f) dst[k * WIDE_HP + f] = M[f * ld + col0 + k];
   };
+  auto put_n = [&](float* dst, const float* M, int ld, int col0) {  // dst[f][k] = M[f][col0 + k]
+    for (int f = 0; f < H; ++f)
+      for (int k = 0; k < H; ++k) dst[f * WIDE_HP + k] = M[f * ld + col0 + k];
+  };
   for (int l = 0; l < L; ++l) {
     float* wl = hw + WIDE_HEAD + (size_t)l * WideLayer::SIZE;
     const float* e0w = q; q += H * (2 * H + 2);
@@ -679,6 +965,13 @@ extern "C" int pita_egnn_wide_create(pita_egnn_wide_t** out, const pita_egnn_wid
     put_t(wl + WideLayer::WN1A, n0w, 2 * H, 0);
     put_t(wl + WideLayer::WN1B, n0w, 2 * H, H);
     put_t(wl + WideLayer::WN2, n2w, H, 0);
+    put_n(wl + WideLayer::WAN, e0w, 2 * H + 2, 0);
+    put_n(wl + WideLayer::WBN, e0w, 2 * H + 2, H);
+    put_n(wl + WideLayer::W2N, e2w, H, 0);
+    put_n(wl + WideLayer::WC1N, c0w, H, 0);
+    put_n(wl + WideLayer::WN1AN, n0w, 2 * H, 0);
+    put_n(wl + WideLayer::WN1BN, n0w, 2 * H, H);
+    put_n(wl + WideLayer::WN2N, n2w, H, 0);
     for (int f = 0; f < H; ++f) {
       wl[WideLayer::WR + f] = e0w[f * (2 * H + 2) + 2 * H];
       wl[WideLayer::WE + f] = e0w[f * (2 * H + 2) + 2 * H + 1];
@@ -732,6 +1025,7 @@ extern "C" int pita_egnn_wide_uses_matrix_pipe(const pita_egnn_wide_t* net) {
 extern "C" int pita_egnn_wide_destroy(pita_egnn_wide_t* net) {
   if (!net) return PITA_OK;
   wide64_release(net);
+  (void)hipFree(net->d_vjp_ws);
   (void)hipFree(net->d_w);
   (void)hipFree(net->d_estatic);
   delete net;
@@ -919,6 +1213,57 @@ extern "C" int pita_egnn_wide_sampler_run(pita_egnn_wide_t* net, float* x, int64
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(waves * 64), per_wave * waves, st, p);
     if (hipGetLastError() != hipSuccess) rc = fail(PITA_EHIP, "pita_egnn_wide_sampler_run: launch failed");
     else net->vec_attr[1] = true;
+  }
+  if (switched) (void)hipSetDevice(prev);
+  return rc;
+}
+
+// Reverse-mode derivative of the denoiser around the wide backbone (see egnn_wide_vjp_kernel); arguments as pita_egnn_vjp
+extern "C" int pita_egnn_wide_vjp(pita_egnn_wide_t* net, const float* h, const float* x, const float* beta, const float* cot,
+                                  float* out, float* vjp, float* dot_h, int64_t B, void* stream) {
+  PITA_REQUIRE(net && B >= 0, "pita_egnn_wide_vjp: bad argument");
+  if (B == 0) return PITA_OK;
+  PITA_REQUIRE(h && x && vjp, "pita_egnn_wide_vjp: null argument");
+  PITA_REQUIRE(beta || !net->cfg.condition_beta, "pita_egnn_wide_vjp: beta required (condition_beta)");
+  int prev = -1;
+  bool switched = false;
+  if (net->device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != net->device)
+    switched = hipSetDevice(net->device) == hipSuccess;
+  WideVjpParams q{};
+  WideParams& p = q.base;
+  p.w = net->d_w; p.estatic = net->d_estatic;
+  p.n = net->cfg.n_particles; p.dim = net->cfg.n_dim; p.H = net->cfg.hidden_nf; p.L = net->cfg.n_layers;
+  p.attention = net->cfg.attention; p.tanh_on = net->cfg.tanh; p.has_beta = net->cfg.condition_beta;
+  p.coord_scale = net->cfg.coords_range / (float)net->cfg.n_layers;
+  p.B = B; p.mode = 1; p.x = x; p.t = h; p.beta = beta; p.out = out;
+  q.cot = cot; q.vjp = vjp; q.dot_h = dot_h;
+  int rc = PITA_OK;
+  const size_t per_wave = sizeof(float) * (size_t)(5 * p.n * WIDE_HP + 6 * p.n * 4 + WIDE_HP);
+  int waves = 4;
+  while (waves > 1 && per_wave * waves > 150 * 1024) waves >>= 1;
+  auto kernel = p.H <= 32 ? egnn_wide_vjp_kernel<32> : egnn_wide_vjp_kernel<64>;
+  const long long want = (B + waves - 1) / waves, cap = (long long)net->n_cu;  // one wave per SIMD
+  const unsigned grid = (unsigned)(want < cap ? want : cap);
+  const size_t ws_need = sizeof(float) * (size_t)grid * waves * p.L * ((size_t)2 * p.n * WIDE_HP + (size_t)p.n * 4);
+  if (per_wave * waves > 150 * 1024) {
+    rc = fail(PITA_EUNSUPPORTED, "pita_egnn_wide_vjp: %d particles need %zu B of LDS per wave", p.n, per_wave);
+  } else if (ws_need > net->vjp_ws_bytes) {
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);  // an earlier launch may still use the old buffer
+    (void)hipFree(net->d_vjp_ws);
+    net->d_vjp_ws = nullptr;
+    net->vjp_ws_bytes = 0;
+    if (e == hipSuccess) e = hipMalloc(&net->d_vjp_ws, ws_need);
+    if (e != hipSuccess) rc = fail(PITA_EHIP, "pita_egnn_wide_vjp: checkpoint buffer: %s", hipGetErrorString(e));
+    else net->vjp_ws_bytes = ws_need;
+  }
+  if (rc == PITA_OK &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)(per_wave * waves)) != hipSuccess)
+    rc = fail(PITA_EHIP, "pita_egnn_wide_vjp: cannot reserve %zu B of LDS", per_wave * waves);
+  if (rc == PITA_OK) {
+    q.ws = net->d_vjp_ws;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(waves * 64), per_wave * waves, (hipStream_t)stream, q);
+    if (hipGetLastError() != hipSuccess) rc = fail(PITA_EHIP, "pita_egnn_wide_vjp: launch failed");
   }
   if (switched) (void)hipSetDevice(prev);
   return rc;

@@ -177,3 +177,25 @@ class EGNN_dynamics_AD2_cat(nn.Module):
                                                  _lib.ptr(dot_out), stride, int(dot_col), _lib.ptr(diag_acc), B,
                                                  _lib.stream_ptr(x_t.device)), "pita_egnn_wide_jvp")
         return out, dout
+
+    def vjp(self, h_t, x_t, beta, cot=None, want_primal=True, want_dot_h=False):
+        """(D, J_x D^T cot[, <cot, dD/dh>]): the EDM denoiser around this backbone and its reverse-mode derivative for a
+        per-walker cotangent (default: x_t itself) from ONE launch (pita_egnn_wide_vjp) -- same contract as
+        ``EGNN_dynamics.vjp``; ``EnergyNet.forward`` and the debiased drift use it instead of dim + 1 ``jvp`` launches."""
+        x_t = _lib.dev_tensor(x_t, "x_t")
+        B = x_t.shape[0]
+        h_t = _lib.dev_tensor(h_t, "h_t").reshape(-1).expand(B).contiguous()
+        b = None
+        if self.condition_beta:
+            if beta is None:
+                raise ValueError("EGNN_dynamics_AD2_cat(condition_beta=True) needs beta")
+            b = _as_batch(beta, B, x_t.device)
+        if cot is not None:
+            cot = _lib.dev_tensor(cot, "cot")
+        out = torch.empty_like(x_t) if want_primal else None
+        vjp = torch.empty_like(x_t)
+        dot_h = torch.empty(B, device=x_t.device) if want_dot_h else None
+        _lib.check(_lib.lib().pita_egnn_wide_vjp(self._native(x_t.device), h_t.data_ptr(), x_t.data_ptr(), _lib.ptr(b),
+                                                 _lib.ptr(cot), _lib.ptr(out), vjp.data_ptr(), _lib.ptr(dot_h), B,
+                                                 _lib.stream_ptr(x_t.device)), "pita_egnn_wide_vjp")
+        return (out, vjp, dot_h) if want_dot_h else (out, vjp)

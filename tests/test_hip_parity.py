@@ -431,6 +431,62 @@ def test_egnn_ad2cat_forward_mode_vs_oracle_jacobian(pa, golden, tag, L, tanh, a
     assert torch.equal(big[:B], small) and torch.equal(big[-B:], small)
 
 
+@pytest.mark.parametrize("tag,L,tanh,att", [("h64", 5, True, True), ("h48", 2, False, False), ("h64", 5, True, False)])
+def test_egnn_ad2cat_reverse_mode_vs_oracle_jacobian(pa, golden, tag, L, tanh, att):
+    """pita_egnn_wide_vjp (reverse mode through EGNN_dynamics_AD2_cat: ONE launch for J_x D^T cot and <cot, dD/dh>)
+    against vmap(jacrev) of the fp64 oracle on the inputs of the reference golden -- cot = x (what grad_x E_theta needs,
+    energy_net.py:51-62) and a dense cotangent --, against the forward-mode launches it replaces, and through
+    EnergyNet.forward against autograd of the oracle's E_theta; rel 5e-5 like the h32 reverse-mode kernel."""
+    from torch.func import jacrev, vmap
+
+    from pita_amd.egnn_dynamics_ad2_cat import EGNN_dynamics_AD2_cat
+    from pita_amd.energy_net import EnergyNet
+
+    g = golden(f"egnn_ad2cat_{tag}_fwd.npz")
+    w = {k[2:]: T(v) for k, v in g.items() if k.startswith("w.")}
+    H = w["egnn.embedding.weight"].shape[0]
+    if not att:  # the gate's parameters are absent from an attention=False module
+        w = {k: v for k, v in w.items() if "att_mlp" not in k}
+    net = EGNN_dynamics_AD2_cat(22, 3, hidden_nf=H, n_layers=L, tanh=tanh, attention=att, condition_beta=True)
+    net.load_state_dict(w)
+    sel = np.arange(0, g["x"].shape[0], 2)[:6]
+    x, h, beta = T(g["x"][sel]), T(g["h"][sel]), T(g["beta"][sel])
+    B = x.shape[0]
+    wd = {k: v.double() for k, v in w.items()}
+    bb = lambda cn, xs, b: O.egnn_ad2_cat_forward(wd, cn, xs, b, 22, 3, n_layers=L, tanh=tanh, attention=att)
+    one = lambda hh, xx, b: O.denoiser(bb, hh[None], xx[None], b[None])[0]
+    Jx = vmap(jacrev(one, argnums=1))(h.double(), x.double(), beta.double())      # [B, 66, 66]
+    Jh = vmap(jacrev(one, argnums=0))(h.double(), x.double(), beta.double())      # [B, 66]
+    D64 = O.denoiser(bb, h.double(), x.double(), beta.double())
+    xc, hc, bc = x.cuda(), h.cuda(), beta.cuda()
+    gen = torch.Generator().manual_seed(11)
+    for name, cot in (("x", None), ("dense", torch.randn(B, 66, generator=gen))):
+        c64 = (x if cot is None else cot).double()
+        D, vj, dh = net.vjp(hc, xc, bc, cot=None if cot is None else cot.cuda(), want_dot_h=True)
+        assert rel(D, D64) < 2e-6, name
+        assert rel(vj, torch.einsum("bq,bqk->bk", c64, Jx)) < 5e-5, (name, rel(vj, torch.einsum("bq,bqk->bk", c64, Jx)))
+        want_h = (c64 * Jh).sum(-1)
+        np.testing.assert_allclose(dh.cpu().numpy(), want_h.numpy(), rtol=2e-4, atol=2e-4 * float(want_h.abs().mean()))
+        _, vj2 = net.vjp(hc, xc, bc, cot=None if cot is None else cot.cuda(), want_primal=False)  # x-only sweep
+        assert rel(vj2, vj) < 1e-6
+    # the forward-mode launches it replaces
+    jtx = torch.empty(B, 66, device="cuda")
+    for k in range(66):
+        net.jvp(hc, xc, bc, direction=k, want_primal=False, want_tangent=False, dot_out=jtx, dot_col=k)
+    _, vj = net.vjp(hc, xc, bc)
+    assert rel(vj, jtx) < 2e-5
+    # grad_x E_theta through the plug-in class
+    en = EnergyNet(net)
+    xr = x.double().requires_grad_(True)
+    gref = torch.autograd.grad(O.energy_theta(bb, h.double(), xr, beta.double()).sum(), xr)[0]
+    assert rel(en(hc, xc, bc), gref) < 5e-5
+    # batch edges: empty batch; more walkers than resident waves give the same bits per walker
+    assert net.vjp(hc[:0], xc[:0], bc[:0])[1].shape == (0, 66)
+    reps = 400
+    _, big = net.vjp(hc.repeat(reps), xc.repeat(reps, 1), bc.repeat(reps), want_primal=False)
+    assert torch.equal(big[:B], vj) and torch.equal(big[-B:], vj)
+
+
 def test_debiased_regime_on_the_ad2cat_backbone_vs_oracle(pa, golden):
     """VEReverseSDE(debias_inference=True) -- the reference default (model/energytemp.yaml:78) -- with the
     alanine-dipeptide backbone EGNN_dynamics_AD2_cat for the score AND the energy net (sdes.py:151-239 on

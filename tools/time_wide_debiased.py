@@ -1,5 +1,5 @@
 """Debiased (Feynman-Kac) step with the alanine-dipeptide backbone EGNN_dynamics_AD2_cat (hidden 64 x 5) for score and
-energy net: forward-mode launches (pita_egnn_wide_jvp), config C4's per-GPU shard by default.
+energy net: forward-mode launches (pita_egnn_wide_jvp) for the trace, one reverse-mode launch (pita_egnn_wide_vjp), config C4's per-GPU shard by default.
 python tools/time_wide_debiased.py [walkers]"""
 import copy, os, sys, time
 import torch
@@ -29,6 +29,8 @@ os.environ["PITA_WIDE_NO_MFMA"] = "1"
 fwd_v = ev(lambda: net.edm(1, h, x, b), 2)
 del os.environ["PITA_WIDE_NO_MFMA"]
 one = ev(lambda: net.jvp(h, x, b, direction=3, want_primal=False, want_tangent=False, diag_acc=torch.zeros(B, device="cuda")), 2)
+rev = ev(lambda: net.vjp(h, x, b, want_dot_h=True), 2)
 step = ev(lambda: sde.f(t, x, 1.0, gam, None, None, resampling_interval=1))
 print(f"B={B}: denoiser forward {fwd*1e3:.2f} ms (matrix pipe), {fwd_v*1e3:.2f} ms (vector pipe); one forward-mode launch "
-      f"{one*1e3:.2f} ms; debiased step (2 x 67 launches) {step*1e3:.1f} ms = {B/step:.3e} walker-steps/s")
+      f"{one*1e3:.2f} ms; one reverse-mode launch {rev*1e3:.2f} ms; debiased step (67 forward-mode launches + 1 "
+      f"reverse-mode launch) {step*1e3:.1f} ms = {B/step:.3e} walker-steps/s")
