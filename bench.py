@@ -629,8 +629,9 @@ def main():
         net64.sampler_run(xa, tab64, 50, seed=seed, walker_offset=rank * B, step0=2, remove_mean=True)
         torch.cuda.synchronize()
         dt64 = (time.perf_counter() - t0) / 50
-        # the debiased (Feynman-Kac) regime with this backbone as score AND energy net: 2 x (dim + 1) forward-mode
-        # launches per step (pita_egnn_wide_jvp: matrix-pipe kernel for 22 atoms), assembly, clamp
+        # the debiased (Feynman-Kac) regime with this backbone as score AND energy net: dim + 1 forward-mode launches for
+        # the score net's trace (pita_egnn_wide_jvp: matrix-pipe kernel for 22 atoms), ONE reverse-mode launch on the
+        # energy net (pita_egnn_wide_vjp), assembly, clamp
         import copy as _copy
 
         from pita_amd.energy_net import EnergyNet as _EnergyNet
@@ -652,7 +653,8 @@ def main():
                   "walkers": B, "ms_per_step": dt64 * 1e3, "value": B / dt64, "unit": "walker-steps/s",
                   "ms_per_step_launch_per_step_path": dt64_steps * 1e3,
                   "debiased": {"ms_per_step": dt64_deb * 1e3, "value": B / dt64_deb, "unit": "walker-steps/s",
-                               "launches_per_step": f"2 x {n * d + 1} forward-mode launches (pita_egnn_wide_jvp) + assembly + clamp"},
+                               "launches_per_step": f"{n * d + 1} forward-mode launches (pita_egnn_wide_jvp) + 1 reverse-mode launch "
+                                                    "(pita_egnn_wide_vjp) + assembly + clamp"},
                   "algorithmic_TFLOPs": 2 * mac * B / dt64 / 1e12,
                   ("frac_of_dense_f16_mfma_peak_2500" if on_mfma else "frac_of_plain_fma_rate_78.6"):
                       2 * mac * B / dt64 / (2500e12 if on_mfma else 78.65e12),
