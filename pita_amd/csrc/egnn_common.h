@@ -375,6 +375,8 @@ struct pita_egnn {
   float* d_vecs = nullptr;       // [VEC_EMB_F + L*VEC_LAYER_F]
   float* d_vecs_h = nullptr;     // the same vectors with the PREC 2 scale factors folded in
   float* d_vecs_div = nullptr;   // [L][4][32] fragment order: DIV_ST kS (w_r + w_e), kS w_r, kS w_e, DIV_SV w_c2 / kS
+  int* d_vjp_mark = nullptr;     // [B + 16] marks + flag of the reverse-mode kernel's f16 path (pita_egnn_vjp)
+  size_t vjp_mark_bytes = 0;
   const void* shape = nullptr;   // pita::EgnnShape of egnn_kernel.hip
   const void* shape_small = nullptr;  // optional mapping with fewer walkers per wave, for batches that underfill the GPU
   int n_cu = 256;

@@ -831,6 +831,7 @@ extern "C" int pita_egnn_destroy(pita_egnn_t* net) {
   (void)hipFree(net->d_mats);
   (void)hipFree(net->d_vecs);
   (void)hipFree(net->d_mats16);
+  (void)hipFree(net->d_vjp_mark);
   (void)hipFree(net->d_mats16h);
   (void)hipFree(net->d_vecs_h);
   (void)hipFree(net->d_vecs_div);

@@ -28,6 +28,7 @@ namespace pita {
 
 struct VjpParams {
   const unsigned* mats16;
+  const unsigned* mats16h;  // f16 two-piece fragments (PE = 2: the per-edge recompute GEMMs W2, Wc1)
   const float* vecs;
   int n_layers, in_nf, attention, tanh_on, feature_layout;
   float coord_scale;
@@ -41,6 +42,8 @@ struct VjpParams {
   float* dot_h;       // nullable [B]: <cot, dD/dh> -- the reverse sweep also reaches the inputs that depend on h (time
                       // feature, c_in scaling) and the explicit c_s(h), c_out(h): no forward-mode launch needed
   float* ws;          // checkpoint scratch: total_waves * ws_f floats
+  const int* mark;    // repair pass (nullable): only the walkers marked by vjp_mark_kernel are recomputed and written
+  const int* flag;    // repair pass: 0 = nothing was marked, return at once
 };
 
 template <int N, int DIM, int G, int WAVES>
@@ -107,11 +110,29 @@ __device__ __forceinline__ void lds_add16(float* dst, const f32x16& v) {
   }
 }
 
+// a per-edge primal GEMM of the sweeps: bf16x3 (PE = 1), or the f16 two-piece path of the forward kernels (PE = 2: half
+// the matrix instructions, a two-instruction operand split; the accumulator holds F16_SX F16_SW x the pre-activation)
+template <int PE>
+__device__ __forceinline__ f32x16 edge_gemm(const WFrag<PE>& w, const f32x16& in, const f32x16& bias) {
+  if constexpr (PE == 2) {
+    f32x16 r = w.mul(in, bias * (F16_SX * F16_SW));
+    r *= F16_UNSCALE;
+    return r;
+  } else {
+    return w.mul(in, bias);
+  }
+}
+
 // FIXED: attention gate, tanh-bounded coordinate head and the h-derivative output are compile-time "on" (every reference
 // configuration of the debiased regime): the edge loops carry no run-time branch.  FIXED = false keeps them run-time.
-template <int N, int DIM, int G, int WAVES, bool FIXED>
+// PE: arithmetic of the four per-edge primal GEMMs (W2, Wc1 in the forward sweep and again in the recompute of the
+// backward sweep); the adjoint GEMMs and the per-node layers stay bf16x3 (adjoints have no fixed range to scale for).
+// A walker whose activations leave the f16 range ends non-finite, is marked by vjp_mark_kernel and recomputed by the
+// PE = 1 instantiation (`mark`), like the forward and divergence kernels do it.
+template <int N, int DIM, int G, int WAVES, bool FIXED, int PE>
 __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
   using C = VjpCfg<N, DIM, G, WAVES>;
+  if (p.mark && *p.flag == 0) return;
   const bool att_on = FIXED ? true : (p.attention != 0);
   const bool tanh_on = FIXED ? true : (p.tanh_on != 0);
   const bool want_h = FIXED ? true : (p.dot_h != nullptr);
@@ -140,6 +161,10 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
   const long long wend = (wbeg + quota < p.B) ? wbeg + quota : p.B;
   for (long long walker0 = wbeg; walker0 < wend; walker0 += G) {
     const int nwalk = (int)((wend - walker0) < G ? (wend - walker0) : G);
+    if (p.mark) {  // repair pass: groups without a marked walker are skipped (wave-uniform)
+      const int m = (lane < nwalk) ? p.mark[walker0 + lane] : 0;
+      if (!__any(m != 0)) continue;
+    }
     const int ncol = nwalk * N;
     const int ntile = (ncol + 31) >> 5;
     int col[NT], nodei[NT];
@@ -213,9 +238,10 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
         }
       }
       wave_lds_fence();
-      WFrag<1> w2f, wc1f;
-      w2f.load(nullptr, mats16, M_W2, lane);
-      wc1f.load(nullptr, mats16, M_WC1, lane);
+      const unsigned* matse = PE == 2 ? p.mats16h + (size_t)l * M_COUNT * MAT_WH : mats16;
+      WFrag<PE> w2f, wc1f;
+      w2f.load(nullptr, matse, M_W2, lane);
+      wc1f.load(nullptr, matse, M_WC1, lane);
       frag_to_agpr(w2f);
       frag_to_agpr(wc1f);
       const float a_re = lds[VEC_EMB_F + l * VEC_LAYER_F + V_WRE * EH + lane];
@@ -251,14 +277,14 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
           f32x16 z = Ai + lds_vec16(PB + cj * PBS + hh * 16);
           z = __builtin_amdgcn_mfma_f32_32x32x2f32(a_re, hh ? ea : radial, z, 0, 0, 0);
           silu16(z);
-          z = w2f.mul(z, lds_vec16(vl + V_B2 * EH));
+          z = edge_gemm<PE>(w2f, z, lds_vec16(vl + V_B2 * EH));
           silu16(z);
           if (att_on) {
             const float att = fast_sigmoid(xhalf_sum(dot16(lds_vec16(vl + V_WATT * EH), z)) + b_att);
             z *= att;
           }
           if (!last) agg += z;
-          f32x16 c1 = wc1f.mul(z, lds_vec16(vl + V_BC1 * EH));
+          f32x16 c1 = edge_gemm<PE>(wc1f, z, lds_vec16(vl + V_BC1 * EH));
           silu16(c1);
           float cs = xhalf_sum(dot16(lds_vec16(vl + V_WC2 * EH), c1));
           if (tanh_on) cs = tanh_select(cs) * p.coord_scale;
@@ -311,7 +337,8 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
         float s = 0.f, sc = 0.f;
         for (int q = 0; q < N; ++q) { s += scr[(cb + q) * DIM + k]; sc += scr[C::POS_F + (cb + q) * DIM + k]; }
         const float F = (posi[T][k] - p0i[T][k]) - s / (float)N;
-        if (p.out && valid[T] && hh == 0) p.out[(walker0 * N + col[T]) * DIM + k] = fmaf(c_s[T], xin[T][k], c_out[T] * F);
+        if (p.out && valid[T] && hh == 0 && (!p.mark || p.mark[walker0 + col[T] / N]))
+          p.out[(walker0 * N + col[T]) * DIM + k] = fmaf(c_s[T], xin[T][k], c_out[T] * F);
         if (want_h && valid[T] && hh == 0) {  // explicit h-dependence of D = c_s(h) x + c_out(h) F
           const float op = 1.0f + hvv[T];
           const float dcs = -c_s[T] * c_s[T];                               // d/dh 1/(1+h)
@@ -363,9 +390,11 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
         }
       }
       wave_lds_fence();
-      WFrag<1> w2f, wc1f, w2t, wc1t;
-      w2f.load(nullptr, mats16, M_W2, lane);
-      wc1f.load(nullptr, mats16, M_WC1, lane);
+      const unsigned* matse = PE == 2 ? p.mats16h + (size_t)l * M_COUNT * MAT_WH : mats16;
+      WFrag<PE> w2f, wc1f;
+      WFrag<1> w2t, wc1t;
+      w2f.load(nullptr, matse, M_W2, lane);
+      wc1f.load(nullptr, matse, M_WC1, lane);
       w2t.load(nullptr, mats16, M_W2T, lane);
       wc1t.load(nullptr, mats16, M_WC1T, lane);
       frag_to_agpr(w2f);
@@ -427,7 +456,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
           z = __builtin_amdgcn_mfma_f32_32x32x2f32(a_re, hh ? ea : radial, z, 0, 0, 0);
           f32x16 g1, g2, m2, gc;
           { f32x16 yv; silu_grad16(z, yv, g1); z = yv; }
-          z = w2f.mul(z, lds_vec16(vl + V_B2 * EH));
+          z = edge_gemm<PE>(w2f, z, lds_vec16(vl + V_B2 * EH));
           silu_grad16(z, m2, g2);
           float att = 1.0f;
           f32x16 m = m2;
@@ -435,7 +464,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
             att = fast_sigmoid(xhalf_sum(dot16(lds_vec16(vl + V_WATT * EH), m2)) + b_att);
             m *= att;
           }
-          z = wc1f.mul(m, lds_vec16(vl + V_BC1 * EH));
+          z = edge_gemm<PE>(wc1f, m, lds_vec16(vl + V_BC1 * EH));
           { f32x16 yv; silu_grad16(z, yv, gc); z = yv; }
           const f32x16 v_wc2 = lds_vec16(vl + V_WC2 * EH);
           float cs = xhalf_sum(dot16(v_wc2, z)), dcs_raw = 1.0f;
@@ -516,10 +545,11 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
 #pragma unroll
     for (int T = 0; T < NT; ++T) {
       if (!(valid[T] && hh == 0)) continue;
+      const bool wr = !p.mark || p.mark[walker0 + col[T] / N] != 0;
 #pragma unroll
       for (int k = 0; k < DIM; ++k) {
         const float yb = pb[T][k] + p0acc[T][k] + p0sc[col[T] * DIM + k] - vfin[T][k];
-        p.vjp[(walker0 * N + col[T]) * DIM + k] = fmaf(c_s[T], cot[T][k], c_in[T] * yb);
+        if (wr) p.vjp[(walker0 * N + col[T]) * DIM + k] = fmaf(c_s[T], cot[T][k], c_in[T] * yb);
         if (want_h) dhacc[T] = fmaf((-0.5f * c_in[T] / (1.0f + hvv[T])) * yb, xin[T][k], dhacc[T]);  // through c_in(h) x
       }
     }
@@ -543,16 +573,31 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
         if (!(valid[T] && hh == 0 && nodei[T] == 0)) continue;
         float sum = 0.f;
         for (int q = 0; q < N; ++q) sum += red[col[T] + q] + red[C::NCOLP + col[T] + q];
-        p.dot_h[walker0 + col[T] / N] = sum;
+        if (!p.mark || p.mark[walker0 + col[T] / N]) p.dot_h[walker0 + col[T] / N] = sum;
       }
       wave_lds_fence();
     }
   }
 }
 
+// marks the walkers whose results of the f16-path launch are not finite (one thread per walker)
+__global__ void vjp_mark_kernel(const float* __restrict__ vjp, const float* __restrict__ dot_h, const float* __restrict__ out,
+                                long long B, int D, int* __restrict__ mark, int* __restrict__ flag) {
+  const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= B) return;
+  bool bad = dot_h && !__builtin_isfinite(dot_h[w]);
+  for (int k = 0; k < D; ++k) {
+    bad = bad || !__builtin_isfinite(vjp[w * D + k]);
+    if (out) bad = bad || !__builtin_isfinite(out[w * D + k]);
+  }
+  mark[w] = bad ? 1 : 0;
+  if (bad) *flag = 1;
+}
+
 struct VjpShape {
   int n, dim, G, waves;
-  void (*kernel[2])(VjpParams);  // [FIXED]
+  void (*kernel[2])(VjpParams);  // [FIXED], bf16x3 edge GEMMs (also the repair pass)
+  void (*kernel16[2])(VjpParams);  // [FIXED], f16 two-piece edge GEMMs
   size_t (*lds_bytes)(int);
   size_t (*ws_f)(int);
 };
@@ -561,7 +606,8 @@ static size_t vjp_lds_bytes_of(int L) { return VjpCfg<N, DIM, G, WAVES>::lds_byt
 template <int N, int DIM, int G, int WAVES>
 static size_t vjp_ws_f_of(int L) { return VjpCfg<N, DIM, G, WAVES>::ws_f(L); }
 #define PITA_VJP_SHAPE(N, DIM, G, WAVES)                                                         \
-  VjpShape { N, DIM, G, WAVES, {egnn_vjp_kernel<N, DIM, G, WAVES, false>, egnn_vjp_kernel<N, DIM, G, WAVES, true>}, \
+  VjpShape { N, DIM, G, WAVES, {egnn_vjp_kernel<N, DIM, G, WAVES, false, 1>, egnn_vjp_kernel<N, DIM, G, WAVES, true, 1>}, \
+             {egnn_vjp_kernel<N, DIM, G, WAVES, false, 2>, egnn_vjp_kernel<N, DIM, G, WAVES, true, 2>}, \
              vjp_lds_bytes_of<N, DIM, G, WAVES>, \
              vjp_ws_f_of<N, DIM, G, WAVES> }
 static const VjpShape kVjpShapes[] = {
@@ -592,28 +638,66 @@ extern "C" int pita_egnn_vjp(pita_egnn_t* net, const float* h, const float* x, c
   p.coord_scale = net->cfg.coords_range / (float)net->cfg.n_layers;
   p.B = B; p.h = h; p.x = x; p.beta = beta; p.cot = cot; p.out = out; p.vjp = vjp; p.dot_h = dot_h;
   const size_t lds = s->lds_bytes(p.n_layers);
-  const auto kernel = s->kernel[(p.attention && p.tanh_on && dot_h) ? 1 : 0];
-  static thread_local PerDevice<const void*> configured_on;  // the opt-in is per device
-  const void*& configured = configured_on.get();
-  if (configured != (const void*)kernel) {
-    PITA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = (const void*)kernel;
-  }
+  const int fixed = (p.attention && p.tanh_on && dot_h) ? 1 : 0;
+  static const bool force_bf16 = getenv("PITA_VJP_BF16") != nullptr;  // development aid: A/B against the bf16x3 edge GEMMs
+  const bool f16 = net->cfg.precision == 2 && !force_bf16;
+  p.mats16h = net->d_mats16h;
+  hipStream_t st = (hipStream_t)stream;
+  static thread_local PerDevice<const void*> configured_on[2];  // the opt-in is per device
+  auto configure = [&](const void* k, int slot) -> int {
+    const void*& configured = configured_on[slot].get();
+    if (configured != k) {
+      PITA_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      configured = k;
+    }
+    return PITA_OK;
+  };
   const long long ngroups = (B + s->G - 1) / s->G;
   long long want = (ngroups + s->waves - 1) / s->waves;
   const long long cap = net->n_cu;  // one 4-wave block per CU (one wave per SIMD)
   const unsigned grid = (unsigned)(want < cap ? want : cap);
   const size_t need = sizeof(float) * s->ws_f(p.n_layers) * (size_t)grid * s->waves;
   if (net->ws_bytes < need) {  // checkpoint scratch, owned by the handle (one stream at a time, see pita_hip.h)
-    PITA_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    PITA_HIP_CHECK(hipStreamSynchronize(st));
     (void)hipFree(net->d_ws);
     net->d_ws = nullptr; net->ws_bytes = 0;
     PITA_HIP_CHECK(hipMalloc(&net->d_ws, need));
     net->ws_bytes = need;
   }
   p.ws = net->d_ws;
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(s->waves * 64), lds, (hipStream_t)stream, p);
+  const auto kernel = s->kernel[fixed];
+  if (!f16) {
+    const int rc = configure(reinterpret_cast<const void*>(kernel), 0);
+    if (rc != PITA_OK) return rc;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(s->waves * 64), lds, st, p);
+    PITA_LAUNCH_CHECK();
+    return PITA_OK;
+  }
+  // f16 edge GEMMs first; walkers that came out non-finite are marked and recomputed by the bf16x3 kernel, which returns
+  // at once when nothing was marked
+  if (sizeof(int) * ((size_t)B + 16) > net->vjp_mark_bytes) {
+    PITA_HIP_CHECK(hipStreamSynchronize(st));
+    (void)hipFree(net->d_vjp_mark);
+    net->d_vjp_mark = nullptr; net->vjp_mark_bytes = 0;
+    PITA_HIP_CHECK(hipMalloc(&net->d_vjp_mark, sizeof(int) * ((size_t)B + 16)));
+    net->vjp_mark_bytes = sizeof(int) * ((size_t)B + 16);
+  }
+  int* mark = net->d_vjp_mark;
+  int* flag = mark + B;
+  PITA_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), st));
+  const auto kernel16 = s->kernel16[fixed];
+  int rc = configure(reinterpret_cast<const void*>(kernel16), 1);
+  if (rc != PITA_OK) return rc;
+  hipLaunchKernelGGL(kernel16, dim3(grid), dim3(s->waves * 64), lds, st, p);
+  PITA_LAUNCH_CHECK();
+  hipLaunchKernelGGL(vjp_mark_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, vjp, dot_h, out, (long long)B,
+                     net->cfg.n_particles * net->cfg.n_dim, mark, flag);
+  PITA_LAUNCH_CHECK();
+  p.mark = mark;
+  p.flag = flag;
+  rc = configure(reinterpret_cast<const void*>(kernel), 0);
+  if (rc != PITA_OK) return rc;
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(s->waves * 64), lds, st, p);
   PITA_LAUNCH_CHECK();
   return PITA_OK;
 }

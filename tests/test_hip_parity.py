@@ -1971,6 +1971,35 @@ def test_vjp_vs_oracle(pa, golden):
                                            atol=1e-4 * float(dj.abs().mean()))
 
 
+def test_vjp_f16_edge_gemms_and_marked_walker_repair(pa, golden):
+    """pita_egnn_vjp runs its four per-edge primal GEMMs on the f16 two-piece path (precision-2 handles) and hands the
+    walkers whose activations leave the f16 range to the bf16x3 instantiation: the two paths agree to fp32 rounding; a
+    walker with beta = 1e7 comes out finite and bit-equal to a bf16x3-only handle's result; its neighbours keep the
+    f16 path's bits; ragged groups (7 walkers per wave) around the marked walker are untouched."""
+    w = golden("egnn_weights_trainedlike.npz")
+    n, d, B = 13, 3, 45
+    net = make_net(pa, n, d, w)
+    net_b = make_net(pa, n, d, w, precision="bf16x3")  # handle whose reverse-mode launch is the bf16x3 kernel alone
+    gen = torch.Generator().manual_seed(77)
+    h = torch.tensor([0.01, 0.3, 2.0, 40.0, 900.0])[torch.arange(B) % 5].cuda()
+    x = O.remove_mean(torch.randn(B, n * d, generator=gen) * (1 + h.cpu().sqrt())[:, None], n, d).cuda()
+    beta = (torch.rand(B, generator=gen) + 0.7).cuda()
+    D0, v0, dh0 = net.vjp(h, x, beta, want_dot_h=True)
+    assert torch.isfinite(v0).all() and torch.isfinite(dh0).all()
+    hot = beta.clone()
+    hot[17] = 1.0e7
+    D1, v1, dh1 = net.vjp(h, x, hot, want_dot_h=True)
+    keep = torch.arange(B) != 17
+    assert torch.equal(v1[keep], v0[keep]) and torch.equal(dh1[keep], dh0[keep]) and torch.equal(D1[keep], D0[keep])
+    Db, vb, dhb = net_b.vjp(h, x, beta, want_dot_h=True)
+    assert rel(v0, vb) < 5e-6 and not torch.equal(v0, vb)
+    np.testing.assert_allclose(dh0.cpu().numpy(), dhb.cpu().numpy(), rtol=2e-5, atol=2e-5 * float(dhb.abs().mean()))
+    Dh, vh, dhh = net_b.vjp(h, x, hot, want_dot_h=True)
+    assert torch.equal(v1[17].view(torch.int32), vh[17].view(torch.int32))
+    assert torch.equal(dh1[17:18].view(torch.int32), dhh[17:18].view(torch.int32))
+    assert torch.equal(D1[17].view(torch.int32), Dh[17].view(torch.int32))
+
+
 @pytest.mark.parametrize("variant", ["no_attention", "no_tanh", "layers2"])
 def test_vjp_network_variants(pa, golden, variant):
     """The reverse-mode kernel's run-time instantiation (gate off, tanh off, two layers; the compile-time path covers
