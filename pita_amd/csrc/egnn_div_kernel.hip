@@ -408,7 +408,8 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_kernel(DivParams p) {
 //   [pos: POSF] then per tile T: [edge dd = 1..N-1: nv(l) x 1024 vectors | 8 x 64 scalars] [gn: 1024]
 // scalar slots: 0 cs, 1 dcs_f (incl. the tangent scales), 2 att, 3 att (1 - att), 4 vcdmu | qr, 5 qe.  Middle-layer
 // records (round 4): vector 1 is att (g2 o .) -- the gate folded into the cached SiLU derivative --, slot 3 is 1 - att,
-// and slots 4..7 hold the edge's geometry as [column 32][df[3], inv, e0[3], hsq] so that no tangent wave recomputes it.  The position
+// and slots 4..7 hold the edge's geometry as [column 32][df[3], inv, e0[3], hsq] so that no tangent wave recomputes it;
+// first / last layer records keep it as [column 32][df[3], inv] in slots 2-3 and [column 32][e0[3], hsq] in slots 6-7.  The position
 // block carries, behind the NT x 32 x DIM positions, c_skip and c_out c_in of every column (layer 0's block is the one
 // read).  Every item is a whole number of 1 KB chunks and a group's items lie in the order the tangent sweep consumes
 // them, so the block-shared tangent kernel can stream a group as plain 1 KB pieces.
@@ -727,8 +728,18 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) egnn_div_fast_kernel(DivParam
           if (cscal) {
             cscal[lane] = cs;
             cscal[64 + lane] = dcs_f;
-            cscal[128 + lane] = att;
-            cscal[192 + lane] = (first || last) ? datt_f : (p.attention ? 1.0f - att : 0.0f);  // middle: the gate rides in g2
+            if (first || last) {
+              // first / last layer records: the edge's geometry [column][df | inv] in slots 2-3, [column][e0 | hsq] in
+              // slots 6-7 (their tangent sweeps read neither the gate nor its derivative)
+              f32x4 gq = {0.f, 0.f, 0.f, hh ? hsq : inv};
+              gq.x = hh ? e0[0] : df[0];
+              gq.y = hh ? e0[1] : df[1];
+              if (DIM > 2) gq.z = hh ? e0[DIM > 2 ? 2 : 0] : df[DIM > 2 ? 2 : 0];
+              *reinterpret_cast<f32x4*>(cscal + (hh ? 384 : 128) + cl * 4) = gq;
+            } else {
+              cscal[128 + lane] = att;
+              cscal[192 + lane] = p.attention ? 1.0f - att : 0.0f;  // the gate itself rides in g2
+            }
           }
           float dcs[K];
           if (first) {
@@ -1018,7 +1029,6 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_tangent_kernel(DivPara
 #pragma unroll
       for (int q = 0; q < K; ++q) dhf[T][q] = zero16;
     }
-    for (int i = lane; i < C::POS_F; i += 64) pos0[i] = cgrp[i];  // layer 0's entry positions are pos0
     wave_lds_fence();
 
     int cur = 0;
@@ -1026,8 +1036,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_tangent_kernel(DivPara
       const unsigned* mats16h = p.mats16h + (size_t)l * M_COUNT * MAT_WH;
       const bool first = (l == 0), last = (l == L - 1) && !first;
       const float* clay = cgrp + CA::layer_off(l, L);
-      for (int i = lane; i < C::POS_F; i += 64) posc[i] = clay[i];
-      if (!first) {
+      if (!first) {  // (the edges' geometry comes with their records: the layer's position block is not read here)
         WFrag<2> wb;
         wb.load(nullptr, mats16h, M_WB, lane);
 #pragma unroll
@@ -1062,12 +1071,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_tangent_kernel(DivPara
           }
         }
         f32x16 dagg[K];
-        float dxacc[K][DIM], pown[DIM], p0own[DIM];
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) {
-          pown[k] = posc[col[T] * DIM + k];
-          p0own[k] = pos0[col[T] * DIM + k];
-        }
+        float dxacc[K][DIM];
 #pragma unroll
         for (int d = 0; d < K; ++d) {
           dagg[d] = zero16;
@@ -1093,17 +1097,14 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_tangent_kernel(DivPara
             if constexpr (DIM > 2) { df[DIM - 1] = ga.z; e0[DIM - 1] = gb.z; }
             inv = ga.w;
             hsq = gb.w;
-          } else {
-            float radial = 0.f;
-#pragma unroll
-            for (int k = 0; k < DIM; ++k) {
-              df[k] = pown[k] - posc[cj * DIM + k];
-              radial = fmaf(df[k], df[k], radial);
-              e0[k] = p0own[k] - pos0[cj * DIM + k];
-            }
-            const float sq = __builtin_amdgcn_sqrtf(radial + 1e-8f);
-            inv = __builtin_amdgcn_rcpf(sq + 1.0f);
-            hsq = 0.5f * __builtin_amdgcn_rcpf(sq);
+          } else {  // first / last layer records: slots 2-3 and 6-7
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(cscal + 128 + cl * 4);
+            const f32x4 gb = *reinterpret_cast<const f32x4*>(cscal + 384 + cl * 4);
+            df[0] = ga.x; e0[0] = gb.x;
+            df[1] = ga.y; e0[1] = gb.y;
+            if constexpr (DIM > 2) { df[DIM - 1] = ga.z; e0[DIM - 1] = gb.z; }
+            inv = ga.w;
+            hsq = gb.w;
           }
           float u[DIM];
 #pragma unroll
@@ -1559,12 +1560,7 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
       const int nwm = first ? 0 : (last ? 2 : 3);  // matrices ahead of the positions
       begin_item();
       {
-        const float* ipos = item + nwm * MAT_WH;
-        for (int i = threadIdx.x; i < C::POS_F; i += NW * 64) {
-          const float v = ipos[i];
-          posc[i] = v;
-          if (first) pos0[i] = v;
-        }
+        const float* ipos = item + nwm * MAT_WH;  // (positions: the edges' geometry comes with their records)
         if (first)
           for (int i = threadIdx.x; i < 2 * C::NCOLP; i += NW * 64) cstab[i] = ipos[CA::POSX + i];
       }
@@ -1636,17 +1632,14 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
               if constexpr (DIM > 2) { df[DIM - 1] = ga.z; e0[DIM - 1] = gb.z; }
               inv = ga.w;
               hsq = gb.w;
-            } else {
-              float radial = 0.f;
-#pragma unroll
-              for (int k = 0; k < DIM; ++k) {
-                df[k] = posc[col[T] * DIM + k] - posc[cj * DIM + k];
-                radial = fmaf(df[k], df[k], radial);
-                e0[k] = pos0[col[T] * DIM + k] - pos0[cj * DIM + k];
-              }
-              const float sq = __builtin_amdgcn_sqrtf(radial + 1e-8f);
-              inv = __builtin_amdgcn_rcpf(sq + 1.0f);
-              hsq = 0.5f * __builtin_amdgcn_rcpf(sq);
+            } else {  // first / last layer records: slots 2-3 and 6-7
+              const f32x4 ga = *reinterpret_cast<const f32x4*>(sc + 128 + cl * 4);
+              const f32x4 gb = *reinterpret_cast<const f32x4*>(sc + 384 + cl * 4);
+              df[0] = ga.x; e0[0] = gb.x;
+              df[1] = ga.y; e0[1] = gb.y;
+              if constexpr (DIM > 2) { df[DIM - 1] = ga.z; e0[DIM - 1] = gb.z; }
+              inv = ga.w;
+              hsq = gb.w;
             }
             float u[DIM];
 #pragma unroll
