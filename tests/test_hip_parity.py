@@ -1800,6 +1800,33 @@ def test_jacobian_trace_22_atoms_four_layers(pa, golden):
     np.testing.assert_allclose(tr.cpu().numpy(), acc.cpu().numpy(), rtol=2e-5, atol=2e-5 * scale)
 
 
+@pytest.mark.parametrize("n_layers", [2, 4])
+def test_jacobian_trace_lj55_block_shared_layer_counts(pa, golden, n_layers):
+    """55 particles on the block-shared tangent kernel (two column tiles, 8 waves x 1 direction, the per-ITEM piece table)
+    with fewer and more layers than the reference configs' three: the item sequence, the ring and the table sizes all
+    depend on the depth.  Equal to the trace assembled from single-direction forward-mode launches."""
+    w = {k: T(v) for k, v in golden("egnn_weights_trainedlike.npz").items()}
+    net = pa.EGNN_dynamics(55, 3, hidden_nf=32, n_layers=n_layers, recurrent=True, tanh=True, attention=True,
+                           condition_time=True, condition_temperature=True, agg="sum")
+    sd = net.state_dict()
+    gen = torch.Generator().manual_seed(31 + n_layers)
+    for k in sd:
+        src = w.get(k, w.get(k.replace("gcl_3", "gcl_1")))
+        sd[k] = src.clone() if src is not None and src.shape == sd[k].shape else 0.2 * torch.randn(sd[k].shape, generator=gen)
+    net.load_state_dict(sd)
+    B = 301
+    h = torch.tensor([0.05, 0.8, 12.0])[torch.arange(B) % 3].cuda()
+    x = O.remove_mean(torch.randn(B, 165, generator=gen) * (1 + h.cpu().sqrt())[:, None], 55, 3).cuda()
+    beta = (torch.rand(B, generator=gen) + 0.7).cuda()
+    tr = net.jacobian_trace(h, x, beta)
+    acc = torch.zeros(B, device="cuda")
+    for k in range(165):
+        net.jvp(h, x, beta, direction=k, want_primal=False, want_tangent=False, diag_acc=acc)
+    scale = float(acc.abs().mean()) + 1.0
+    assert torch.isfinite(tr).all()
+    np.testing.assert_allclose(tr.cpu().numpy(), acc.cpu().numpy(), rtol=2e-5, atol=2e-5 * scale)
+
+
 def test_jacobian_trace_in_cache_chunks(golden):
     """A batch whose primal cache exceeds PITA_DIV_CACHE_GB is processed in chunks of walkers; the result does not
     depend on the chunking (the budget is read once per process, so this runs in a child process)."""
