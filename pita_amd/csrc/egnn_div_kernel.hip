@@ -1322,6 +1322,28 @@ __device__ __forceinline__ void glds16s(unsigned lds_byte, const float* sbase, u
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
 }
+// a run of N <= 4 consecutive pieces from one source: ONE m0 / address set-up, the instruction offset advances the
+// global address and the LDS address together (LDS address = m0 + offset + 16 lane)
+template <int N>
+__device__ __forceinline__ void glds16s_run(unsigned lds_byte, const float* sbase, unsigned voff) {
+  unsigned keep;
+  if constexpr (N == 4)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:1024\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:3072\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+  else if constexpr (N == 3)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:1024\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+  else if constexpr (N == 2)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:1024\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+}
 __device__ __forceinline__ f32x16 slot_vec16(const float* rec, int v, int lane) {  // vector v of a record (cache_store16 layout)
   const f32x4* d = reinterpret_cast<const f32x4*>(rec + v * 1024) + lane;
   f32x16 r;
@@ -1470,10 +1492,24 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
         ents = ptab[ri * S + d * PPW + (lane < PPW ? lane : 0)];
       }
       const unsigned dst = ring_byte + (unsigned)(rs * S + d * PPW) * 1024u;
+      // edge items (and the weight runs of the others) are PPW consecutive pieces of one source: one address set-up per
+      // four pieces instead of one per piece -- the loading waves' scalar work is what every other wave waits for
+      const int e0 = __builtin_amdgcn_readlane(ents, 0);
+      if (__builtin_amdgcn_ballot_w64(lane < PPW && ents - lane != e0) == 0ull) {
+        const float* sb = (e0 < 0 ? wsrc : gsrc) + (size_t)(e0 & 0x7fffffff) * 256;
 #pragma unroll
-      for (int q = 0; q < PPW; ++q) {
-        const int ent = __builtin_amdgcn_readlane(ents, q);
-        glds16s(dst + q * 1024u, (ent < 0 ? wsrc : gsrc) + (size_t)(ent & 0x7fffffff) * 256, lane16);
+        for (int q = 0; q < PPW; q += 4) {
+          if (PPW - q >= 4) glds16s_run<4>(dst + q * 1024u, sb + q * 256, lane16);
+          else if (PPW - q == 3) glds16s_run<3>(dst + q * 1024u, sb + q * 256, lane16);
+          else if (PPW - q == 2) glds16s_run<2>(dst + q * 1024u, sb + q * 256, lane16);
+          else glds16s_run<1>(dst + q * 1024u, sb + q * 256, lane16);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) {
+          const int ent = __builtin_amdgcn_readlane(ents, q);
+          glds16s(dst + q * 1024u, (ent < 0 ? wsrc : gsrc) + (size_t)(ent & 0x7fffffff) * 256, lane16);
+        }
       }
     }
     rs = (rs + 1 == NSLOT) ? 0 : rs + 1;
