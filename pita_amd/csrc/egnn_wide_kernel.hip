@@ -1256,10 +1256,13 @@ extern "C" int pita_egnn_wide_vjp(pita_egnn_wide_t* net, const float* h, const f
     if (e != hipSuccess) rc = fail(PITA_EHIP, "pita_egnn_wide_vjp: checkpoint buffer: %s", hipGetErrorString(e));
     else net->vjp_ws_bytes = ws_need;
   }
-  if (rc == PITA_OK &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)(per_wave * waves)) != hipSuccess)
-    rc = fail(PITA_EHIP, "pita_egnn_wide_vjp: cannot reserve %zu B of LDS", per_wave * waves);
+  if (rc == PITA_OK && !net->vjp_attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(per_wave * waves)) != hipSuccess)
+      rc = fail(PITA_EHIP, "pita_egnn_wide_vjp: cannot reserve %zu B of LDS", per_wave * waves);
+    else
+      net->vjp_attr = true;
+  }
   if (rc == PITA_OK) {
     q.ws = net->d_vjp_ws;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(waves * 64), per_wave * waves, (hipStream_t)stream, q);
