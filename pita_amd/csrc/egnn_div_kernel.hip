@@ -1387,7 +1387,6 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
   int* ptab = resw + C::RES_G;                       // [MAX_P] source of every piece of a group's sequence: bit 31 weights / cache, piece offset; then the count
   float* dPB = reinterpret_cast<float*>(ptab + C::MAX_P + 4) + wave * C::WAVE_F;  // [K][PB_F]  DIV_ST x Wb dh_j
   float* dposb = dPB + K * C::PB_F;                  // [K][2][POS_F]
-  float* dpos0 = dposb + 2 * K * C::POS_F;           // [K][POS_F]
   const unsigned ring_byte = (unsigned)(size_t)ring;
   const f32x16 zero16 = {0};
   // this wave's directions
@@ -1567,6 +1566,14 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
       return (valid[T] && q < myndir && nodei[T] * DIM + k == mydir0 + q) ? 1.0f : 0.f;
     };
     f32x16 dhf[NT][K];
+    int dnode[K], dk[K];  // this wave's directions as (node, component); node -1: no such direction
+    float si[NT][K];      // 2 [column's node == dnode]
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      const int dq = mydir0 + q;
+      dnode[q] = (q < myndir) ? dq / DIM : -1;
+      dk[q] = dq - (dq / DIM) * DIM;
+    }
 #pragma unroll
     for (int T = 0; T < NT; ++T) {
       col[T] = T * 32 + cl;
@@ -1574,15 +1581,14 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
       nodei[T] = col[T] - w * N;
       valid[T] = col[T] < ncol;
 #pragma unroll
+      for (int q = 0; q < K; ++q) si[T][q] = (valid[T] && nodei[T] == dnode[q]) ? 2.0f : 0.0f;
+#pragma unroll
       for (int k = 0; k < DIM; ++k)
 #pragma unroll
         for (int q = 0; q < K; ++q) {
           const float v = unit(T, q, k);
           dposi[T][q][k] = v;
-          if (hh == 0) {
-            dpos0[q * C::POS_F + col[T] * DIM + k] = v;
-            dposb[(2 * q) * C::POS_F + col[T] * DIM + k] = v;
-          }
+          if (hh == 0) dposb[(2 * q) * C::POS_F + col[T] * DIM + k] = v;
         }
 #pragma unroll
       for (int q = 0; q < K; ++q) dhf[T][q] = zero16;
@@ -1685,15 +1691,18 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
             for (int d = 0; d < K; ++d) {
               const float* dposcur = dposb + (2 * d + cur) * C::POS_F;
               dradial[d] = 0.f;
-              dea[d] = 0.f;
 #pragma unroll
               for (int k = 0; k < DIM; ++k) {
                 ddf[d][k] = dposi[T][d][k] - dposcur[cj * DIM + k];
                 dradial[d] = fmaf(df[k], ddf[d][k], dradial[d]);
-                dea[d] = fmaf(e0[k], unit(T, d, k) - dpos0[d * C::POS_F + cj * DIM + k], dea[d]);
               }
               dradial[d] *= 2.0f;
-              dea[d] *= 2.0f;
+              // tangent of the frozen edge attribute |x_i - x_j|^2 along the unit direction (node dnode, component dk):
+              // 2 e0[dk] ([i == dnode] - [j == dnode]) -- no per-direction table of the input displacement
+              float e0k = e0[0];
+#pragma unroll
+              for (int k = 1; k < DIM; ++k) e0k = (dk[d] == k) ? e0[k] : e0k;
+              dea[d] = e0k * (si[T][d] - ((valid[T] && j == dnode[d]) ? 2.0f : 0.0f));
             }
             float dcs[K];
             if constexpr (first) {
