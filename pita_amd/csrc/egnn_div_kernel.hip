@@ -485,6 +485,7 @@ template <int N, int DIM, int G, int WAVES, int K, int DAL, int OCC = 1>
 __global__ void __launch_bounds__(WAVES * 64, OCC) egnn_div_fast_kernel(DivParams p) {
   using C = DivCfg<N, DIM, G, WAVES, K, DAL>;
   constexpr int NT = C::NT;
+  constexpr int KA = K > 0 ? K : 1;  // array extents (K = 0, the cache writer: no direction, the loops over d vanish)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int L = p.n_layers;
   const int vec_f = C::vec_f(L);
@@ -495,12 +496,12 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) egnn_div_fast_kernel(DivParam
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cl = lane & 31, hh = lane >> 5;
   float* PB = lds + vec_f + wave * C::WAVE_F;
-  float* dPB = PB + C::PB_F;                       // [K][PB_F]  DIV_ST x Wb dh_j
-  float* dA = dPB + K * C::PB_F;                   // [K][PB_F]  DIV_ST x Wa dh_i (DAL = 1; else registers)
+  float* dPB = PB + C::PB_F;                       // [KA][PB_F]  DIV_ST x Wb dh_j
+  float* dA = dPB + K * C::PB_F;                   // [KA][PB_F]  DIV_ST x Wa dh_i (DAL = 1; else registers)
   float* posb = dA + DAL * K * C::PB_F;            // [2][POS_F]
   float* pos0 = posb + 2 * C::POS_F;
-  float* dposb = pos0 + C::POS_F;                  // [K][2][POS_F]
-  float* dpos0 = dposb + 2 * K * C::POS_F;         // [K][POS_F]
+  float* dposb = pos0 + C::POS_F;                  // [KA][2][POS_F]
+  float* dpos0 = dposb + 2 * K * C::POS_F;         // [KA][POS_F]
   const float* vemb = lds;
   const f32x16 zero16 = {0};
 
@@ -519,8 +520,8 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) egnn_div_fast_kernel(DivParam
     int col[NT], nodei[NT];
     bool valid[NT];
     float c_s[NT], c_in[NT], c_out[NT];
-    float posi[NT][DIM], p0i[NT][DIM], dposi[NT][K][DIM], dp0i[NT][K][DIM];
-    f32x16 hf[NT], dhf[NT][K];
+    float posi[NT][DIM], p0i[NT][DIM], dposi[NT][KA][DIM], dp0i[NT][KA][DIM];
+    f32x16 hf[NT], dhf[NT][KA];
 #pragma unroll
     for (int T = 0; T < NT; ++T) {
       col[T] = T * 32 + cl;
@@ -623,7 +624,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) egnn_div_fast_kernel(DivParam
 #pragma unroll
       for (int T = 0; T < NT; ++T) {
         if (T >= ntile) continue;
-        f32x16 Ai, dAr[DAL ? 1 : K];
+        f32x16 Ai, dAr[DAL ? 1 : KA];
         {
           WFrag<2> wa;
           wa.load(nullptr, mats16h, M_WA, lane);
@@ -645,8 +646,8 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) egnn_div_fast_kernel(DivParam
           }
         }
         wave_lds_fence();
-        f32x16 agg = {0}, dagg[K];
-        float xacc[DIM], dxacc[K][DIM];
+        f32x16 agg = {0}, dagg[KA];
+        float xacc[DIM], dxacc[KA][DIM];
 #pragma unroll
         for (int k = 0; k < DIM; ++k) xacc[k] = 0.f;
 #pragma unroll
@@ -707,7 +708,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) egnn_div_fast_kernel(DivParam
             xacc[k] = fmaf(u[k], cs, xacc[k]);
           }
           // per-direction geometry
-          float ddf[K][DIM], dradial[K], dea[K];
+          float ddf[KA][DIM], dradial[KA], dea[KA];
 #pragma unroll
           for (int d = 0; d < K; ++d) {
             const float* dposcur = dposb + (2 * d + cur) * C::POS_F;
@@ -741,7 +742,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) egnn_div_fast_kernel(DivParam
               cscal[192 + lane] = p.attention ? 1.0f - att : 0.0f;  // the gate itself rides in g2
             }
           }
-          float dcs[K];
+          float dcs[KA];
           if (first) {
             // every direction: dz1 = dradial_d (w_r + w_e) (radial == edge_attr, dh == 0): one shared tangent chain
             f32x16 du_ = w2f.mul(g1 * lds_vec16(vd), zero16);
@@ -848,7 +849,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) egnn_div_fast_kernel(DivParam
           WFrag<2> wn;
           wn.load(nullptr, mats16h, M_WN1A, lane);
           f32x16 zn = wn.mul(hf[T], lds_vec16(vl + V_BN1 * EH));
-          f32x16 dzn[K];
+          f32x16 dzn[KA];
 #pragma unroll
           for (int d = 0; d < K; ++d) dzn[d] = first ? zero16 : wn.mul(dhf[T][d], zero16);
           wn.load(nullptr, mats16h, M_WN1B, lane);
@@ -878,8 +879,8 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) egnn_div_fast_kernel(DivParam
 
     // dD_d = c_s + c_out c_in (dF - mean dF)_d  (unit position tangents); the K terms of a walker are summed by ONE lane,
     // added only when finite, otherwise the walker is marked for the bf16x3 kernel
-    float* dscr = dPB;          // [K][NCOLP*DIM]
-    float* tsl = PB;            // [G][K] terms (the partner table is free now)
+    float* dscr = dPB;          // [KA][NCOLP*DIM]
+    float* tsl = PB;            // [G][KA] terms (the partner table is free now)
 #pragma unroll
     for (int T = 0; T < NT; ++T)
 #pragma unroll
@@ -909,19 +910,25 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) egnn_div_fast_kernel(DivParam
     bool bad[NT];
 #pragma unroll
     for (int T = 0; T < NT; ++T) {
-      const int w = col[T] / N;
-      float sum = 0.f;
+      bad[T] = false;
+      if constexpr (K > 0) {
+        const int w = col[T] / N;
+        float sum = 0.f;
 #pragma unroll
-      for (int d = 0; d < K; ++d) sum += tsl[(valid[T] ? w : 0) * K + d];
-      bad[T] = valid[T] && !__builtin_isfinite(sum);
-      if (valid[T] && hh == 0 && nodei[T] == 0) {
-        if (!bad[T]) p.diag_acc[walker0 + w] += sum;
-        p.mark[walker0 + w] = bad[T] ? 1 : 0;
-        if (bad[T] && p.bad_flag) *p.bad_flag = p.bad_seq;
+        for (int d = 0; d < K; ++d) sum += tsl[(valid[T] ? w : 0) * K + d];
+        bad[T] = valid[T] && !__builtin_isfinite(sum);
+        if (valid[T] && hh == 0 && nodei[T] == 0) {
+          if (!bad[T]) p.diag_acc[walker0 + w] += sum;
+          p.mark[walker0 + w] = bad[T] ? 1 : 0;
+          if (bad[T] && p.bad_flag) *p.bad_flag = p.bad_seq;
+        }
       }
     }
     wave_lds_fence();
-    if (p.out) {  // primal denoiser D = c_s x + c_out (F - mean F), F = pos^L - pos^0 (x = pos^0 / c_in)
+    // primal denoiser D = c_s x + c_out (F - mean F), F = pos^L - pos^0 (x = pos^0 / c_in).  A launch without directions
+    // (K = 0: the cache writer) marks by the primal itself: a non-finite position anywhere in the walker reaches every
+    // column through the mean
+    if (p.out || K == 0) {
       float* scr = PB;
 #pragma unroll
       for (int T = 0; T < NT; ++T)
@@ -934,13 +941,28 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) egnn_div_fast_kernel(DivParam
       for (int T = 0; T < NT; ++T) {
         if (!(valid[T] && hh == 0) || bad[T]) continue;
         const int cb = col[T] - nodei[T];
+        float F[DIM];
+        bool fin = true;
 #pragma unroll
         for (int k = 0; k < DIM; ++k) {
           float sum = 0.f;
           for (int q = 0; q < N; ++q) sum += scr[(cb + q) * DIM + k];
-          const float F = (posi[T][k] - p0i[T][k]) - sum / (float)N;
-          const long long gi = (walker0 * N + col[T]) * DIM + k;
-          p.out[gi] = fmaf(c_s[T], p.x[gi], c_out[T] * F);
+          F[k] = (posi[T][k] - p0i[T][k]) - sum / (float)N;
+          fin = fin && __builtin_isfinite(F[k]);
+        }
+        if constexpr (K == 0) {
+          if (nodei[T] == 0) {
+            p.mark[walker0 + col[T] / N] = fin ? 0 : 1;
+            if (!fin && p.bad_flag) *p.bad_flag = p.bad_seq;
+          }
+          if (!fin) continue;
+        }
+        if (p.out) {
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) {
+            const long long gi = (walker0 * N + col[T]) * DIM + k;
+            p.out[gi] = fmaf(c_s[T], p.x[gi], c_out[T] * F[k]);
+          }
         }
       }
       wave_lds_fence();
@@ -1909,14 +1931,14 @@ static const DivShape kDivShapes[] = {
 // in LDS), K = 4: 102.8 ms (more register shuffling; no longer fits in LDS), 39 single-direction JVP launches: 126 ms.
 // PITA_DIV_K selects an alternative for experiments.
 static const DivShape kDivAlt[] = {PITA_DIV_SHAPE(13, 3, 2, 4, 2)};
-// cache writers for the block-shared tangent kernel: the first launch of a trace carries ONE direction (the tangent-only
-// launches take 16 each, so 1 + 13 + 13 + 12 beats 3 + 16 + 16 + 4 for LJ13: the primal launch is lighter and the three
-// streams are balanced)
+// cache writers for the block-shared tangent kernel: the first launch of a trace carries NO direction (round 4; a
+// direction costs 0.9 ms in this one-wave-per-SIMD launch and 0.17 ms in a tangent-only launch, which take 16 each: 0 + 13
+// + 13 + 13 for LJ13; rounds 2-3: 1 + 13 + 13 + 12) and marks out-of-range walkers by their primal
 // (measured with two blocks per CU, i.e. two waves per SIMD at 256 registers: 976 B/lane of scratch, the launch takes
 // 14 ms instead of 5 -- the primal's adjoint factors plus one tangent chain need the 492 registers it uses)
 #define PITA_DIV_WRITER_SHAPE(N, DIM, G, WAVES) \
-  DivShape { N, DIM, G, WAVES, 1, nullptr, egnn_div_fast_kernel<N, DIM, G, WAVES, 1, 0, 1>, \
-             div_lds_bytes_of<N, DIM, G, WAVES, 1, 0>, 1 }
+  DivShape { N, DIM, G, WAVES, 0, nullptr, egnn_div_fast_kernel<N, DIM, G, WAVES, 0, 0, 1>, \
+             div_lds_bytes_of<N, DIM, G, WAVES, 0, 0>, 1 }
 static const DivShape kDivWriters[] = {PITA_DIV_WRITER_SHAPE(13, 3, 2, 4), PITA_DIV_WRITER_SHAPE(22, 3, 1, 4)};
 static const DivShape* find_div_writer(int n, int dim) {
   static const bool off = getenv("PITA_DIV_NOWRITER") != nullptr;  // development aid
@@ -2049,7 +2071,7 @@ extern "C" int pita_egnn_div_work(const pita_egnn_t* net, double* mfma16_per_wal
     const DivShape* wr = (ts0 && ts0->shared) ? find_div_writer(N, s->dim) : nullptr;
     if (wr && wr->G == s->G && wr->waves == s->waves && D > s->K) K = wr->K;
   }
-  double launches = (D + K - 1) / K;
+  double launches = K > 0 ? (D + K - 1) / K : 0;
   const double tiles_per_walker = (double)((s->G * N + 31) / 32) / s->G;
   double m16 = 0, m32 = 0, t16 = 0, t32 = 0;  // per tile: one K-direction launch with primal; one tangent-only direction
   const bool fast = div_fast_enabled(net);
@@ -2277,6 +2299,11 @@ extern "C" int pita_egnn_jacobian_trace(pita_egnn_t* net, const float* h, const 
       DivParams r = p;
       r.repair = 1;
       r.cache = nullptr;
+      if (ndir == 0) {  // a launch without directions: only the denoiser of the marked walkers is recomputed
+        if (!out) return PITA_OK;
+        r.dir0 = 0; r.ndir = 0; r.out = out;
+        return div_launch(s, s->kernel, net, r, stream);
+      }
       for (int d0 = 0; d0 < ndir; d0 += s->K) {
         r.dir0 = dir0 + d0;
         r.ndir = (ndir - d0) < s->K ? (ndir - d0) : s->K;
