@@ -103,13 +103,15 @@ struct WFrag<1> {
     for (int st = 0; st < 2; ++st)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
         const unsigned a = __float_as_uint(in[8 * st + 2 * q]), b = __float_as_uint(in[8 * st + 2 * q + 1]);
         const unsigned a1 = a & 0xFFFF0000u, b1 = b & 0xFFFF0000u;
-        const unsigned ar = __float_as_uint(__uint_as_float(a) - __uint_as_float(a1));  // exact
-        const unsigned br = __float_as_uint(__uint_as_float(b) - __uint_as_float(b1));
+        // the two remainders of a pair as ONE packed subtraction (exact either way)
+        const f32x2_t r1 = f32x2_t{__uint_as_float(a), __uint_as_float(b)} - f32x2_t{__uint_as_float(a1), __uint_as_float(b1)};
+        const unsigned ar = __float_as_uint(r1.x), br = __float_as_uint(r1.y);
         const unsigned a2 = ar & 0xFFFF0000u, b2 = br & 0xFFFF0000u;
-        const unsigned a3 = __float_as_uint(__uint_as_float(ar) - __uint_as_float(a2));  // exact; truncated on packing
-        const unsigned b3 = __float_as_uint(__uint_as_float(br) - __uint_as_float(b2));
+        const f32x2_t r2 = r1 - f32x2_t{__uint_as_float(a2), __uint_as_float(b2)};  // exact; truncated on packing
+        const unsigned a3 = __float_as_uint(r2.x), b3 = __float_as_uint(r2.y);
         x[0][st][q] = __builtin_amdgcn_perm(b1, a1, 0x07060302u);  // {hi16(b), hi16(a)}
         x[1][st][q] = __builtin_amdgcn_perm(b2, a2, 0x07060302u);
         x[2][st][q] = __builtin_amdgcn_perm(b3, a3, 0x07060302u);
