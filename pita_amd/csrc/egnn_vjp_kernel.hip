@@ -593,18 +593,23 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
   }
 }
 
-// marks the walkers whose results of the f16-path launch are not finite (one thread per walker)
-__global__ void vjp_mark_kernel(const float* __restrict__ vjp, const float* __restrict__ dot_h, const float* __restrict__ out,
-                                long long B, int D, int* __restrict__ mark, int* __restrict__ flag) {
-  const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+// marks the walkers whose results of the f16-path launch are not finite (one wavefront per walker: coalesced rows)
+__global__ void __launch_bounds__(256) vjp_mark_kernel(const float* __restrict__ vjp, const float* __restrict__ dot_h,
+                                                       const float* __restrict__ out, long long B, int D,
+                                                       int* __restrict__ mark, int* __restrict__ flag) {
+  const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (w >= B) return;
-  bool bad = dot_h && !__builtin_isfinite(dot_h[w]);
-  for (int k = 0; k < D; ++k) {
+  bool bad = lane == 0 && dot_h && !__builtin_isfinite(dot_h[w]);
+  for (int k = lane; k < D; k += 64) {
     bad = bad || !__builtin_isfinite(vjp[w * D + k]);
     if (out) bad = bad || !__builtin_isfinite(out[w * D + k]);
   }
-  mark[w] = bad ? 1 : 0;
-  if (bad) *flag = 1;
+  const bool any = __builtin_amdgcn_ballot_w64(bad) != 0ull;
+  if (lane == 0) {
+    mark[w] = any ? 1 : 0;
+    if (any) *flag = 1;
+  }
 }
 
 struct VjpShape {
@@ -703,7 +708,7 @@ extern "C" int pita_egnn_vjp(pita_egnn_t* net, const float* h, const float* x, c
   if (rc != PITA_OK) return rc;
   hipLaunchKernelGGL(kernel16, dim3(grid), dim3(s->waves * 64), lds, st, p);
   PITA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(vjp_mark_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, vjp, dot_h, out, (long long)B,
+  hipLaunchKernelGGL(vjp_mark_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, vjp, dot_h, out, (long long)B,
                      net->cfg.n_particles * net->cfg.n_dim, mark, flag);
   PITA_LAUNCH_CHECK();
   p.mark = mark;
