@@ -43,6 +43,12 @@ struct DivParams {
   long long cache_waves;  // block-shared tangent kernel: waves of the launch that wrote the cache (its group layout)
   float* diag_acc;    // [B] += sum_k dD_k[b, dir0 + k]
   float* out;         // [B, D] denoiser D of the primal (nullable: the caller asks for it with the first launch only)
+  int no_mean;        // != 0: the launch is part of a FULL trace (pita_egnn_jacobian_trace) and leaves out the mean-free
+                      // projection's share of each diagonal entry, -(1/N) sum_i d pos^L_{i,k} / d x_{i0,k}: summed over all
+                      // N dim directions these shares cancel exactly -- the network sees positions through differences
+                      // only, so moving every particle along k moves every pos^L_{i,k} by the same amount,
+                      // sum_{i0} d pos^L_{i,k} / d x_{i0,k} = 1, and sum_d (sum_i d pos^L_{i,k_d} - 1) = dim N - N dim = 0.
+                      // What is left of a direction's term needs the tangent of ONE output coordinate only.
 };
 
 template <int N, int DIM, int G, int WAVES, int K, int DAL = 1>  // DAL: Wa dh_i tables in LDS (1) or in registers (0)
@@ -362,7 +368,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_kernel(DivParams p) {
           if (!(mine[T] && hh == 0 && d < p.ndir && nodei[T] * DIM + k == p.dir0 + d)) continue;
           float ds = 0.f;
           for (int q = 0; q < N; ++q) ds += dscr[d * C::POS_F + (cb + q) * DIM + k];
-          const float dF = dposi[T][d][k] - ds / (float)N;
+          const float dF = p.no_mean ? dposi[T][d][k] : dposi[T][d][k] - ds / (float)N;
           // the K owners of one walker are different lanes: the read-modify-writes below would race
           atomicAdd(&p.diag_acc[walker0 + col[T] / N], fmaf(c_out[T], dF, c_s[T]));
         }
@@ -902,7 +908,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) egnn_div_fast_kernel(DivParam
           if (!(valid[T] && hh == 0 && d < p.ndir && nodei[T] * DIM + k == p.dir0 + d)) continue;
           float ds = 0.f;
           for (int q = 0; q < N; ++q) ds += dscr[d * C::POS_F + (cb + q) * DIM + k];
-          const float dF = dposi[T][d][k] - ds / (float)N;
+          const float dF = p.no_mean ? dposi[T][d][k] : dposi[T][d][k] - ds / (float)N;
           tsl[(col[T] / N) * K + d] = fmaf(c_out[T] * c_in[T], dF, c_s[T]);
         }
     }
@@ -1259,7 +1265,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_tangent_kernel(DivPara
           if (!(valid[T] && hh == 0 && d < p.ndir && nodei[T] * DIM + k == p.dir0 + d)) continue;
           float ds = 0.f;
           for (int q = 0; q < N; ++q) ds += dscr[d * C::POS_F + (cb + q) * DIM + k];
-          const float dF = dposi[T][d][k] - ds / (float)N;
+          const float dF = p.no_mean ? dposi[T][d][k] : dposi[T][d][k] - ds / (float)N;
           tsl[(col[T] / N) * K + d] = fmaf(cc[T], dF, c_s[T]);
         }
     }
@@ -1876,7 +1882,7 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
           if (!(valid[T] && hh == 0 && d < myndir && nodei[T] * DIM + k == mydir0 + d)) continue;
           float ds = 0.f;
           for (int q = 0; q < N; ++q) ds += dscr[d * C::POS_F + (cb + q) * DIM + k];
-          const float dF = dposi[T][d][k] - ds / (float)N;
+          const float dF = p.no_mean ? dposi[T][d][k] : dposi[T][d][k] - ds / (float)N;
           tsl[(col[T] / N) * K + d] = fmaf(cstab[C::NCOLP + col[T]], dF, cstab[col[T]]);
         }
     }
@@ -2276,6 +2282,7 @@ extern "C" int pita_egnn_jacobian_trace(pita_egnn_t* net, const float* h, const 
     p.attention = net->cfg.attention; p.tanh_on = net->cfg.tanh; p.feature_layout = net->cfg.feature_layout;
     p.coord_scale = net->cfg.coords_range / (float)L;
     p.B = Bc; p.h = h + b0; p.x = x + b0 * D; p.beta = beta ? beta + b0 : nullptr; p.diag_acc = trace + b0;
+    p.no_mean = 1;  // all D directions are summed: the mean-free projection's shares cancel (DivParams::no_mean)
     // grid of the fast / tangent kernels (identical: the cache is indexed by wave and group)
     const long long ngroups = (Bc + s->G - 1) / s->G;
     long long want = (ngroups + s->waves - 1) / s->waves;
