@@ -1622,6 +1622,31 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
       for (int q = 0; q < K; ++q) dhf[T][q] = zero16;
     }
 
+    // Last layer of a FULL trace (DivParams::no_mean): a direction's term needs the tangent of ONE output coordinate,
+    // (dnode, dk) of every walker -- the edges (dnode, j) only.  Lanes are re-mapped for that layer: lane = (virtual
+    // column, feature half), virtual column = (walker of the group, direction of this wave, record of the item); one
+    // pass per item instead of [records] x [directions] passes over all columns.
+    constexpr int EPI2 = S / 6;  // records per first- / last-layer item
+    static_assert(G * K * EPI2 <= 32, "virtual columns of the last layer");
+    // (the kernel is launched for full traces of networks with at least two layers only: divshr_fits)
+    // (the virtual column's coordinates are recomputed where they are used -- the last layer and the epilogue -- so that
+    // nothing of them stays live across the other layers)
+    auto vcol = [&](int& v_e, int& v_d, int& v_w, int& v_i0, int& v_k0, bool& v_on, int& v_col0, int& v_c0) {
+      v_e = cl % EPI2; v_d = (cl / EPI2) % K; v_w = cl / (EPI2 * K);
+      v_i0 = 0; v_k0 = 0;
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        v_i0 = (v_d == q) ? dnode[q] : v_i0;
+        v_k0 = (v_d == q) ? dk[q] : v_k0;
+      }
+      v_on = active && v_w < nwalk && v_w < G && v_i0 >= 0;
+      v_col0 = v_on ? v_w * N + v_i0 : 0;
+      v_c0 = v_col0 & 31;
+    };
+    float vacc[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) vacc[k] = 0.f;
+
     int cur = 0;
     for (int l = 0; l < L; ++l) {
       const bool first = (l == 0), last = (l == L - 1) && !first;
@@ -1813,10 +1838,73 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
           end_item();
         }
         };
-        if (first) run_edges(std::integral_constant<int, 0>{});
-        else if (last) run_edges(std::integral_constant<int, 2>{});
+        if (last) {
+          int v_e, v_d, v_w, v_i0, v_k0, v_col0, v_c0;
+          bool v_on;
+          vcol(v_e, v_d, v_w, v_i0, v_k0, v_on, v_col0, v_c0);
+          // the virtual column's own Wa dh_i (held by lane (c0, half) of its direction's registers)
+          const bool mine = v_on && (v_col0 >> 5) == T && tile_on;
+          f32x16 dAv = zero16;
+#pragma unroll
+          for (int q = 0; q < K; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float t = __shfl(dAr[q][r], v_c0 + 32 * hh, 64);  // (ds_bpermute)
+              dAv[r] = (v_d == q) ? t : dAv[r];
+            }
+          const float* vdpos = dposb + (2 * v_d + cur) * C::POS_F;
+          const float* vdPB = dPB + v_d * C::PB_F + hh * 16;
+          for (int dd0 = 1; dd0 < N; dd0 += EPI2) {
+            begin_item();
+            const int dd = dd0 + v_e;
+            const bool on = mine && dd < N;
+            int j = v_i0 + (on ? dd : 0);
+            j = (j >= N) ? j - N : j;
+            const int cj = on ? v_w * N + j : 0;
+            const float* rec = item + v_e * (1024 + 512);
+            const float* sc = rec + 1024;
+            const float cs = sc[v_c0], dcs_f = sc[64 + v_c0], qr = sc[256 + v_c0], qe = sc[320 + v_c0];
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(sc + 128 + v_c0 * 4);
+            const f32x4 gb = *reinterpret_cast<const f32x4*>(sc + 384 + v_c0 * 4);
+            float df[DIM], e0[DIM];
+            df[0] = ga.x; e0[0] = gb.x;
+            df[1] = ga.y; e0[1] = gb.y;
+            if constexpr (DIM > 2) { df[DIM - 1] = ga.z; e0[DIM - 1] = gb.z; }
+            const float inv = ga.w, hsq = gb.w;
+            float ddf[DIM], dradial = 0.f, e0k = e0[0];
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+              ddf[k] = vdpos[v_col0 * DIM + k] - vdpos[cj * DIM + k];
+              dradial = fmaf(df[k], ddf[k], dradial);
+              if (k > 0) e0k = (v_k0 == k) ? e0[k] : e0k;
+            }
+            dradial *= 2.0f;
+            const float dea = 2.0f * e0k;  // i is the direction's node, j is not
+            f32x16 qv;
+            {
+              const f32x4* qp = reinterpret_cast<const f32x4*>(rec) + (hh * 32 + v_c0);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const f32x4 t = qp[q * 64];
+                qv[4 * q] = t.x; qv[4 * q + 1] = t.y; qv[4 * q + 2] = t.z; qv[4 * q + 3] = t.w;
+              }
+            }
+            const f32x16 dz1 = dAv + lds_vec16(vdPB + cj * PBS);
+            const float sdot = xhalf_sum(dot16(qv, dz1));
+            const float dcs = dcs_f * fmaf(qr, dradial, fmaf(qe, dea, sdot));
+            const float dnrm = dradial * hsq;
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+              const float u = df[k] * inv;
+              const float du = (ddf[k] - u * dnrm) * inv;
+              const float t = fmaf(du, cs, u * dcs);
+              vacc[k] += on ? t : 0.0f;
+            }
+            end_item();
+          }
+        } else if (first) run_edges(std::integral_constant<int, 0>{});
         else run_edges(std::integral_constant<int, 1>{});
-        if (tile_on) {
+        if (tile_on && !last) {
 #pragma unroll
           for (int k = 0; k < DIM; ++k)
 #pragma unroll
@@ -1858,33 +1946,34 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
     }
 
     // epilogue: as egnn_div_fast_kernel, per wave for its own directions, then the block's waves are summed in order
-    float* dscr = dPB;                 // [K][NCOLP*DIM]
     float* tsl = dPB + K * C::POS_F;   // [G][K]
     wave_lds_fence();
+    {
+      int v_e, v_d, v_w, v_i0, v_k0, v_col0, v_c0;
+      bool v_on;
+      vcol(v_e, v_d, v_w, v_i0, v_k0, v_on, v_col0, v_c0);
+      // re-mapped last layer: the records of a virtual column's (walker, direction) sit in EPI2 neighbouring lanes; the
+      // output tangent is what entered the last layer (table of the previous layer, `cur` has moved on) + their sum
+      float tot[DIM];
 #pragma unroll
-    for (int T = 0; T < NT; ++T)
+      for (int k = 0; k < DIM; ++k) {
+        tot[k] = vacc[k];
 #pragma unroll
-      for (int d = 0; d < K; ++d)
+        for (int e = 1; e < EPI2; ++e) tot[k] += __shfl_down(vacc[k], e, 64);
+      }
+      if (lane < G * K) tsl[lane] = 0.f;
+      wave_lds_fence();
+      if (v_on && hh == 0 && v_e == 0) {
+        const float* vdpos = dposb + (2 * v_d + (cur ^ 1)) * C::POS_F;
+        float tk = tot[0], pk = vdpos[v_col0 * DIM];
 #pragma unroll
-        for (int k = 0; k < DIM; ++k) {
-          dposi[T][d][k] -= unit(T, d, k);  // dF
-          if (hh == 0) dscr[d * C::POS_F + col[T] * DIM + k] = dposi[T][d][k];
+        for (int k = 1; k < DIM; ++k) {
+          tk = (v_k0 == k) ? tot[k] : tk;
+          pk = (v_k0 == k) ? vdpos[v_col0 * DIM + k] : pk;
         }
-    if (lane < G * K) tsl[lane] = 0.f;
-    wave_lds_fence();
-#pragma unroll
-    for (int T = 0; T < NT; ++T) {
-      const int cb = (col[T] < ncol) ? col[T] - nodei[T] : 0;
-#pragma unroll
-      for (int d = 0; d < K; ++d)
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) {
-          if (!(valid[T] && hh == 0 && d < myndir && nodei[T] * DIM + k == mydir0 + d)) continue;
-          float ds = 0.f;
-          for (int q = 0; q < N; ++q) ds += dscr[d * C::POS_F + (cb + q) * DIM + k];
-          const float dF = p.no_mean ? dposi[T][d][k] : dposi[T][d][k] - ds / (float)N;
-          tsl[(col[T] / N) * K + d] = fmaf(cstab[C::NCOLP + col[T]], dF, cstab[col[T]]);
-        }
+        const float dF = (pk + tk) - 1.0f;  // d(pos^L - pos^0) of the direction's own coordinate
+        tsl[v_w * K + v_d] = fmaf(cstab[C::NCOLP + v_col0], dF, cstab[v_col0]);
+      }
     }
     wave_lds_fence();
     if (lane < G) {
@@ -1985,7 +2074,7 @@ template <int N, int DIM, int G, int NW, int K>
 static bool divshr_fits(int L) {
   using C = DivShrCfg<N, DIM, G, NW, K>;
   using CA = DivCache<N, DIM, C::NT>;
-  if (L > SHR_LMAX) return false;
+  if (L > SHR_LMAX || L < 2) return false;  // (a one-layer network has no "last" layer of the re-mapped kind)
   long long items = 0;
   for (int l = 0; l < L; ++l) {
     const int epi = SHR_S / (int)(CA::edge_f(l, L) / 256);
