@@ -177,7 +177,7 @@ def debiased_leg(pita_amd, net, cfg, dev, B, with_cpu):
     sde = pita_amd.VEReverseSDE(noise_schedule=sched, score_net=pita_amd.ScoreNet(net),
                                 energy_net=EnergyNet(copy.deepcopy(net)), debias_inference=True)
     x = pita_amd.Prior(scale=3.0, n_particles=n, spatial_dim=d, device=dev, seed=7).sample(B)
-    t = torch.tensor(0.5, device=dev)
+    t = torch.tensor(0.5)  # host scalar, as the integrator passes the step time
     L = pita_amd._lib.lib()
 
     def step():

@@ -354,7 +354,7 @@ class WeightedSDEIntegrator:
             st8 = torch.zeros(N, 8, dtype=torch.float64, device=dev)
         st = _lib.stream_ptr(dev)
         for step in range(N):
-            t = times[step].to(dev)
+            t = times[step]  # host scalar: the schedules' scalars (gamma, dgamma/dt) are then read without a device sync
             row = tab_h[step]
             if step < self.start_resampling_step:  # walkers frozen, weights zero (:278-280)
                 a = torch.zeros_like(a)

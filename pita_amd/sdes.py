@@ -92,7 +92,11 @@ class TermStats:
 
 
 def _per_walker(t, x):
-    return t * torch.ones(x.shape[0], device=x.device) if t.dim() == 0 else t
+    if t.dim() != 0:
+        return t.to(x.device)
+    if t.device != x.device:  # a host scalar (what the integrator passes): filled on the device, no synchronisation
+        return torch.full((x.shape[0],), float(t), device=x.device, dtype=torch.float32)
+    return t * torch.ones(x.shape[0], device=x.device)
 
 
 class VEReverseSDE:
@@ -123,12 +127,16 @@ class VEReverseSDE:
         clamp of the weight drift per chunk of that many walkers -- what the reference gets by calling ``f`` once per
         inference chunk (sde_integration.py:312-343, sdes.py:230), without its per-chunk launch overhead."""
         gamma_energy = gamma_energy_schedule.gamma(t)  # gamma_score is overwritten by it (sdes.py:142-143)
-        t = _per_walker(t, x)
-        if isinstance(gamma_energy, torch.Tensor):
-            gamma_energy = gamma_energy.to(x.device)
         if not self.debias_inference:
+            t = _per_walker(t, x)
+            if isinstance(gamma_energy, torch.Tensor):
+                gamma_energy = gamma_energy.to(x.device)
             return self.f_not_debiased(t, x, beta, gamma_energy)
-        return self.f_debiased(t, x, beta, gamma_energy, gamma_energy_schedule, clamp_chunk, energy_function)
+        # gamma and dgamma/dt enter the assembly kernel as scalars: taken from the step time AS GIVEN -- a host scalar
+        # (the integrator's) costs nothing, a device tensor costs one synchronisation each
+        dgamma = gamma_energy_schedule.dgamma_dt(t) if t.dim() == 0 else None
+        t = _per_walker(t, x)
+        return self.f_debiased(t, x, beta, gamma_energy, gamma_energy_schedule, clamp_chunk, energy_function, dgamma)
 
     # ------------------------------------------------------------------ debiased regime (sdes.py:151-239)
     def _denoiser_jacobian_terms(self, model, ht, x, beta, want_h_direction):
@@ -180,7 +188,8 @@ class VEReverseSDE:
             tt = t.detach().clone().requires_grad_(True)
             return torch.autograd.grad(sched.h(tt).sum(), tt)[0]
 
-    def f_debiased(self, t, x, beta, gamma_energy, gamma_energy_schedule, clamp_chunk=None, energy_function=None):
+    def f_debiased(self, t, x, beta, gamma_energy, gamma_energy_schedule, clamp_chunk=None, energy_function=None,
+                   dgamma_dt=None):
         assert self.energy_net is not None
         if self.score_net is None:
             # sdes.py:204-216 (Laplacian of E_theta by vmap(hessian)).  Unreachable in the reference as shipped: its
@@ -213,7 +222,7 @@ class VEReverseSDE:
             pin_w, pin_dw = float(one_minus**3), float(-3 * one_minus**2)
             logp_t = _lib.dev_tensor(energy_function(x), "energy_function(x)").contiguous()
         gamma = float(gamma_energy.reshape(-1)[0]) if isinstance(gamma_energy, torch.Tensor) else float(gamma_energy)
-        dg = gamma_energy_schedule.dgamma_dt(t)
+        dg = gamma_energy_schedule.dgamma_dt(t) if dgamma_dt is None else dgamma_dt
         dgamma = float(dg.reshape(-1)[0]) if isinstance(dg, torch.Tensor) else float(dg)
         D_E, jtx_E, dot_h = self._energy_gradient_terms(self.energy_net.net, ht, x, beta)
         D_S, trace_S = self._score_divergence_terms(self.score_net.model, ht, x, beta)
