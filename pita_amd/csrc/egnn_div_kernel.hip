@@ -31,6 +31,7 @@ struct DivParams {
   int* mark;                // [B] fast kernel: 1 = this launch's contribution of the walker was non-finite and NOT added;
                             // this kernel with repair != 0: recompute and add exactly the marked walkers
   int repair;
+  int nchunk;               // repair pass: > 1 = the ndir directions are processed in this many chunks of K in one launch
   int* bad_flag;            // one word behind the marks: the launch that marked a walker leaves its sequence number
   int bad_seq;              // here, and the repair launches behind a launch that marked nobody return at once
   int n_layers, in_nf, attention, tanh_on, feature_layout;
@@ -112,6 +113,12 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_kernel(DivParams p) {
       for (int w = 0; w < nwalk; ++w) any = any || p.mark[walker0 + w] != 0;
       if (!any) continue;
     }
+    // repair pass with `nchunk` > 1: the directions dir0 .. dir0 + ndir - 1 in chunks of K inside ONE launch (one launch
+    // per tangent-only launch instead of one per K directions: these launches return at once almost always)
+    const int nch = (p.repair && p.nchunk > 1) ? p.nchunk : 1;
+    for (int ch = 0; ch < nch; ++ch) {
+    const int dir0 = p.dir0 + ch * K;
+    const int ndir = nch > 1 ? ((p.ndir - ch * K) < K ? (p.ndir - ch * K) : K) : p.ndir;
 #pragma unroll
     for (int T = 0; T < NT; ++T) {
       col[T] = T * 32 + cl;
@@ -139,7 +146,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_kernel(DivParams p) {
         }
 #pragma unroll
         for (int q = 0; q < K; ++q) {
-          const float v = (valid[T] && q < p.ndir && nodei[T] * DIM + k == p.dir0 + q) ? c_in[T] : 0.f;  // d(c_in x)
+          const float v = (valid[T] && q < ndir && nodei[T] * DIM + k == dir0 + q) ? c_in[T] : 0.f;  // d(c_in x)
           dposi[T][q][k] = v;
           dp0i[T][q][k] = v;
           if (hh == 0) {
@@ -365,7 +372,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_kernel(DivParams p) {
       for (int d = 0; d < K; ++d)
 #pragma unroll
         for (int k = 0; k < DIM; ++k) {
-          if (!(mine[T] && hh == 0 && d < p.ndir && nodei[T] * DIM + k == p.dir0 + d)) continue;
+          if (!(mine[T] && hh == 0 && d < ndir && nodei[T] * DIM + k == dir0 + d)) continue;
           float ds = 0.f;
           for (int q = 0; q < N; ++q) ds += dscr[d * C::POS_F + (cb + q) * DIM + k];
           const float dF = p.no_mean ? dposi[T][d][k] : dposi[T][d][k] - ds / (float)N;
@@ -374,7 +381,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_kernel(DivParams p) {
         }
     }
     wave_lds_fence();
-    if (p.out) {  // primal denoiser D = c_s x + c_out (F - mean F), F = pos^L - pos^0 (x = pos^0 / c_in)
+    if (p.out && ch == 0) {  // primal denoiser D = c_s x + c_out (F - mean F), F = pos^L - pos^0 (x = pos^0 / c_in)
       float* scr = PB;
 #pragma unroll
       for (int T = 0; T < NT; ++T)
@@ -398,6 +405,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_div_kernel(DivParams p) {
       }
       wave_lds_fence();
     }
+    }  // chunks of directions
   }
 }
 
@@ -2400,14 +2408,11 @@ extern "C" int pita_egnn_jacobian_trace(pita_egnn_t* net, const float* h, const 
         r.dir0 = 0; r.ndir = 0; r.out = out;
         return div_launch(s, s->kernel, net, r, stream);
       }
-      for (int d0 = 0; d0 < ndir; d0 += s->K) {
-        r.dir0 = dir0 + d0;
-        r.ndir = (ndir - d0) < s->K ? (ndir - d0) : s->K;
-        r.out = (d0 == 0) ? out : nullptr;
-        const int rc = div_launch(s, s->kernel, net, r, stream);
-        if (rc != PITA_OK) return rc;
-      }
-      return PITA_OK;
+      r.dir0 = dir0;
+      r.ndir = ndir;
+      r.nchunk = (ndir + s->K - 1) / s->K;
+      r.out = out;
+      return div_launch(s, s->kernel, net, r, stream);
     };
     // first launch: primal + its own directions, cache written
     const int first_k = wr ? wr->K : s->K;
