@@ -1624,7 +1624,10 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
         for (int q = 0; q < K; ++q) {
           const float v = unit(T, q, k);
           dposi[T][q][k] = v;
-          if (hh == 0) dposb[(2 * q) * C::POS_F + col[T] * DIM + k] = v;
+          if (hh == 0) {
+            dposb[(2 * q) * C::POS_F + col[T] * DIM + k] = v;
+            dposb[(2 * q + 1) * C::POS_F + col[T] * DIM + k] = 0.f;  // filled by the re-mapped first layer
+          }
         }
 #pragma unroll
       for (int q = 0; q < K; ++q) dhf[T][q] = zero16;
@@ -1846,7 +1849,128 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
           end_item();
         }
         };
-        if (last) {
+        // (instantiations with K = 2 directions per wave sit at 256 registers: there the re-mapped first layer spills --
+        // LJ13 trace 20.7 -> 22.9 ms -- and the column mapping stays; with K = 1, LJ55, it gains 2 %)
+        constexpr bool VFIRST = K == 1;
+        if (first && VFIRST) {
+          // First layer of a unit direction (dh = 0, d pos = the unit vector of node i0): only the edges that touch i0
+          // have a tangent -- the row (i0, j) and the column (j, i0), 2 (N - 1) of N (N - 1).  Lanes re-mapped as in the
+          // last layer: virtual column = (walker, direction, record of the item, side); side 0 = edge (i0, i0 + dd),
+          // side 1 = edge (i0 - dd, i0).  What an edge gives its node a -- the aggregate's tangent (16 features per
+          // half) and the position tangent -- goes to per-wave tables (the partner table is idle in this layer, the
+          // "next" position table is this layer's output anyway): side 1 hits every node a != i0 exactly once, side 0
+          // sums its records in registers and writes node i0 at the end.  Then the columns read their rows back.
+          const int f_e = cl % EPI2, f_s = (cl / EPI2) & 1, f_d = (cl / (2 * EPI2)) % K, f_w = cl / (2 * EPI2 * K);
+          static_assert(!VFIRST || G * K * 2 * EPI2 <= 32, "virtual columns of the first layer");
+          int f_i0 = 0, f_k0 = 0;
+#pragma unroll
+          for (int q = 0; q < K; ++q) {
+            f_i0 = (f_d == q) ? dnode[q] : f_i0;
+            f_k0 = (f_d == q) ? dk[q] : f_k0;
+          }
+          const bool f_on = tile_on && f_w < nwalk && f_w < G && f_i0 >= 0;
+          float* aggT = dPB + f_d * C::PB_F + hh * 16;                   // [column][PBS]: tangent of the aggregate
+          float* posT = dposb + (2 * f_d + (cur ^ 1)) * C::POS_F;       // [column][DIM]: tangent positions leaving the layer
+          f32x16 accA = zero16;
+          float accX[DIM];
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) accX[k] = 0.f;
+          for (int dd0 = 1; dd0 < N; dd0 += EPI2) {
+            begin_item();
+            const int dd = dd0 + f_e;
+            int na = f_s ? f_i0 - dd : f_i0;  // the edge's own node
+            na = (na < 0) ? na + N : na;
+            const int ca = f_w * N + na;
+            const bool on = f_on && dd < N && (ca >> 5) == T;
+            const int c = on ? (ca & 31) : 0;
+            const float* rec = item + f_e * (1024 + 512);
+            const float* sc = rec + 1024;
+            const float cs = sc[c], dcs_f = sc[64 + c], vcdmu = sc[256 + c];
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(sc + 128 + c * 4);
+            const float hsq = sc[384 + c * 4 + 3];
+            float df[DIM];
+            df[0] = ga.x;
+            df[1] = ga.y;
+            if constexpr (DIM > 2) df[DIM - 1] = ga.z;
+            const float inv = ga.w;
+            float dfk = df[0];
+#pragma unroll
+            for (int k = 1; k < DIM; ++k) dfk = (f_k0 == k) ? df[k] : dfk;
+            const float sg = f_s ? -1.0f : 1.0f;  // d(pos_a - pos_b) along the direction: +1 if a is its node, -1 if b is
+            const float dradial = 2.0f * sg * dfk;
+            f32x16 v;
+            {
+              const f32x4* qp = reinterpret_cast<const f32x4*>(rec) + (hh * 32 + c);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const f32x4 t = qp[q * 64];
+                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+              }
+            }
+            v *= dradial;
+            const float dcs = dcs_f * (dradial * vcdmu);
+            const float dnrm = dradial * hsq;
+            float x[DIM];
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+              const float u = df[k] * inv;
+              const float du = (((f_k0 == k) ? sg : 0.0f) - u * dnrm) * inv;
+              x[k] = fmaf(du, cs, u * dcs);
+            }
+            if (on && f_s) {  // node a != i0: its one and only contribution
+              f32x4* dst = reinterpret_cast<f32x4*>(aggT + ca * PBS);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) dst[q] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+              if (hh == 0) {
+#pragma unroll
+                for (int k = 0; k < DIM; ++k) posT[ca * DIM + k] = x[k];
+              }
+            }
+            if (on && !f_s) {
+              accA += v;
+#pragma unroll
+              for (int k = 0; k < DIM; ++k) accX[k] += x[k];
+            }
+            end_item();
+          }
+          {  // node i0: the sum over its records (EPI2 neighbouring lanes)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float t = accA[r];
+#pragma unroll
+              for (int e = 1; e < EPI2; ++e) t += __shfl_down(accA[r], e, 64);
+              accA[r] = t;
+            }
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+              float t = accX[k];
+#pragma unroll
+              for (int e = 1; e < EPI2; ++e) t += __shfl_down(accX[k], e, 64);
+              accX[k] = t;
+            }
+            const int c0g = f_w * N + f_i0;
+            if (f_on && !f_s && f_e == 0 && (c0g >> 5) == T) {
+              f32x4* dst = reinterpret_cast<f32x4*>(aggT + c0g * PBS);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) dst[q] = f32x4{accA[4 * q], accA[4 * q + 1], accA[4 * q + 2], accA[4 * q + 3]};
+              if (hh == 0) {
+#pragma unroll
+                for (int k = 0; k < DIM; ++k) posT[c0g * DIM + k] = ((f_k0 == k) ? 1.0f : 0.0f) + accX[k];
+              }
+            }
+          }
+          wave_lds_fence();
+          if (tile_on) {  // back in the column mapping
+#pragma unroll
+            for (int d = 0; d < K; ++d) {
+              const bool has = valid[T] && d < myndir;
+              dagg[d] = has ? lds_vec16(dPB + d * C::PB_F + col[T] * PBS + hh * 16) : zero16;
+#pragma unroll
+              for (int k = 0; k < DIM; ++k)
+                dposi[T][d][k] = has ? dposb[(2 * d + (cur ^ 1)) * C::POS_F + col[T] * DIM + k] : 0.0f;
+            }
+          }
+        } else if (last) {
           int v_e, v_d, v_w, v_i0, v_k0, v_col0, v_c0;
           bool v_on;
           vcol(v_e, v_d, v_w, v_i0, v_k0, v_on, v_col0, v_c0);
@@ -1912,7 +2036,7 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
           }
         } else if (first) run_edges(std::integral_constant<int, 0>{});
         else run_edges(std::integral_constant<int, 1>{});
-        if (tile_on && !last) {
+        if (tile_on && !last && !(first && VFIRST)) {
 #pragma unroll
           for (int k = 0; k < DIM; ++k)
 #pragma unroll
