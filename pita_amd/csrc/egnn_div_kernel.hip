@@ -1659,8 +1659,11 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
     for (int k = 0; k < DIM; ++k) vacc[k] = 0.f;
 
     int cur = 0;
-    for (int l = 0; l < L; ++l) {
-      const bool first = (l == 0), last = (l == L - 1) && !first;
+    // the layer sweep as a generic lambda: the first layer is its own instantiation, called ahead of the loop, so that
+    // nothing of the later layers' state (feature tangents, Wa dh_i, W2 fragments) is live while it runs
+    auto layer = [&](const int l, auto first_tag) {
+      constexpr bool first = decltype(first_tag)::value;
+      const bool last = (l == L - 1) && !first;
       // first item of the layer: [Wb Wa W2 |] position block; the positions are copied to the block's tables (the
       // ring moves on), the fragments to registers
       const int nwm = first ? 0 : (last ? 2 : 3);  // matrices ahead of the positions
@@ -2075,7 +2078,9 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
         end_item();
       }
       cur ^= 1;
-    }
+    };
+    layer(0, std::true_type{});
+    for (int l = 1; l < L; ++l) layer(l, std::false_type{});
 
     // epilogue: as egnn_div_fast_kernel, per wave for its own directions, then the block's waves are summed in order
     float* tsl = dPB + K * C::POS_F;   // [G][K]
