@@ -1661,9 +1661,9 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
     int cur = 0;
     // the layer sweep as a generic lambda: the first layer is its own instantiation, called ahead of the loop, so that
     // nothing of the later layers' state (feature tangents, Wa dh_i, W2 fragments) is live while it runs
-    auto layer = [&](const int l, auto first_tag) {
-      constexpr bool first = decltype(first_tag)::value;
-      const bool last = (l == L - 1) && !first;
+    auto layer = [&](const int l, auto kind_tag) {  // kind 0: first layer, 1: middle layers, 2: last layer
+      constexpr bool first = decltype(kind_tag)::value == 0;
+      constexpr bool last = decltype(kind_tag)::value == 2;
       // first item of the layer: [Wb Wa W2 |] position block; the positions are copied to the block's tables (the
       // ring moves on), the fragments to registers
       const int nwm = first ? 0 : (last ? 2 : 3);  // matrices ahead of the positions
@@ -2079,8 +2079,9 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
       }
       cur ^= 1;
     };
-    layer(0, std::true_type{});
-    for (int l = 1; l < L; ++l) layer(l, std::false_type{});
+    layer(0, std::integral_constant<int, 0>{});
+    for (int l = 1; l < L - 1; ++l) layer(l, std::integral_constant<int, 1>{});
+    layer(L - 1, std::integral_constant<int, 2>{});  // (L >= 2: divshr_fits)
 
     // epilogue: as egnn_div_fast_kernel, per wave for its own directions, then the block's waves are summed in order
     float* tsl = dPB + K * C::POS_F;   // [G][K]
