@@ -1756,20 +1756,31 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
             float ddf[K][DIM], dradial[K], dea[K];
 #pragma unroll
             for (int d = 0; d < K; ++d) {
-              const float* dposcur = dposb + (2 * d + cur) * C::POS_F;
-              dradial[d] = 0.f;
+              // 2 ([i == dnode] - [j == dnode]): twice the input displacement of this edge along the unit direction
+              const float sij = si[T][d] - ((valid[T] && j == dnode[d]) ? 2.0f : 0.0f);
+              if constexpr (first) {  // the positions entering the first layer ARE the input: no table read
+                float dfk = df[0];
 #pragma unroll
-              for (int k = 0; k < DIM; ++k) {
-                ddf[d][k] = dposi[T][d][k] - dposcur[cj * DIM + k];
-                dradial[d] = fmaf(df[k], ddf[d][k], dradial[d]);
+                for (int k = 1; k < DIM; ++k) dfk = (dk[d] == k) ? df[k] : dfk;
+                dradial[d] = dfk * sij;
+#pragma unroll
+                for (int k = 0; k < DIM; ++k) ddf[d][k] = (dk[d] == k) ? 0.5f * sij : 0.0f;
+              } else {
+                const float* dposcur = dposb + (2 * d + cur) * C::POS_F;
+                dradial[d] = 0.f;
+#pragma unroll
+                for (int k = 0; k < DIM; ++k) {
+                  ddf[d][k] = dposi[T][d][k] - dposcur[cj * DIM + k];
+                  dradial[d] = fmaf(df[k], ddf[d][k], dradial[d]);
+                }
+                dradial[d] *= 2.0f;
               }
-              dradial[d] *= 2.0f;
               // tangent of the frozen edge attribute |x_i - x_j|^2 along the unit direction (node dnode, component dk):
               // 2 e0[dk] ([i == dnode] - [j == dnode]) -- no per-direction table of the input displacement
               float e0k = e0[0];
 #pragma unroll
               for (int k = 1; k < DIM; ++k) e0k = (dk[d] == k) ? e0[k] : e0k;
-              dea[d] = e0k * (si[T][d] - ((valid[T] && j == dnode[d]) ? 2.0f : 0.0f));
+              dea[d] = e0k * sij;
             }
             float dcs[K];
             if constexpr (first) {

@@ -1673,10 +1673,22 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
         if (first)
           for (int i = threadIdx.x; i < 2 * C::NCOLP; i += NW * 64) cstab[i] = ipos[CA::POSX + i];
       }
-      WFrag<2> wa, w2f;
+      WFrag<2> w2f;
+      f32x16 dArT[NT][K];  // DIV_ST x Wa dh_i of every tile, formed while the item is here: Wa itself is not kept
       if (!first && active) {
+        {
+          const WFrag<2> wa = slot_wfrag(item, 0, lane);
+#pragma unroll
+          for (int T = 0; T < NT; ++T) {
+            if (T >= ntile) continue;
+#pragma unroll
+            for (int d = 0; d < K; ++d) {
+              dArT[T][d] = wa.mul(dhf[T][d], zero16);
+              dArT[T][d] *= F16_UNSCALE;
+            }
+          }
+        }
         const WFrag<2> wb = slot_wfrag(item, 1, lane);
-        wa = slot_wfrag(item, 0, lane);
         if (!last) w2f = slot_wfrag(item, 2, lane);
 #pragma unroll
         for (int T = 0; T < NT; ++T) {
@@ -1700,10 +1712,7 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
         f32x16 dAr[K];
         if (!first && tile_on) {
 #pragma unroll
-          for (int d = 0; d < K; ++d) {
-            dAr[d] = wa.mul(dhf[T][d], zero16);
-            dAr[d] *= F16_UNSCALE;
-          }
+          for (int d = 0; d < K; ++d) dAr[d] = dArT[T][d];
         }
         f32x16 dagg[K];
         float dxacc[K][DIM];
