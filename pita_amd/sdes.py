@@ -135,8 +135,14 @@ class VEReverseSDE:
         # gamma and dgamma/dt enter the assembly kernel as scalars: taken from the step time AS GIVEN -- a host scalar
         # (the integrator's) costs nothing, a device tensor costs one synchronisation each
         dgamma = gamma_energy_schedule.dgamma_dt(t) if t.dim() == 0 else None
+        # a host scalar also gives h(t), g(t)^2 and dh/dt as three fills instead of a dozen element-wise launches on [B]
+        sched_scalars = None
+        if t.dim() == 0 and t.device.type == "cpu":
+            t1 = t.detach().reshape(1).to(torch.float32)
+            sched_scalars = (float(self.noise_schedule.h(t1)[0]), float(self.g(t1).pow(2)[0]), float(self._dh_dt(t1)[0]))
         t = _per_walker(t, x)
-        return self.f_debiased(t, x, beta, gamma_energy, gamma_energy_schedule, clamp_chunk, energy_function, dgamma)
+        return self.f_debiased(t, x, beta, gamma_energy, gamma_energy_schedule, clamp_chunk, energy_function, dgamma,
+                               sched_scalars)
 
     # ------------------------------------------------------------------ debiased regime (sdes.py:151-239)
     def _denoiser_jacobian_terms(self, model, ht, x, beta, want_h_direction):
@@ -189,7 +195,7 @@ class VEReverseSDE:
             return torch.autograd.grad(sched.h(tt).sum(), tt)[0]
 
     def f_debiased(self, t, x, beta, gamma_energy, gamma_energy_schedule, clamp_chunk=None, energy_function=None,
-                   dgamma_dt=None):
+                   dgamma_dt=None, sched_scalars=None):
         assert self.energy_net is not None
         if self.score_net is None:
             # sdes.py:204-216 (Laplacian of E_theta by vmap(hessian)).  Unreachable in the reference as shipped: its
@@ -200,9 +206,12 @@ class VEReverseSDE:
 
         x = _lib.dev_tensor(x, "x")
         B, D = x.shape
-        ht = _lib.dev_tensor(self.noise_schedule.h(t), "h(t)").contiguous()
-        g2 = _lib.dev_tensor(self.g(t).pow(2), "g(t)^2").contiguous()
-        dhdt = _lib.dev_tensor(self._dh_dt(t), "dh/dt").contiguous()
+        if sched_scalars is not None:  # uniform step time (the integrator's): the schedule evaluated once on the host
+            ht, g2, dhdt = (torch.full((B,), v, device=x.device, dtype=torch.float32) for v in sched_scalars)
+        else:
+            ht = _lib.dev_tensor(self.noise_schedule.h(t), "h(t)").contiguous()
+            g2 = _lib.dev_tensor(self.g(t).pow(2), "g(t)^2").contiguous()
+            dhdt = _lib.dev_tensor(self._dh_dt(t), "dh/dt").contiguous()
         pb_e = bool(getattr(self.energy_net, "precondition_beta", False))
         pb_s = bool(getattr(self.score_net, "precondition_beta", False))
         beta_b = None
