@@ -26,22 +26,17 @@ struct ElemParams {
   double* stats_out;            // OP_EM, nullable [4]: += sum / sum of squares of drift and of noise_scale * xi
 };
 
-// wave reduction in double + one atomic per wave (order of the atomics varies run to run at the 1e-16 level only)
-__device__ __forceinline__ void moments_commit(double* out, int nq, const float* part) {
-  for (int q = 0; q < nq; ++q) {
-    double v = (double)part[q];
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(out + q, v);
-  }
-}
-
 template <int DIM, int OP>
 __global__ void __launch_bounds__(256) elem_kernel(float* __restrict__ x, const float* __restrict__ drift,
                                                    const float* __restrict__ noise, long long B, int n, int WB,
                                                    ElemParams p) {
   extern __shared__ float sm[];  // [WB*n*DIM]
+  __shared__ double red[4][4];   // OP_EM moments: one commit per BLOCK at the end of its grid-stride loop (an atomic per
+                                 // wave and batch of WB walkers -- 55 000 double atomics on four addresses at 65 536 LJ13
+                                 // walkers -- made this the slowest small kernel of a debiased step: 0.67 ms)
   const int tid = threadIdx.x;
   const long long nblk = (B + WB - 1) / WB;
+  double momd[4] = {0.0, 0.0, 0.0, 0.0};
   for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
     const long long w0 = blk * WB;
     const int nw = (int)((B - w0) < WB ? (B - w0) : WB);
@@ -76,7 +71,10 @@ __global__ void __launch_bounds__(256) elem_kernel(float* __restrict__ x, const 
         sm[(w * n + i) * DIM + k] = v[k];
       }
     }
-    if (OP == OP_EM && p.stats_out) moments_commit(p.stats_out, 4, mom);
+    if (OP == OP_EM && p.stats_out) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) momd[q] += (double)mom[q];
+    }
     __syncthreads();
     if (act) {
       const long long base = ((w0 + w) * n + i) * DIM;
@@ -92,6 +90,16 @@ __global__ void __launch_bounds__(256) elem_kernel(float* __restrict__ x, const 
     }
     __syncthreads();
   }
+  if (OP == OP_EM && p.stats_out) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double vq = momd[q];
+      for (int o = 32; o > 0; o >>= 1) vq += __shfl_xor(vq, o, 64);
+      if ((tid & 63) == 0) red[tid >> 6][q] = vq;
+    }
+    __syncthreads();
+    if (tid < 4) atomicAdd(p.stats_out + tid, (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
+  }
 }
 
 template <int OP>
@@ -105,7 +113,9 @@ static int launch_elem(float* x, const float* drift, const float* noise, int64_t
   if (B == 0) return PITA_OK;
   const int WB = 256 / n;
   const long long nblk = (B + WB - 1) / WB;
-  const unsigned grid = (unsigned)(nblk < 256LL * 16 ? nblk : 256LL * 16);
+  // with moments: a grid-stride loop over fewer blocks (one set of four atomics per block)
+  const long long cap = (OP == OP_EM && p.stats_out) ? 256LL * 4 : 256LL * 16;
+  const unsigned grid = (unsigned)(nblk < cap ? nblk : cap);
   const size_t lds = sizeof(float) * (size_t)(WB * n * d);
   hipStream_t s = (hipStream_t)stream;
   switch (d) {
