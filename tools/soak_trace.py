@@ -8,7 +8,7 @@ import pita_amd
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 w = dict(np.load(os.path.join(ROOT, "tests/golden/egnn_weights_trainedlike.npz")))
 bad = 0
-for n, sizes in ((13, (1, 2, 3, 511, 4097, 20011, 65536)), (22, (1, 5, 4096, 9001))):
+for n, sizes in ((13, (1, 2, 3, 511, 4097, 20011, 65536)), (22, (1, 5, 4096, 9001)), (55, (1, 2, 257, 1031))):
     net = pita_amd.EGNN_dynamics(n, 3, hidden_nf=32, n_layers=3, recurrent=True, tanh=True, attention=True,
                                  condition_time=True, condition_temperature=True, agg="sum")
     net.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
