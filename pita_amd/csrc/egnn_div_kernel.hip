@@ -1324,7 +1324,7 @@ struct DivShrCfg {
   static constexpr int NCOLP = NT * 32;
   static constexpr int PB_F = NCOLP * PBS;
   static constexpr int POS_F = NCOLP * DIM;
-  static constexpr int WAVE_F = K * PB_F + 3 * K * POS_F;   // dPB[K]; dpos[K][2], dpos0[K]
+  static constexpr int WAVE_F = K * PB_F + 2 * K * POS_F;   // dPB[K]; dpos[K][2]
   static constexpr int RES_G = 32;                           // groups between result flushes
   // piece table of one group's sequence: one entry per piece, or -- systems whose sequence is longer (LJ55: 189 items)
   // -- two words per ITEM (every item is [weight pieces | cache pieces | padding]: first piece and count of each run)
