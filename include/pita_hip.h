@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PITA_ABI_VERSION 7
+#define PITA_ABI_VERSION 8
 
 enum {
   PITA_OK = 0,
@@ -397,6 +397,11 @@ int pita_em_step(float* x, const float* drift, const float* noise, int64_t B, in
 /* out[0] += sum v, out[1] += sum v^2 (device double[2]): moments of one SDETerms field (divergence_score, cross_term,
  * dUt_dt; sdes.py:34-41), so the integrator returns statistics instead of N x [B] host copies (sde_integration.py:289) */
 int pita_moments(const float* v, int64_t n, double* out, void* stream);
+/* The same for up to four vectors of one length in one launch (null pointers are skipped): out[2 q], out[2 q + 1] += the sum /
+ * sum of squares of v_q -- the four per-step SDETerms statistics of the debiased regime (drift_A, divergence_score,
+ * cross_term, dUt_dt; sde_integration.py:150,289). */
+int pita_moments4(const float* v0, const float* v1, const float* v2, const float* v3, int64_t n, double* out /*[8]*/,
+                  void* stream);
 /* K9: MeanFreePrior.sample (base_prior.py:77-83): x = scale * N(0,1) minus particle mean.
  * noise nullable -> Philox keyed (seed, walker_offset + walker, step = -1). */
 int pita_prior_sample(float* x, const float* noise, int64_t B, int n_particles, int n_dim,

@@ -430,6 +430,45 @@ extern "C" int pita_em_step(float* x, const float* drift, const float* noise, in
   return launch_elem<OP_EM>(x, drift, noise, B, n, d, p, stream);
 }
 
+// the same for up to four vectors of one length in ONE launch: out[2 q], out[2 q + 1] += sum / sum of squares of v_q
+// (the four per-step statistics of the debiased regime were four launches of ~27 us)
+__global__ void __launch_bounds__(256) moments4_kernel(const float* __restrict__ v0, const float* __restrict__ v1,
+                                                       const float* __restrict__ v2, const float* __restrict__ v3,
+                                                       long long n, double* __restrict__ out) {
+  const float* vs[4] = {v0, v1, v2, v3};
+  __shared__ double red[4][8];
+  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (vs[q]) {
+        const double a = (double)vs[q][e];
+        acc[2 * q] += a;
+        acc[2 * q + 1] += a * a;
+      }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    double t = acc[q];
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8 && vs[threadIdx.x >> 1])
+    atomicAdd(out + threadIdx.x, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+}
+
+extern "C" int pita_moments4(const float* v0, const float* v1, const float* v2, const float* v3, int64_t n, double* out,
+                             void* stream) {
+  PITA_REQUIRE(n >= 0 && out, "pita_moments4: bad argument");
+  if (n == 0 || !(v0 || v1 || v2 || v3)) return PITA_OK;
+  const long long nb = (n + 255) / 256;
+  hipLaunchKernelGGL(moments4_kernel, dim3((unsigned)(nb < 256 ? nb : 256)), dim3(256), 0, (hipStream_t)stream, v0, v1, v2, v3,
+                     (long long)n, out);
+  PITA_LAUNCH_CHECK();
+  return PITA_OK;
+}
+
 extern "C" int pita_moments(const float* v, int64_t n, double* out, void* stream) {
   PITA_REQUIRE(n >= 0 && out, "pita_moments: bad argument");
   if (n == 0) return PITA_OK;

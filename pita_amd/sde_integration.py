@@ -369,9 +369,9 @@ class WeightedSDEIntegrator:
                                       float(row[_lib.ST_NOISE_SCALE]), float(row[_lib.ST_SQRT_DT]), key, off, step, 0,
                                       _lib.ptr(st4[step]) if st4 is not None else 0, st), "pita_em_step")
             if st8 is not None:
-                for j, v in enumerate((terms.drift_A, terms.divergence_score, terms.cross_term, terms.dUt_dt)):
-                    if v is not None:
-                        _lib.check(L.pita_moments(v.data_ptr(), Bl, st8[step, 2 * j:].data_ptr(), st), "pita_moments")
+                vs = [None if v is None else _lib.dev_tensor(v, "SDETerms field").contiguous()
+                      for v in (terms.drift_A, terms.divergence_score, terms.cross_term, terms.dUt_dt)]
+                _lib.check(L.pita_moments4(*(_lib.ptr(v) for v in vs), Bl, st8[step].data_ptr(), st), "pita_moments4")
             a = a + terms.drift_A * float(row[_lib.ST_DT])
             if step >= self.end_resampling_step:
                 a = torch.zeros_like(a)
