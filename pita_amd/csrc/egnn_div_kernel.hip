@@ -1872,9 +1872,9 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
           end_item();
         }
         };
-        // (instantiations with K = 2 directions per wave sit at 256 registers: there the re-mapped first layer spills --
-        // LJ13 trace 20.7 -> 22.9 ms -- and the column mapping stays; with K = 1, LJ55, it gains 2 %)
-        constexpr bool VFIRST = K == 1;
+        // (its item loop must stay a loop: unrolled four times -- the compiler's choice -- the kernel grew from 5 600 to
+        // 9 200 instructions and lost 0.7 ms; `#pragma unroll 1` below)
+        constexpr bool VFIRST = true;
         if (first && VFIRST) {
           // First layer of a unit direction (dh = 0, d pos = the unit vector of node i0): only the edges that touch i0
           // have a tangent -- the row (i0, j) and the column (j, i0), 2 (N - 1) of N (N - 1).  Lanes re-mapped as in the
@@ -1898,6 +1898,7 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
           float accX[DIM];
 #pragma unroll
           for (int k = 0; k < DIM; ++k) accX[k] = 0.f;
+#pragma unroll 1
           for (int dd0 = 1; dd0 < N; dd0 += EPI2) {
             begin_item();
             const int dd = dd0 + f_e;
@@ -2009,6 +2010,7 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
             }
           const float* vdpos = dposb + (2 * v_d + cur) * C::POS_F;
           const float* vdPB = dPB + v_d * C::PB_F + hh * 16;
+#pragma unroll 1
           for (int dd0 = 1; dd0 < N; dd0 += EPI2) {
             begin_item();
             const int dd = dd0 + v_e;
