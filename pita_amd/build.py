@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpita_hip.so")
-SOURCES = ["abi.hip", "energy_kernels.hip", "ring_kernels.hip", "ff_kernel.hip", "egnn_kernel.hip", "egnn_wide_kernel.hip", "egnn_wide_mfma_kernel.hip", "egnn_wide_mfma_jvp_kernel.hip", "egnn_jvp_kernel.hip", "egnn_vjp_kernel.hip", "egnn_div_kernel.hip", "fk_kernels.hip", "mlp_kernel.hip", "sampler_kernels.hip"]
+SOURCES = ["abi.hip", "energy_kernels.hip", "ring_kernels.hip", "ff_kernel.hip", "egnn_kernel.hip", "egnn_wide_kernel.hip", "egnn_wide_mfma_kernel.hip", "egnn_wide_mfma_jvp_kernel.hip", "egnn_jvp_kernel.hip", "egnn_vjp_kernel.hip", "egnn_div_kernel.hip", "egnn_div_walker_kernel.hip", "fk_kernels.hip", "mlp_kernel.hip", "sampler_kernels.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          # no implicit FMA contraction: every fused multiply-add is an explicit fmaf, so results are bitwise

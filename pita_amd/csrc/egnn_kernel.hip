@@ -821,6 +821,13 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
     pita_egnn_destroy(net);
     return fail(PITA_EHIP, "pita_egnn_create: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e3));
   }
+  {  // weight packing of the walker-resident trace kernel (particle systems it is instantiated for)
+    const int rc = wk_pack_create(net, cfg, w);
+    if (rc != PITA_OK) {
+      pita_egnn_destroy(net);
+      return rc;
+    }
+  }
   *out = net;
   return PITA_OK;
 }
@@ -839,6 +846,7 @@ extern "C" int pita_egnn_destroy(pita_egnn_t* net) {
   (void)hipFree(net->d_bk);
   (void)hipFree(net->d_mark);
   (void)hipFree(net->d_divcache);
+  (void)hipFree(net->d_wk);
   delete net;
   return PITA_OK;
 }
