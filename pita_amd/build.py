@@ -8,6 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpita_hip.so")
 SOURCES = ["abi.hip", "energy_kernels.hip", "ring_kernels.hip", "ff_kernel.hip", "egnn_kernel.hip", "egnn_wide_kernel.hip", "egnn_wide_mfma_kernel.hip", "egnn_wide_mfma_jvp_kernel.hip", "egnn_jvp_kernel.hip", "egnn_vjp_kernel.hip", "egnn_div_kernel.hip", "egnn_div_walker_kernel.hip", "fk_kernels.hip", "mlp_kernel.hip", "sampler_kernels.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FALLBACK_OBJECTS = []  # sources whose optional per-file flags the toolchain rejected in this build
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          # no implicit FMA contraction: every fused multiply-add is an explicit fmaf, so results are bitwise
          # independent of how the compiler schedules the unrolled column tiles (sharding invariance)
@@ -19,6 +20,13 @@ PER_FILE_FLAGS = {"egnn_wide_mfma_kernel.hip": ["-mllvm", "-amdgpu-mfma-vgpr-for
                   "egnn_wide_mfma_jvp_kernel.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                   # reverse-mode kernel (one wave per SIMD, resident weight fragments parked in AGPRs): 5.74 -> 5.22 ms
                   "egnn_vjp_kernel.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# REQUIRED per-file flags (correctness, never dropped by the retry below).  egnn_div_walker_kernel.hip: no packed fp32
+# vector instructions.  With hipcc's v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 in that kernel (8 waves per workgroup,
+# v_mfma_f32_16x16x32_f16 chains, two waves per SIMD) one result in ~1e4 walkers differed from run to run: the LOW half of a
+# packed result wrong in lanes 48..63 with all its inputs intact (profiles/r05_walker_packed_fp32_hazard.txt; the
+# instruction-level probes under tools/ubench/ rule out the matrix-instruction and LDS wait states).  Without packed
+# instructions: 0 differing results in 6e5 walker evaluations.
+REQUIRED_FILE_FLAGS = {"egnn_div_walker_kernel.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]}
 # (egnn_div_kernel.hip: the same treatment gained 4 % on the LJ55 trace, nothing on LJ13, and ONE instantiation --
 # egnn_div_fast_kernel<4,2,8,4,3,1>, the DW4 writer -- then faulted with a memory aperture violation: bisected to the
 # combination of this experimental option with the AGPR-parked fragments in that kernel; either alone is fine there.
@@ -45,23 +53,35 @@ def build(force=False, verbose=True, extra_flags=()):
         if not os.path.exists(src):
             continue
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
-        cmd = [HIPCC, *FLAGS, *PER_FILE_FLAGS.get(s, []), *extra_flags, "-c", src, "-o", obj]
+        cmd = [HIPCC, *FLAGS, *REQUIRED_FILE_FLAGS.get(s, []), *PER_FILE_FLAGS.get(s, []), *extra_flags, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((s, subprocess.Popen(cmd)))
+        procs.append((s, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
         objs.append(obj)
-    for s, p in procs:
-        if p.wait() != 0:
-            # the per-file flags are experimental LLVM options (validated against ROCm 7.2.0): a toolchain that dropped
-            # or renamed one must not take the whole library down -- retry that file without them, loudly
-            extra = PER_FILE_FLAGS.get(s)
-            if extra:
-                print(f"pita_amd.build: hipcc failed on {s} with {extra}; retrying without them (slower kernels in that file)",
-                      file=sys.stderr, flush=True)
-                src, obj = os.path.join(CSRC, s), os.path.join(CSRC, s.replace(".hip", ".o"))
-                if subprocess.call([HIPCC, *FLAGS, *extra_flags, "-c", src, "-o", obj]) == 0:
-                    continue
-            raise RuntimeError(f"hipcc failed on {s}")
+    failed = None
+    for s, p in procs:  # every child is waited for, also behind a failure
+        err = p.communicate()[1] or ""
+        if err.strip():
+            print(err, file=sys.stderr, end="", flush=True)
+        if p.returncode == 0 or failed:
+            continue
+        # the optional per-file flags are experimental LLVM options (validated against ROCm 7.2.0): a toolchain that dropped
+        # or renamed one must not take the whole library down -- retry that file without them, loudly, but ONLY when the
+        # compiler's complaint names the option (a genuine compile error is reported once)
+        extra = PER_FILE_FLAGS.get(s)
+        if extra and any(("nknown" in ln or "unrecognized" in ln) and any(f.lstrip("-") in ln for f in extra if f != "-mllvm")
+                         for ln in err.splitlines()):
+            print(f"pita_amd.build: hipcc rejected {extra} on {s}; retrying without them (slower kernels in that file)",
+                  file=sys.stderr, flush=True)
+            src, obj = os.path.join(CSRC, s), os.path.join(CSRC, s.replace(".hip", ".o"))
+            if subprocess.call([HIPCC, *FLAGS, *REQUIRED_FILE_FLAGS.get(s, []), *extra_flags, "-c", src, "-o", obj]) == 0:
+                FALLBACK_OBJECTS.append(s)
+                continue
+        failed = s
+    if failed:
+        raise RuntimeError(f"hipcc failed on {failed}")
+    with open(os.path.join(CSRC, "build_fallbacks.txt"), "w") as fh:  # read by tests/test_kernel_resources.py and bench.py
+        fh.write("\n".join(FALLBACK_OBJECTS))
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
     if verbose:
         print(" ".join(cmd), flush=True)

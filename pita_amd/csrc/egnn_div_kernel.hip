@@ -2474,6 +2474,7 @@ extern "C" int pita_egnn_jacobian_trace(pita_egnn_t* net, const float* h, const 
     r.B = B; r.h = h; r.x = x; r.beta = beta; r.diag_acc = trace; r.no_mean = 1;
     r.mark = net->d_mark; r.bad_flag = bad_flag; r.bad_seq = seq;
     r.repair = 1; r.dir0 = 0; r.ndir = D; r.nchunk = (D + s->K - 1) / s->K; r.out = denoiser_out;
+    if (getenv("PITA_WK_NOREPAIR")) return PITA_OK;  // development aid: marked walkers keep a zero trace
     return div_launch(s, s->kernel, net, r, stream);
   }
   const DivTanShape* ts = div_fast_enabled(net) ? find_div_tan_shape(n, dim, L) : nullptr;

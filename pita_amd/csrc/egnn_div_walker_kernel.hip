@@ -62,7 +62,6 @@ struct WkParams {
   int* mark;
   int* bad_flag;
   int bad_seq;
-  int dbg;  // development experiments (PITA_WK_DBG)
 };
 
 // development aid (-DPITA_WK_STAMPS): shader cycles per section of the kernel, summed over all waves
@@ -78,15 +77,6 @@ __device__ unsigned long long wk_dbg[16];
 #define WK_STAMP(k) do { } while (0)
 #endif
 
-#ifdef PITA_WK_DUMP
-__device__ float wk_dump[65536 * 13 * 8];
-#define WK_DUMP(slot, val)                                                                     \
-  do {                                                                                         \
-    if (wid < 128) wk_dump[(((wid * 3 + l) * 13 + i) * 8 + (slot)) * 64 + lane] = (val);        \
-  } while (0)
-#else
-#define WK_DUMP(slot, val) do { } while (0)
-#endif
 
 struct WkFrag { u32x4 hi, lo; };  // eight operand elements as two f16 pieces
 struct WkMat { WkFrag f[2]; };    // a 32 x 32 A operand (two row blocks)
@@ -133,15 +123,10 @@ __device__ __forceinline__ void wk_silu_d(float z, float& y, float& g) {
   y = z * s;
   g = s * fmaf(z, 1.0f - s, 1.0f);
 }
-__device__ int wk_dbg_flags;
 // sum over the four lanes (c, g = 0..3) that share a column: the 32 features of one dot product
 __device__ __forceinline__ float wk_gsum(float v) {
   // v_permlane16_swap / v_permlane32_swap (gfx950) exchange rows / halves of two registers inside the VALU: swapping two
   // copies of v leaves (even rows, even rows) and (odd rows, odd rows): their sum is v + v[lane ^ 16]; likewise for 32
-  if (wk_dbg_flags & 8) {
-    v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-    return v;
-  }
   const unsigned u = __float_as_uint(v);
   const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
   v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
@@ -149,10 +134,6 @@ __device__ __forceinline__ float wk_gsum(float v) {
 }
 // sum over the 16 columns of a tile (the lanes of one DPP row); every lane of the row gets the sum
 __device__ __forceinline__ float wk_rowsum(float v) {
-  if (wk_dbg_flags & 4) {
-    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-    return v;
-  }
   v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
   v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
   v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x141, 0xf, 0xf, true));  // row_half_mirror
@@ -213,7 +194,9 @@ struct WkCfg {
   static constexpr int O_VEC = O_ZA + 2 * N * 32 * 4;          // float [WK_VEC_LAYER_F]
   static constexpr int O_DIAG = O_VEC + ((WK_VEC_LAYER_F * 4 + 15) / 16) * 16;  // float [N * DIM (pad 48)] + scratch
   static constexpr int O_NODE = O_DIAG + 64 * 4;               // float [WK_NW][48]: a node's aggregate and position update
-  static constexpr int O_FT = O_NODE + WK_NW * 48 * 4;
+  static constexpr int O_DPN = O_NODE + WK_NW * 48 * 4;        // float4 [N][NT * 16]: d pos of every node (true scale), touched by its owner only
+  static constexpr int O_PNEW = O_DPN + N * NT * 16 * 16;      // float4 [N]: positions leaving the layer
+  static constexpr int O_FT = O_PNEW + N * 16;
   static constexpr int LDS_BYTES = O_FT + WK_NW * FT_F * 4;
 };
 
@@ -229,9 +212,20 @@ __global__ void __launch_bounds__(WK_NW * 64, 2) egnn_div_walker_kernel(WkParams
   float* zbT = zaT + N * 32;
   float* vecL = reinterpret_cast<float*>(lds + C::O_VEC);
   float* diag = reinterpret_cast<float*>(lds + C::O_DIAG);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int wave = threadIdx.x >> 6;
+  int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  // re-derive the lane coordinates from an opaque copy at the head of every phase: left alone the compiler hoists every
+  // lane-dependent LDS address of the whole walker loop to the top of the kernel and spills them (64 of its scratch slots)
+#define WK_RELANE()                               \
+  do {                                            \
+    int l_ = threadIdx.x & 63;                    \
+    asm volatile("" : "+v"(l_));                  \
+    lane = l_; c = l_ & 15; g = l_ >> 4;          \
+  } while (0)
   float* FT = reinterpret_cast<float*>(lds + C::O_FT) + wave * C::FT_F;
   float* nodeS = reinterpret_cast<float*>(lds + C::O_NODE) + wave * 48;
+  f32x4* dpn = reinterpret_cast<f32x4*>(lds + C::O_DPN);
+  f32x4* posNew = reinterpret_cast<f32x4*>(lds + C::O_PNEW);
   const int nown = (wave + WK_NW < N) ? 2 : (wave < N ? 1 : 0);
   const int L = p.n_layers;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -239,14 +233,15 @@ __global__ void __launch_bounds__(WK_NW * 64, 2) egnn_div_walker_kernel(WkParams
 
   for (int t = threadIdx.x; t < 2 * C::ZB_NODE / 16; t += WK_NW * 64) reinterpret_cast<u32x4*>(dposF)[t] = u32x4{0u, 0u, 0u, 0u};
   // d pos of node i (lanes g = 0: rows k of column 16 ct + c) -> its K slots 3 i + k of the shared B fragments
-  auto publish_dpos = [&](int i, const f32x4 (&dp)[NT]) {
+  auto publish_dpos = [&](int i) {
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
     typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
     if (g == 0) {
       const int t = 4 * i;  // elements t & 7 = 0 or 4 of lane group (t & 31) >> 3: one 8-byte store per tile and piece
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) {
-        const float v0 = WK_SS * dp[ct].x, v1 = WK_SS * dp[ct].y, v2 = WK_SS * dp[ct].z;
+        const f32x4 dp = dpn[i * (NT * 16) + 16 * ct + c];
+        const float v0 = WK_SS * dp.x, v1 = WK_SS * dp.y, v2 = WK_SS * dp.z;
         const f16x2 h01 = __builtin_convertvector(f32x2_t{v0, v1}, f16x2), h2 = __builtin_convertvector(f32x2_t{v2, 0.f}, f16x2);
         const f16x2 l01 = __builtin_convertvector(f32x2_t{v0 - (float)h01.x, v1 - (float)h01.y}, f16x2);
         const f16x2 l2 = __builtin_convertvector(f32x2_t{v2 - (float)h2.x, 0.f}, f16x2);
@@ -262,6 +257,7 @@ __global__ void __launch_bounds__(WK_NW * 64, 2) egnn_div_walker_kernel(WkParams
   for (long long wid = blockIdx.x; wid < p.B; wid += gridDim.x) {
     WK_STAMP(0);
     // ---------------------------------------------------------------- walker set-up
+    WK_RELANE();
     const float hv = p.h[wid], bet = p.beta ? p.beta[wid] : 0.f;
     const float op = 1.0f + hv, rs = 1.0f / sqrtf(op);
     const float c_s = 1.0f / op, c_in = rs, c_out = sqrtf(hv) * rs, tfeat = 0.125f * logf(hv);
@@ -288,19 +284,16 @@ __global__ void __launch_bounds__(WK_NW * 64, 2) egnn_div_walker_kernel(WkParams
       for (int e = 0; e < 8; ++e) hq[e] = (c < nown) ? fmaf(w0[e], a0, fmaf(w1[e], a1, eb[e])) : 0.f;
     }
     f32x4 dHs[C::OWN][2][NT];  // WK_ST x the feature tangents of the owned nodes
-    f32x4 dPn[C::OWN][NT];     // their position tangents leaving the layer (lanes g = 0: rows k = 0..DIM-1)
-    float pnew[C::OWN][DIM];   // their positions leaving the layer
 #pragma unroll
     for (int s = 0; s < C::OWN; ++s) {
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) {
         dHs[s][0][ct] = zero4; dHs[s][1][ct] = zero4;
         const int rel = 16 * ct + c - (wave + WK_NW * s) * DIM;  // unit directions: d pos_i[k][d] = [d == i dim + k]
-        dPn[s][ct] = f32x4{rel == 0 ? 1.f : 0.f, rel == 1 ? 1.f : 0.f, (DIM > 2 && rel == 2) ? 1.f : 0.f, 0.f};
+        if (s < nown && g == 0)
+          dpn[(wave + WK_NW * s) * (NT * 16) + 16 * ct + c] = f32x4{rel == 0 ? 1.f : 0.f, rel == 1 ? 1.f : 0.f, (DIM > 2 && rel == 2) ? 1.f : 0.f, 0.f};
       }
-#pragma unroll
-      for (int k = 0; k < DIM; ++k) pnew[s][k] = 0.f;
-      if (s < nown) publish_dpos(wave + WK_NW * s, dPn[s]);
+      if (s < nown) publish_dpos(wave + WK_NW * s);
     }
 
     WK_STAMP(1);
@@ -309,6 +302,7 @@ __global__ void __launch_bounds__(WK_NW * 64, 2) egnn_div_walker_kernel(WkParams
       const unsigned* mats = p.mats + (size_t)l * WM_COUNT * WK_MAT_W;
       const float* vl = p.vecs + WK_VEC_EMB_F + (size_t)l * WK_VEC_LAYER_F;
       // ------------------------------------------------------------ layer start: tables every wave reads
+      WK_RELANE();
       if (threadIdx.x < WK_VEC_LAYER_F) vecL[threadIdx.x] = vl[threadIdx.x];
       {  // Wa h + b1, Wb h of the owned nodes (columns 0, 1)
         WkFrag xh[1];
@@ -363,8 +357,8 @@ __global__ void __launch_bounds__(WK_NW * 64, 2) egnn_div_walker_kernel(WkParams
       // ------------------------------------------------------------ the owned nodes, one at a time
 #pragma unroll
       for (int s = 0; s < C::OWN; ++s) {
-        if ((p.dbg & 1) && s > 0) __syncthreads();
         if (s >= nown) continue;
+        WK_RELANE();
         const int i = wave + WK_NW * s;
         const f32x4 pi4 = posT[i], p04 = posT[N + i];
         const float pi[3] = {pi4.x, pi4.y, pi4.z}, p0i[3] = {p04.x, p04.y, p04.z};
@@ -537,6 +531,7 @@ __global__ void __launch_bounds__(WK_NW * 64, 2) egnn_div_walker_kernel(WkParams
         wave_lds_fence();
         WK_STAMP(4);
 
+        WK_RELANE();
         // ===== tangent: Acc = [d agg_i x (WK_SA WK_SZ) ; d pos_i update x (SQ WK_SZ)]
         f32x4 acc[3][NT];
 #pragma unroll
@@ -607,8 +602,8 @@ __global__ void __launch_bounds__(WK_NW * 64, 2) egnn_div_walker_kernel(WkParams
             }
           }
         }
-        WK_DUMP(0, acc[0][0].x + acc[1][1].y); WK_DUMP(1, acc[2][0].x + acc[2][2].y); WK_DUMP(2, abar[0][0] + abar[1][3] + abar[2][1]);
         WK_STAMP(5);
+        WK_RELANE();
         {
           // coefficients of dr / de: alpha = M w_r = a o (W2 (g1 o w_r)) + m' (p . w_r), eps likewise -- recomputed here from the
           // factor table (two small products per node) instead of being carried in 16 registers across the edge loop
@@ -653,48 +648,34 @@ __global__ void __launch_bounds__(WK_NW * 64, 2) egnn_div_walker_kernel(WkParams
           }
           wave_lds_fence();  // the factor table has been read: the R / E tables take its place
           WK_STAMP(6);
+          WK_RELANE();
           // ---- R_i [35 rows][slot (j', k')]: Acc_i += R_i dPos_all  (dPos as B fragments every wave reads, K = 64)
           //   rows < 32: -2 Delta_ij',k' alpha_ij' ; column (i, k'): + sum_jj 2 Delta_ij,k' alpha_ij
           //   row 32 + k: -2 Delta_ij',k' alpha3_k - phi/(|d|+1) [k == k'] ; column (i, k'): + the sums
           {
             float* R = FT;
-            {
-              float rv[8][4], r3[3][4], si[8][4], s3[3][4];
 #pragma unroll
-              for (int k2 = 0; k2 < 4; ++k2) {
-                const float m2 = k2 < DIM ? -2.0f * dlt[k2 < 3 ? k2 : 0] : 0.f;
+            for (int k2 = 0; k2 < DIM; ++k2) {
+              const float m2 = -2.0f * dlt[k2];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                  rv[e][k2] = m2 * al[e];
-                  si[e][k2] = k2 < DIM ? -wk_rowsum(rv[e][k2]) : 0.f;
-                }
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {  // coordinate rows (every lane reads the per-edge scalars of its column)
-                  r3[k][k2] = (k2 < DIM && k < DIM) ? fmaf(m2, x8[2 + k], (k == k2) ? -phs : 0.f) : 0.f;
-                  s3[k][k2] = (k2 < DIM && k < DIM) ? -wk_rowsum(r3[k][k2]) : 0.f;
-                }
+              for (int e = 0; e < 8; ++e) {
+                const float v = m2 * al[e];
+                if (cval) R[wk_feat(8 * g + e) * C::R_STRIDE + 4 * j + k2] = v;
+                const float sm = wk_rowsum(v);
+                if (c == 0) R[wk_feat(8 * g + e) * C::R_STRIDE + 4 * i + k2] = -sm;
               }
-              if (cval) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                  *reinterpret_cast<f32x4*>(R + wk_feat(8 * g + e) * C::R_STRIDE + 4 * j) = f32x4{rv[e][0], rv[e][1], rv[e][2], rv[e][3]};
-                if (g == 0) {
-#pragma unroll
-                  for (int k = 0; k < 3; ++k)
-                    *reinterpret_cast<f32x4*>(R + (32 + k) * C::R_STRIDE + 4 * j) = f32x4{r3[k][0], r3[k][1], r3[k][2], r3[k][3]};
-                }
+              for (int k = 0; k < DIM; ++k) {  // coordinate rows (every lane reads the per-edge scalars of its column)
+                const float w3 = fmaf(m2, x8[2 + k], (k == k2) ? -phs : 0.f);
+                if (cval && g == 0) R[(32 + k) * C::R_STRIDE + 4 * j + k2] = w3;
+                const float sm = wk_rowsum(w3);
+                if (lane == 0) R[(32 + k) * C::R_STRIDE + 4 * i + k2] = -sm;
               }
-              if (c == 0) {
+            }
+            if (lane < 35) {  // the pad slot of every node and the slots behind the last node
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                  *reinterpret_cast<f32x4*>(R + wk_feat(8 * g + e) * C::R_STRIDE + 4 * i) = f32x4{si[e][0], si[e][1], si[e][2], si[e][3]};
-                if (g == 0) {
-#pragma unroll
-                  for (int k = 0; k < 3; ++k)
-                    *reinterpret_cast<f32x4*>(R + (32 + k) * C::R_STRIDE + 4 * i) = f32x4{s3[k][0], s3[k][1], s3[k][2], s3[k][3]};
-                }
-              }
-              if (lane < 35) *reinterpret_cast<f32x4*>(R + lane * C::R_STRIDE + 4 * N) = f32x4{0.f, 0.f, 0.f, 0.f};  // slots 4 N .. 4 N + 3
+              for (int n2 = 0; n2 <= N; ++n2) R[lane * C::R_STRIDE + 4 * n2 + 3] = 0.f;
+              R[lane * C::R_STRIDE + 4 * N] = 0.f; R[lane * C::R_STRIDE + 4 * N + 1] = 0.f; R[lane * C::R_STRIDE + 4 * N + 2] = 0.f;
             }
             wave_lds_fence();
 #pragma unroll
@@ -727,6 +708,7 @@ __global__ void __launch_bounds__(WK_NW * 64, 2) egnn_div_walker_kernel(WkParams
             }
           }
           wave_lds_fence();
+          WK_RELANE();
           // ---- E_i^T [direction (j', kk)][36 rows]: Acc_i += (WK_SZ) E_i   (d pos^0 = I: no product needed)
           {
             float* E = FT;
@@ -771,11 +753,11 @@ __global__ void __launch_bounds__(WK_NW * 64, 2) egnn_div_walker_kernel(WkParams
             }
           }
         }
-        WK_DUMP(3, acc[0][0].x + acc[1][1].y); WK_DUMP(4, acc[2][0].x + acc[2][2].y);
         WK_STAMP(7);
+        WK_RELANE();
         WkFrag xh[NT];
+        if (!first) wk_frags<NT>(dHs[s], 1.0f, xh);
         if (!first) {  // (sum_j M_ij) (Wa dH_i)
-          wk_frags<NT>(dHs[s], 1.0f, xh);
           WkMat wa;
           wk_load(wa, mats, WM_WA, lane);
           f32x4 za[2][NT];
@@ -796,16 +778,18 @@ __global__ void __launch_bounds__(WK_NW * 64, 2) egnn_div_walker_kernel(WkParams
             }
         }
         WK_STAMP(8);
+        WK_RELANE();
         // position tangent leaving the layer (lanes g = 0 hold rows 32..35 of the third block)
         {
           const float un = 1.0f / (SQ * WK_SZ);
 #pragma unroll
           for (int ct = 0; ct < NT; ++ct) {
-            dPn[s][ct] = f32x4{fmaf(acc[2][ct].x, un, dPn[s][ct].x), fmaf(acc[2][ct].y, un, dPn[s][ct].y),
-                               fmaf(acc[2][ct].z, un, dPn[s][ct].z), 0.f};
+            if (g == 0) {
+              const f32x4 o = dpn[i * (NT * 16) + 16 * ct + c];
+              dpn[i * (NT * 16) + 16 * ct + c] = f32x4{fmaf(acc[2][ct].x, un, o.x), fmaf(acc[2][ct].y, un, o.y), fmaf(acc[2][ct].z, un, o.z), 0.f};
+            }
           }
-#pragma unroll
-          for (int k = 0; k < DIM; ++k) pnew[s][k] = pi[k] + nodeS[32 + k];
+          if (lane == 0) posNew[i] = f32x4{pi[0] + nodeS[32], pi[1] + nodeS[33], DIM > 2 ? pi[2] + nodeS[34] : 0.f, 0.f};
         }
         if (!last) {  // node model (egnn_temp_conditioned.py:239-243, 284-291), primal (column s) and tangent
           float hs[8], ag[8];
@@ -872,28 +856,30 @@ __global__ void __launch_bounds__(WK_NW * 64, 2) egnn_div_walker_kernel(WkParams
             dHs[s][1][ct] += dho[1][ct] * (1.0f / WK_SW);
           }
         }
-        WK_DUMP(5, dHs[s][0][0].x + dHs[s][1][2].z); WK_DUMP(6, dPn[s][0].x + dPn[s][1].y + dPn[s][2].z);
         wave_lds_fence();
         WK_STAMP(9);
       }
       __syncthreads();
       WK_STAMP(10);
       // ------------------------------------------------------------ publish the layer's results
+      WK_RELANE();
 #pragma unroll
       for (int s = 0; s < C::OWN; ++s) {
         if (s >= nown) continue;
         const int i = wave + WK_NW * s;
-        if (lane == 0) posT[i] = f32x4{pnew[s][0], pnew[s][1], pnew[s][2], 0.f};
-        publish_dpos(i, dPn[s]);
+        if (lane == 0) posT[i] = posNew[i];
+        publish_dpos(i);
         if (last && g == 0) {  // the diagonal entries of the trace: d pos^L_{i,k} / d x_{i,k} - 1
 #pragma unroll
           for (int ct = 0; ct < NT; ++ct) {
             const int rel = 16 * ct + c - i * DIM;
-            if (rel >= 0 && rel < DIM) diag[i * DIM + rel] = (rel == 0 ? dPn[s][ct].x : (rel == 1 ? dPn[s][ct].y : dPn[s][ct].z)) - 1.0f;
+            if (rel >= 0 && rel < DIM) {
+              const f32x4 dp = dpn[i * (NT * 16) + 16 * ct + c];
+              diag[i * DIM + rel] = (rel == 0 ? dp.x : (rel == 1 ? dp.y : dp.z)) - 1.0f;
+            }
           }
         }
       }
-      if (p.dbg & 2) __syncthreads();
     }
     WK_STAMP(11);
     __syncthreads();
@@ -1069,7 +1055,6 @@ int wk_launch(pita_egnn* net, const float* h, const float* x, const float* beta,
   p.coord_scale = net->cfg.coords_range / (float)L;
   p.B = B; p.h = h; p.x = x; p.beta = beta; p.trace = trace; p.out = out;
   p.mark = mark; p.bad_flag = bad_flag; p.bad_seq = bad_seq;
-  p.dbg = getenv("PITA_WK_DBG") ? atoi(getenv("PITA_WK_DBG")) : 0;
   static PerDevice<int> attr_set;
   if (attr_set.get() < s->lds_bytes) {
     PITA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(s->kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1078,7 +1063,6 @@ int wk_launch(pita_egnn* net, const float* h, const float* x, const float* beta,
   }
   long long grid = B < net->n_cu ? B : net->n_cu;  // one workgroup per CU (LDS), walkers strided over the grid
   if (getenv("PITA_WK_GRID")) grid = atoll(getenv("PITA_WK_GRID"));  // development aid
-  if (p.dbg) (void)hipMemcpyToSymbol(HIP_SYMBOL(wk_dbg_flags), &p.dbg, sizeof(int));
   hipLaunchKernelGGL(s->kernel, dim3((unsigned)grid), dim3(WK_NW * 64), s->lds_bytes, st, p);
   PITA_LAUNCH_CHECK();
   return PITA_OK;
@@ -1086,11 +1070,6 @@ int wk_launch(pita_egnn* net, const float* h, const float* x, const float* beta,
 
 }  // namespace pita
 
-#ifdef PITA_WK_DUMP
-extern "C" int pita_wk_dump(float* out, long long n) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(pita::wk_dump), sizeof(float) * n) == hipSuccess ? 0 : -1;
-}
-#endif
 
 #ifdef PITA_WK_STAMPS
 extern "C" int pita_wk_stamps(unsigned long long* out16, int reset) {

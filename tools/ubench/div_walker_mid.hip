@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
@@ -358,7 +359,7 @@ int main(int argc, char** argv) {
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mid_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mid_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mid_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  for (int rep = 0; rep < 10; ++rep) {
+  for (int rep = 0; rep < 40; ++rep) {
     const int var = rep % 5;
     const int NW = var == 1 ? 8 : 4;
     CHECK(hipEventRecord(e0));
@@ -371,6 +372,17 @@ int main(int argc, char** argv) {
     CHECK(hipEventSynchronize(e1));
     float ms;
     CHECK(hipEventElapsedTime(&ms, e0, e1));
+    {  // run-to-run determinism of the whole output
+      static std::vector<float> first[5];
+      std::vector<float> cur((size_t)blocks * NW * 64);
+      CHECK(hipMemcpy(cur.data(), d_out, cur.size() * 4, hipMemcpyDeviceToHost));
+      if (first[var].empty()) first[var] = cur;
+      else {
+        size_t nd = 0;
+        for (size_t i = 0; i < cur.size(); ++i) nd += (memcmp(&cur[i], &first[var][i], 4) != 0);
+        printf("variant %d: %zu of %zu outputs differ from the first launch of this variant\n", var, nd, cur.size());
+      }
+    }
     std::vector<long long> cyc(blocks * 32);
     CHECK(hipMemcpy(cyc.data(), d_cyc, cyc.size() * 8, hipMemcpyDeviceToHost));
     double a[8] = {0}, b[8] = {0}, c[8] = {0};

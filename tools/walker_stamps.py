@@ -4,6 +4,7 @@ import ctypes, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ["PITA_DIV_WALKER"] = "1"
 import pita_amd
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 w = dict(np.load(os.path.join(ROOT, "tests/golden/egnn_weights_trainedlike.npz")))
