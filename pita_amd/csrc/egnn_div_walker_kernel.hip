@@ -67,11 +67,11 @@ struct WkParams {
 // development aid (-DPITA_WK_STAMPS): shader cycles per section of the kernel, summed over all waves
 #ifdef PITA_WK_STAMPS
 __device__ unsigned long long wk_dbg[16];
-#define WK_STAMP(k)                                                                          \
-  do {                                                                                       \
-    const long long _t = __builtin_amdgcn_s_memtime();                                       \
-    if (lane == 0) atomicAdd(&wk_dbg[k], (unsigned long long)(_t - wk_t0));                  \
-    wk_t0 = __builtin_amdgcn_s_memtime();                                                    \
+#define WK_STAMP(k)                                                        \
+  do {                                                                     \
+    const long long _t = __builtin_amdgcn_s_memtime();                     \
+    wk_acc[k] += (unsigned long long)(_t - wk_t0);                         \
+    wk_t0 = _t;                                                            \
   } while (0)
 #else
 #define WK_STAMP(k) do { } while (0)
@@ -253,6 +253,7 @@ __global__ void __launch_bounds__(WK_NW * 64, 2) egnn_div_walker_kernel(WkParams
   };
 #ifdef PITA_WK_STAMPS
   long long wk_t0 = __builtin_amdgcn_s_memtime();
+  unsigned long long wk_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   for (long long wid = blockIdx.x; wid < p.B; wid += gridDim.x) {
     WK_STAMP(0);
@@ -916,6 +917,10 @@ __global__ void __launch_bounds__(WK_NW * 64, 2) egnn_div_walker_kernel(WkParams
       p.out[gi] = fmaf(c_s, p.x[gi], c_out * F);
     }
   }
+#ifdef PITA_WK_STAMPS
+  if ((threadIdx.x & 63) == 0)
+    for (int k = 0; k < 12; ++k) atomicAdd(&wk_dbg[k], wk_acc[k]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------

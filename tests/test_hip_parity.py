@@ -1916,6 +1916,106 @@ def test_jacobian_trace_out_of_range_walkers_fall_back_to_bf16(pa, golden):
     assert rel(df[:20], db[:20]) < 1e-6
 
 
+def _walker_variant(pa, w, variant):
+    kw = dict(hidden_nf=32, n_layers=3, recurrent=True, tanh=True, attention=True, condition_time=True,
+              condition_temperature=True, agg="sum")
+    kw.update({"no_attention": dict(attention=False), "no_tanh": dict(tanh=False), "layers2": dict(n_layers=2),
+               "layers4": dict(n_layers=4), "default": {}}[variant])
+    net = pa.EGNN_dynamics(13, 3, **kw)
+    sd = net.state_dict()
+    gen = torch.Generator().manual_seed(17)
+    for k in sd:
+        src = w.get(k, w.get(k.replace("gcl_3", "gcl_1")))
+        sd[k] = T(src).clone() if src is not None and tuple(src.shape) == tuple(sd[k].shape) else 0.2 * torch.randn(sd[k].shape, generator=gen)
+    net.load_state_dict(sd)
+    return net
+
+
+@pytest.mark.parametrize("weights", ["egnn_weights_trainedlike.npz", "egnn_weights_seed12345.npz"])
+@pytest.mark.parametrize("variant", ["default", "no_attention", "no_tanh", "layers2", "layers4"])
+def test_walker_resident_trace_vs_oracle_and_cached_path(pa, golden, monkeypatch, weights, variant):
+    """egnn_div_walker_kernel.hip (opt-in: PITA_DIV_WALKER=1) -- all 39 directions as the column dimension of the matrix
+    instructions, one workgroup per walker, no primal cache: trace and denoiser against the fp64 oracle's vmap(jacrev)
+    (the reference's exact divergence, utils.py:30-51) at the tolerance of the cached path's test, and against the cached
+    path itself; measured errors printed."""
+    from torch.func import jacrev, vmap
+
+    w = golden(weights)
+    net = _walker_variant(pa, w, variant)
+    wt = {k: v.double() for k, v in net.state_dict().items()}
+    L = {"layers2": 2, "layers4": 4}.get(variant, 3)
+    B = 43
+    gen = torch.Generator().manual_seed(11)
+    h = torch.tensor([0.0025, 0.01, 0.3, 2.0, 40.0, 900.0, 6400.0, 1.0])[torch.arange(B) % 8]
+    x = O.remove_mean(torch.randn(B, 39, generator=gen) * (1 + h.sqrt())[:, None], 13, 3)
+    beta = torch.rand(B, generator=gen) + 0.7
+    monkeypatch.setenv("PITA_DIV_WALKER", "1")
+    tw, dw_ = net.jacobian_trace(h.cuda(), x.cuda(), beta.cuda(), want_denoiser=True)
+    monkeypatch.setenv("PITA_DIV_WALKER", "0")
+    tc, dc = net.jacobian_trace(h.cuda(), x.cuda(), beta.cuda(), want_denoiser=True)
+    assert not torch.equal(tw, tc)  # two different kernels did run
+    bb = lambda cn, xs, b: O.egnn_forward(wt, cn, xs, b, 13, 3, n_layers=L, tanh=variant != "no_tanh",
+                                          attention=variant != "no_attention")
+    one = lambda hh, xx, b: O.denoiser(bb, hh[None], xx[None], b[None])[0]
+    J = vmap(jacrev(one, argnums=1))(h.double(), x.double(), beta.double())
+    want = torch.diagonal(J, dim1=1, dim2=2).sum(-1)
+    scale = float(want.abs().mean()) + 1.0
+    ew = float(((tw.cpu().double() - want).abs() / (want.abs() + scale)).max())
+    ec = float(((tc.cpu().double() - want).abs() / (want.abs() + scale)).max())
+    print(f"\n{weights} {variant}: walker-resident kernel max err {ew:.2e}, cached path {ec:.2e}; denoiser {rel(dw_, dc):.1e}")
+    np.testing.assert_allclose(tw.cpu().numpy(), want.numpy(), rtol=5e-5, atol=5e-5 * scale)
+    np.testing.assert_allclose(tw.cpu().numpy(), tc.cpu().numpy(), rtol=2e-5, atol=2e-5 * scale)
+    assert rel(dw_, dc) < 1e-6 and torch.isfinite(tw).all()
+
+
+def test_walker_resident_trace_run_to_run(pa, golden, monkeypatch):
+    """Bitwise reproducibility of the walker-resident kernel over reruns -- many walkers per block, a ragged last round of
+    the walker loop, and a grid much smaller than the chip (the configurations in which the packed-fp32 hazard of
+    profiles/r05_walker_packed_fp32_hazard.txt showed) -- and independence of the grid size."""
+    w = golden("egnn_weights_trainedlike.npz")
+    net4 = _walker_variant(pa, w, "layers4")
+    net3 = _walker_variant(pa, w, "default")
+    monkeypatch.setenv("PITA_DIV_WALKER", "1")
+    for B, grid in ((8192, None), (300, None), (64, "8"), (300, "44")):
+        if grid:
+            monkeypatch.setenv("PITA_WK_GRID", grid)
+        else:
+            monkeypatch.delenv("PITA_WK_GRID", raising=False)
+        gen = torch.Generator().manual_seed(B)
+        x = O.remove_mean(torch.randn(B, 39, generator=gen) * 1.5, 13, 3).cuda()
+        h, b = torch.full((B,), 1.0).cuda(), torch.ones(B).cuda()
+        for net in (net3, net4):
+            first = net.jacobian_trace(h, x, b).clone()
+            for _ in range(7):
+                assert torch.equal(net.jacobian_trace(h, x, b), first), (B, grid)
+    monkeypatch.setenv("PITA_WK_GRID", "97")
+    a = net3.jacobian_trace(h, x, b).clone()
+    monkeypatch.setenv("PITA_WK_GRID", "256")
+    assert torch.equal(net3.jacobian_trace(h, x, b), a)  # the walker -> block assignment does not enter the arithmetic
+
+
+def test_walker_resident_trace_marks_out_of_range_walkers(pa, golden, monkeypatch):
+    """Walkers beyond the f16 range come out non-finite in the walker-resident kernel, are marked, and the bf16x3 kernel
+    recomputes exactly those (same contract as the other fast paths): equal to a bf16x3-only handle's result bit for
+    bit; ordinary walkers keep the walker-resident kernel's value; the denoiser follows the same rule."""
+    w = golden("egnn_weights_trainedlike.npz")
+    nf, nb = make_net(pa, 13, 3, w, precision="f16x2"), make_net(pa, 13, 3, w, precision="bf16x3")
+    gen = torch.Generator().manual_seed(5)
+    B = 40
+    x = torch.randn(B, 39, generator=gen)
+    x[20:] *= 2000.0
+    x = O.remove_mean(x, 13, 3).cuda()
+    h, b = torch.full((B,), 0.02).cuda(), torch.ones(B).cuda()
+    monkeypatch.setenv("PITA_DIV_WALKER", "1")
+    tf, df = nf.jacobian_trace(h, x, b, want_denoiser=True)
+    tb, db = nb.jacobian_trace(h, x, b, want_denoiser=True)  # precision 1 handles never take the walker-resident path
+    assert torch.isfinite(tf).all() and torch.isfinite(df).all()
+    assert torch.equal(tf[20:], tb[20:]) and torch.equal(df[20:], db[20:])
+    assert not torch.equal(tf[:20], tb[:20])
+    np.testing.assert_allclose(tf[:20].cpu().numpy(), tb[:20].cpu().numpy(), rtol=2e-5, atol=2e-5)
+    assert rel(df[:20], db[:20]) < 1e-6
+
+
 @pytest.mark.parametrize("n,B", [(22, 9), (55, 3)])
 def test_derivative_kernels_other_shapes(pa, golden, n, B):
     """The 22-atom (alanine dipeptide, config C4) and LJ55 (C5) instantiations of the forward-mode, reverse-mode and
