@@ -231,6 +231,63 @@ def debiased_leg(pita_amd, net, cfg, dev, B, with_cpu):
     return out
 
 
+def e2e_legs(pita_amd, net, cfg, dev, B, n_plain, n_default):
+    """End-to-end numbers at the metric's own length, through the plug-in class (never inside `value`):
+    `not_debiased`   ONE WeightedSDEIntegrator.integrate_sde (sde_integration.py:98-212): B walkers x n_plain steps from
+                     Prior.sample, per-step moments on, resampling off, the f16 repair pass as it falls along the real schedule;
+    `default_regime` n_default steps with debias_inference=True, resampling_interval=1, inference chunks of 512 with their own
+                     0.9-quantile clamp, resample_at_end, 5 adaptive MALA steps at dt = 1e-13 (configs/model/energytemp.yaml:72-84,
+                     experiment/lj13.yaml:24-42; quirk Q9)."""
+    import copy
+
+    import torch
+
+    from pita_amd.energy_net import EnergyNet
+
+    n, d = cfg["n"], cfg["d"]
+    sched = pita_amd.ElucidatingNoiseSchedule(sigma_min=cfg["sigma_min"], sigma_max=80.0, rho=7)
+    gam = pita_amd.ConstantAnnealingFactorSchedule(4 / 3)
+    energy = make_target(pita_amd, cfg, dev)
+    scale = float((sched.h(torch.tensor(1.0)) / gam.gamma(torch.tensor(1.0))) ** 0.5)
+    out = {}
+    for name, N, debias in (("not_debiased", n_plain, False), ("default_regime", n_default, True)):
+        if N <= 0:
+            continue
+        if debias and cfg["target"] not in ("lj",):
+            continue  # the reference's default regime with MALA needs a molecule target with forces (sde_integration.py:397)
+        sde = pita_amd.VEReverseSDE(noise_schedule=sched, score_net=pita_amd.ScoreNet(net),
+                                    energy_net=EnergyNet(copy.deepcopy(net)) if debias else None, debias_inference=debias)
+        kw = dict(resampling_interval=1, batch_size=512, resample_at_end=True, post_mcmc_steps=5, adaptive_mcmc=True,
+                  dt_negative_time=1e-13) if debias else dict(resampling_interval=-1, post_mcmc_steps=0)
+        integ = pita_amd.WeightedSDEIntegrator(sde=sde, num_integration_steps=N, start_resampling_step=0,
+                                               end_resampling_step=int(0.9 * N) if debias else N, num_negative_time_steps=0,
+                                               **kw)
+        x1 = pita_amd.Prior(scale=scale, n_particles=n, spatial_dim=d, device=dev, seed=12345).sample(B)
+        if debias:  # a short run first: handles, primal cache, resampling buffers
+            warm = pita_amd.WeightedSDEIntegrator(sde=sde, num_integration_steps=2, start_resampling_step=0, end_resampling_step=2,
+                                                  num_negative_time_steps=0, **kw)
+            warm.integrate_sde(x1.clone(), energy, gam, inverse_temperature=1.0)
+        else:
+            integ.integrate_sde(x1.clone(), energy, gam, inverse_temperature=1.0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = integ.integrate_sde(x1, energy, gam, inverse_temperature=1.0)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        xf = res[0]
+        out[name] = {"walkers": B, "steps": N, "seconds": dt, "ms_per_step": dt * 1e3 / N, "value": B * N / dt,
+                     "unit": "walker-steps/s", "finite": bool(torch.isfinite(xf).all()),
+                     "what": ("one WeightedSDEIntegrator.integrate_sde from Prior.sample: per-step moments on, resampling off, "
+                              "no MCMC") if not debias else
+                             ("one integrate_sde in the reference's default regime: debias_inference, resampling every step "
+                              "inside [0, 0.9 N), chunks of 512 with their own quantile clamp, resample_at_end, 5 adaptive "
+                              "MALA steps (included in `seconds`)")}
+        if debias:
+            out[name]["distinct_parents_last_event"] = int(res[2][-1]) if len(res[2]) else None
+            out[name]["mala_acceptance"] = [float(a) for a in res[4]]
+    return out
+
+
 def debiased_cpu_baseline(net, cfg, xc):
     """The oracle's debiased drift (autograd + vmap(jacrev)) on a bounded sample, timed on the host cores."""
     import torch
@@ -410,14 +467,53 @@ def rank_breakdown(world, gather_fn, wall_s, launches_s, allgather_s):
             "max_over_min_wall": max(r[0] for r in allr) / max(min(r[0] for r in allr), 1e-12)}
 
 
+def rank_identity(world, rank, dev, rehearsal):
+    """What a multi-rank line says about the ranks it ran on, measured rather than asserted: `rccl_ranks_seen` = an
+    all_reduce(SUM) of ones over the process group, read back; `devices` = every rank's device name and PCI bus id,
+    all-gathered (two ranks on one GPU, or a rank on the wrong device, show here).  `dev` None: gloo dry run."""
+    import torch
+
+    ones = torch.ones(1, dtype=torch.float32, device=dev if (dev is not None and not rehearsal) else "cpu")
+    torch.distributed.all_reduce(ones)
+    if dev is not None:
+        pr = torch.cuda.get_device_properties(dev)
+        bus = getattr(pr, "pci_bus_id", None)
+        mine = {"rank": rank, "device": pr.name, "pci_bus_id": bus if bus is not None else None,
+                "pci": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)),
+                "cuda_index": dev.index, "host": socket.gethostname()}
+    else:
+        mine = {"rank": rank, "device": "cpu (dry run)", "pci": None, "cuda_index": None, "host": socket.gethostname()}
+    devs = [None] * world
+    torch.distributed.all_gather_object(devs, mine)
+    return {"rccl_ranks_seen": int(round(float(ones.item()))), "devices": devs,
+            "distinct_devices": len({(d["host"], d["pci"]) for d in devs}) if dev is not None else None}
+
+
+def init_group(backend, timeout_s, **kw):
+    """init_process_group with a deadline: a rank whose peers never arrive exits non-zero instead of hanging the node
+    (the launcher then tears the job down; nothing here re-executes a process that has touched the GPU)."""
+    import datetime
+
+    import torch
+
+    try:
+        torch.distributed.init_process_group(backend, timeout=datetime.timedelta(seconds=timeout_s), **kw)
+    except Exception as e:  # rendezvous timeout, refused connection, RCCL bootstrap failure
+        print(f"bench.py: rank {os.environ.get('RANK', '?')}: init_process_group({backend}) failed within {timeout_s} s: {e}",
+              file=sys.stderr, flush=True)
+        os._exit(3)
+
+
 def dry_run(args, world, rank):
     """The multi-rank protocol of the real run -- process group, barrier, timed region, max-over-ranks, rank-0 JSON,
     final barrier -- with the kernels replaced by nothing, over gloo on the CPU."""
     import torch
 
+    ident = None
     if world > 1:
-        torch.distributed.init_process_group("gloo")
+        init_group("gloo", args.timeout_s)
         assert torch.distributed.get_world_size() == args.gpus
+        ident = rank_identity(world, rank, None, False)
         torch.distributed.barrier()
     t0 = time.perf_counter()
     shard = torch.full((4, 3), float(rank))
@@ -463,6 +559,8 @@ def dry_run(args, world, rank):
         print(json.dumps({"metric": "dry run (no kernels)", "value": None, "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "scaling": "strong" if args.strong else "weak",
                           "per_rank": per_rank, "resample_exchange": exchange,
+                          "rccl_ranks_seen": ident["rccl_ranks_seen"] if ident else None,
+                          "devices": ident["devices"] if ident else None,
                           "config": {"backend": "gloo" if world > 1 else None}}), flush=True)
     if world > 1:
         torch.distributed.barrier()
@@ -490,6 +588,9 @@ def main():
                     help="with several ranks: after the timed region, time global resampling events (log-weight all-gather + "
                          "systematic resampling + _Comm.exchange_rows) at this shard, as a trajectory that resamples every K "
                          "steps would pay them; reported beside the metric, never inside it")
+    ap.add_argument("--timeout-s", type=float, default=300.0,
+                    help="deadline of init_process_group: a rank whose peers never arrive exits with code 3")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the whole-integrate_sde legs behind the timed region")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / timing protocol only, no kernels and no GPU (gloo): CPU test of the "
                          "multi-rank path; the JSON carries value null")
@@ -519,12 +620,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ident = None
     if world > 1:
         if rehearsal:
-            torch.distributed.init_process_group("gloo")
+            init_group("gloo", args.timeout_s)
         else:
-            torch.distributed.init_process_group("nccl", device_id=dev)
+            init_group("nccl", args.timeout_s, device_id=dev)
         assert torch.distributed.get_world_size() == args.gpus
+        ident = rank_identity(world, rank, dev, rehearsal)
 
     def all_gather(dst, src):
         if rehearsal:
@@ -589,7 +692,9 @@ def main():
         force_rl = force_roofline(pita_amd, cfg, energy, xf, dev, args.force_evals)
         del xf
     if not args.no_debiased and not args.force_last:
-        Bd = B if n <= 22 else min(B, 4096)
+        # LJ55: at the configuration's own shard (32 768 walkers per GPU: the primal cache is processed in chunks of
+        # PITA_DIV_CACHE_GB) unless --walkers asked for something else; rounds 1-4 capped this leg at 4 096
+        Bd = B
         debiased = debiased_leg(pita_amd, net, cfg, dev, Bd, with_cpu=world == 1 and not args.no_cpu_baseline and n <= 13)
     ad2cat = None
     if rank == 0 and world == 1 and args.config == "aldp22" and not args.force_last:
@@ -789,10 +894,21 @@ def main():
         }
         if world > 1:
             out["per_rank"] = per_rank
+            out["rccl_ranks_seen"] = ident["rccl_ranks_seen"]
+            out["devices"] = ident["devices"]
+            out["distinct_devices"] = ident["distinct_devices"]
             if exchange is not None:
                 out["resample_exchange"] = exchange
         if ad2cat is not None:
             out["ad2cat_backbone"] = ad2cat
+        # which part of the reference's 1 000-step grid the timed region covered (t_k = 1 - k / 1000)
+        g0, g1 = W % NGRID, (W + K - 1) % NGRID
+        out["steps_of_grid"] = {"grid_steps": NGRID, "first": g0, "last": g1, "t_first": 1.0 - g0 / NGRID,
+                                "t_last": 1.0 - g1 / NGRID, "wraps": (W + K) > NGRID,
+                                "note": "the timed launches are bare pita_egnn_sampler_run calls along the grid; `e2e` below is "
+                                        "the whole integrate_sde"}
+        if world == 1 and not args.no_e2e:
+            out["e2e"] = e2e_legs(pita_amd, net, cfg, dev, B, NGRID, 100 if n <= 13 else 0)
         if world == 1 and not args.no_cpu_baseline:
             # ~10-20 s of CPU work: the cost per walker-step grows with the number of edges
             steps = args.cpu_steps or max(4, int(300 * 156 / (n * (n - 1))))
@@ -801,7 +917,7 @@ def main():
             out["cpu_baseline"] = None
         if not args.no_debiased:
             if debiased is None:
-                Bd = B if n <= 22 else min(B, 4096)
+                Bd = B
                 debiased = debiased_leg(pita_amd, net, cfg, dev, Bd,
                                         with_cpu=world == 1 and not args.no_cpu_baseline and n <= 13)
             xc = debiased.pop("_x48", None)

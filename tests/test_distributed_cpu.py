@@ -111,6 +111,27 @@ def test_stats_reduction_and_final_gather_order_world2():
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
 
 
+def test_bench_rank_whose_peers_never_arrive_exits_nonzero():
+    """--timeout-s: a rank started with WORLD_SIZE=2 whose peer never shows up leaves init_process_group at the deadline
+    and exits with code 3 (it does not hang the node, and nothing is re-executed)."""
+    import socket
+    import subprocess
+    import sys
+    import time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--timeout-s", "5"],
+                       capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 3, (r.returncode, r.stderr[-1500:])
+    assert "init_process_group" in r.stderr and time.time() - t0 < 200
+
+
 def test_bench_gpus_flag_launches_that_many_ranks():
     """`python bench.py --gpus 2` (no torchrun environment) must start two rank processes itself and report n_gpus = 2;
     a launcher that started a different number of ranks than --gpus must be refused.  --dry-run: protocol only, gloo."""
@@ -132,6 +153,9 @@ def test_bench_gpus_flag_launches_that_many_ranks():
     assert len(pr["wall_s"]) == 2 and len(pr["sampler_launches_s"]) == 2 and len(pr["final_allgather_ms"]) == 2
     assert all(w > 0 for w in pr["wall_s"]) and pr["slowest_rank"] in (0, 1) and pr["max_over_min_wall"] >= 1.0
     assert out["resample_exchange"] is None
+    # ... and verifies the ranks it ran on from its own line: an all_reduce of ones read back, every rank's device gathered
+    assert out["rccl_ranks_seen"] == 2 and [dv["rank"] for dv in out["devices"]] == [0, 1]
+    assert all("device" in dv and "host" in dv for dv in out["devices"])
     # --resample-every: the cost of global resampling events at the shard (log-weight all-gather + _Comm.exchange_rows)
     r3 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
                          "--dry-run", "--resample-every", "1"], capture_output=True, text=True, timeout=300, env=env)
