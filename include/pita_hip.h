@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PITA_ABI_VERSION 8
+#define PITA_ABI_VERSION 9
 
 enum {
   PITA_OK = 0,
@@ -402,6 +402,12 @@ int pita_moments(const float* v, int64_t n, double* out, void* stream);
  * cross_term, dUt_dt; sde_integration.py:150,289). */
 int pita_moments4(const float* v0, const float* v1, const float* v2, const float* v3, int64_t n, double* out /*[8]*/,
                   void* stream);
+/* Histogram of n device floats over nbins + 1 ascending device bin edges, as numpy.histogram / matplotlib's `hist` count
+ * them (bin i = [edges[i], edges[i+1]), the last bin closed; values outside the edges and NaNs are not counted):
+ * counts[nbins] (device, overwritten).  The two 100-bin density arrays under the reference's sample figure
+ * (src/energies/base_molecule_energy_function.py:160-254: bins from the test set, energy range (min - 10, max + 10)) are
+ * these counts divided by (their sum x the bin widths): pita_amd.metrics.sample_histograms.  1 <= nbins <= 1024. */
+int pita_histogram(const float* v, int64_t n, const float* edges, int nbins, unsigned long long* counts, void* stream);
 /* K9: MeanFreePrior.sample (base_prior.py:77-83): x = scale * N(0,1) minus particle mean.
  * noise nullable -> Philox keyed (seed, walker_offset + walker, step = -1). */
 int pita_prior_sample(float* x, const float* noise, int64_t B, int n_particles, int n_dim,

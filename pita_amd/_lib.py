@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpita_hip.so")
 
 STEP_STRIDE = 16
-ABI_VERSION = 8
+ABI_VERSION = 9
 ST_CS, ST_CIN, ST_COUT, ST_CNOISE, ST_H, ST_G2, ST_GAMMA, ST_DT, ST_NOISE_SCALE, ST_SQRT_DT, ST_BETA = range(11)
 
 
@@ -116,6 +116,7 @@ _PROTOS = {
                              c_uint64, c_int64, c_int, c_void_p, c_void_p]),
     "pita_moments": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "pita_moments4": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "pita_histogram": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
     "pita_prior_sample": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_uint64, c_uint64, c_int,
                                   c_void_p]),
     "pita_remove_mean": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p]),

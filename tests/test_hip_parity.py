@@ -2675,6 +2675,55 @@ def test_final_histograms_match_oracle_sampler(pa, golden, N):
         assert abs(w2(got[k], ref[0][k]) - O.w2_1d(got[k], ref[0][k])) < 1e-6 * (1 + seed_to_seed)
         hip_to_ref = max(w2(got[k], ref[0][k]), w2(got[k], ref[1][k]))
         assert hip_to_ref < 4 * seed_to_seed + 1e-3 * float(np.abs(ref[0][k]).mean()), (name, hip_to_ref, seed_to_seed)
+        # the reference's figure view of the same comparison (base_molecule_energy_function.py:160-254): 100-bin densities on
+        # the edges of oracle run 0 (device histogram kernel); bin-wise L1 (total-variation-like, in [0, 2]) of the HIP run
+        # against an oracle run within 4x the oracle's own seed-to-seed L1
+        edges = np.histogram_bin_edges(ref[0][k].astype(np.float32), bins=100)
+        dens = lambda a: metrics._density(metrics.histogram(torch.as_tensor(a, dtype=torch.float32).cuda(), edges), edges)
+        l1 = lambda a, b: float((np.abs(dens(a) - dens(b)) * np.diff(edges.astype(np.float64))).sum())
+        l1_seed, l1_hip = l1(ref[0][k], ref[1][k]), max(l1(got[k], ref[0][k]), l1(got[k], ref[1][k]))
+        print(f"\n{name}: W2 HIP-vs-oracle {hip_to_ref:.4g} (oracle seed to seed {seed_to_seed:.4g}); 100-bin L1 {l1_hip:.4g} (seed to seed {l1_seed:.4g})")
+        assert l1_hip < 4 * l1_seed + 0.02, (name, l1_hip, l1_seed)
+
+
+def test_histogram_kernel_and_reference_sample_histograms(pa):
+    """pita_histogram against numpy.histogram, count for count -- uniform edges from a data range (what matplotlib's
+    `hist(bins=100)` builds), values exactly on edges, out-of-range values, NaNs, a sample much larger than the grid --
+    and pita_amd.metrics.sample_histograms against the reference's own construction of the two 100-bin density pairs
+    (base_molecule_energy_function.py:160-254: distance bins from the test set; energies over (min - 10, max + 10))."""
+    from pita_amd import metrics
+
+    rng = np.random.default_rng(3)
+    for n, nb in ((1, 1), (1000, 7), (300_000, 100), (5_000_000, 1024)):
+        v = rng.normal(2.0, 1.5, n).astype(np.float32)
+        edges = np.histogram_bin_edges(v, bins=nb)
+        v2 = np.concatenate([v, edges[: min(nb + 1, 50)], [np.nan, np.inf, -np.inf, edges[0] - 1.0, edges[-1] + 1.0]]).astype(np.float32)
+        want = np.histogram(v2[np.isfinite(v2)], bins=edges)[0]
+        got = metrics.histogram(torch.from_numpy(v2).cuda(), edges).cpu().numpy()
+        assert got.dtype == np.int64 and np.array_equal(got, want), (n, nb, np.abs(got - want).max())
+    # non-uniform edges (the explicit `bins=` call of the reference's second histogram takes any ascending edges)
+    edges = np.sort(rng.uniform(-3, 8, 65)).astype(np.float32)
+    v = rng.normal(2.0, 3.0, 200_000).astype(np.float32)
+    assert np.array_equal(metrics.histogram(torch.from_numpy(v).cuda(), edges).cpu().numpy(), np.histogram(v, bins=edges)[0])
+    with pytest.raises(pa._lib.PitaHipError):
+        metrics.histogram(torch.zeros(4).cuda(), np.linspace(0, 1, 1026))  # more bins than the kernel's LDS copy holds
+    # the reference's figure numbers on LJ13 configurations
+    energy = pa.LennardJonesEnergy(39, 13, 3)
+    gen = torch.Generator().manual_seed(4)
+    base = O.remove_mean(torch.randn(1, 39, generator=gen) * 0.9, 13, 3)
+    test_set = O.remove_mean(base + 0.08 * torch.randn(5000, 39, generator=gen), 13, 3).cuda()
+    samples = O.remove_mean(base + 0.10 * torch.randn(3000, 39, generator=gen), 13, 3).cuda()
+    h = metrics.sample_histograms(energy, samples, test_set)
+    dt, ds = energy.interatomic_dist(test_set).cpu().numpy().reshape(-1), energy.interatomic_dist(samples).cpu().numpy().reshape(-1)
+    wt, bins = np.histogram(dt, bins=100, density=True)
+    ws, _ = np.histogram(ds, bins=bins, density=True)
+    assert np.array_equal(h["dist_edges"], bins) and np.allclose(h["dist_test"], wt, rtol=0, atol=0) and np.allclose(h["dist_samples"], ws, rtol=0, atol=0)
+    et, es = -energy(test_set).cpu().numpy(), -energy(samples).cpu().numpy()
+    rngE = (float(et.min()) - 10, float(et.max()) + 10)
+    wt, bins = np.histogram(et, bins=100, density=True, range=rngE)
+    ws, _ = np.histogram(es, bins=bins, density=True, range=rngE)
+    assert np.array_equal(h["energy_edges"], bins) and np.array_equal(h["energy_test"], wt) and np.array_equal(h["energy_samples"], ws)
+    assert abs(float((h["dist_test"] * np.diff(h["dist_edges"])).sum()) - 1.0) < 1e-12
 
 
 def test_checkpoint_to_samples_to_metrics_round_trip(pa, golden, tmp_path):
