@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PITA_ABI_VERSION 9
+#define PITA_ABI_VERSION 10
 
 enum {
   PITA_OK = 0,
@@ -278,9 +278,15 @@ int pita_egnn_jvp(pita_egnn_t* net, const float* h, const float* x, const float*
  * reference's torch.autograd.grad through the network.  Checkpoint scratch is owned by the handle.
  * dot_h (nullable, device [B]): <cot, dD/dh> from the same reverse sweep (it also reaches the h-dependent inputs of the
  * backbone -- time feature ln(h)/8, the scaling c_in(h) -- and the explicit c_s(h), c_out(h)): with cot = x this is the
- * term of dE_theta/dt (sdes.py:218) that otherwise takes a forward-mode launch in the h direction. */
+ * term of dE_theta/dt (sdes.py:218) that otherwise takes a forward-mode launch in the h direction.
+ * dot_parts (nullable, device [B, 2], needs dot_h): the same derivative split the way the reference's energy is written
+ * (energy_net.py:33-41, E = |x|^2 (1 - c_s)/(2h) - c_out/(c_in h) <F, c_in x>):
+ *   dot_parts[b][0] = c_out <cot, F>,   dot_parts[b][1] = <cot, d(c_out F)/dh> = dot_h[b] - c_s'(h) <cot, x>.
+ * pita_fk_assemble builds E_theta and dE_theta/dh from these without the |x|^2/h^2-sized cancellation that the forms
+ * through <D, x> and <x, dD/dh> carry at small h. */
 int pita_egnn_vjp(pita_egnn_t* net, const float* h, const float* x, const float* beta, const float* cot /*nullable*/,
-                  float* out /*nullable*/, float* vjp, float* dot_h /*nullable*/, int64_t B, void* stream);
+                  float* out /*nullable*/, float* vjp, float* dot_h /*nullable*/, float* dot_parts /*nullable*/, int64_t B,
+                  void* stream);
 
 /* Exact trace of the denoiser Jacobian, K unit directions per launch sharing one primal evaluation:
  *   diag_acc[b] += sum_{k < ndir} (J_x D(h, x) e_{dir0+k})_{dir0+k},   1 <= ndir <= pita_egnn_div_directions(net).
@@ -312,10 +318,13 @@ int pita_egnn_div_work(const pita_egnn_t* net, double* mfma16_per_walker, double
  *   drift_A = gamma^2 <-grad U, b> + gamma bs (trace_S - D)/h g2/2 + gamma dU/dt + dgamma U   (NOT yet clamped).
  * be / bs: per-walker inverse temperatures when the energy / score net was built with precondition_beta
  * (score_net.py:36-38, energy_net.py:40-41), NULL = 1.  pin_w = (1-t)^3 and pin_dw = -3 (1-t)^2 with logp_target [B];
- * logp_target NULL = no pinning.  All arrays are device pointers: x, D_E, jtx_E, D_S, drift_X [B,D]; the rest [B]. */
+ * logp_target NULL = no pinning.  All arrays are device pointers: x, D_E, jtx_E, D_S, drift_X [B,D]; the rest [B].
+ * dot_parts ([B, 2] from pita_egnn_vjp, nullable): when given, E = be [|x|^2/(2(1+h)) - s1/h] and
+ * dE/dh = be [-|x|^2/(2(1+h)^2) + s1/h^2 - s2/h] with (s1, s2) = dot_parts[b] -- the same quantities in the
+ * reference's own well-conditioned form; NULL keeps the forms through <D_E, x> and dot_h. */
 int pita_fk_assemble(const float* x, const float* h, const float* g2, const float* dhdt, const float* D_E,
-                     const float* jtx_E, const float* dot_h, const float* D_S, const float* trace_S, float gamma,
-                     float dgamma, const float* beta_e /*nullable*/, const float* beta_s /*nullable*/, float pin_w,
+                     const float* jtx_E, const float* dot_h, const float* dot_parts /*nullable*/, const float* D_S,
+                     const float* trace_S, float gamma, float dgamma, const float* beta_e /*nullable*/, const float* beta_s /*nullable*/, float pin_w,
                      float pin_dw, const float* logp_target /*nullable*/, float* drift_X, float* drift_A, float* div_bt,
                      float* cross, float* dUdt, float* Ut, int64_t B, int D, void* stream);
 /* K11: in place a[c] = min(a[c], quantile_q(a over its chunk)), chunks of `chunk` consecutive walkers, linear

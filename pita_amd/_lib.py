@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpita_hip.so")
 
 STEP_STRIDE = 16
-ABI_VERSION = 9
+ABI_VERSION = 10
 ST_CS, ST_CIN, ST_COUT, ST_CNOISE, ST_H, ST_G2, ST_GAMMA, ST_DT, ST_NOISE_SCALE, ST_SQRT_DT, ST_BETA = range(11)
 
 
@@ -94,13 +94,13 @@ _PROTOS = {
     "pita_egnn_edm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "pita_egnn_jvp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
-    "pita_egnn_vjp": (c_int, [c_void_p] * 8 + [c_int64, c_void_p]),
+    "pita_egnn_vjp": (c_int, [c_void_p] * 9 + [c_int64, c_void_p]),
     "pita_egnn_div_directions": (c_int, [c_void_p]),
     "pita_egnn_div_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                          c_int64, c_void_p]),
     "pita_egnn_jacobian_trace": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "pita_egnn_div_work": (c_int, [c_void_p, POINTER(c_double), POINTER(c_double)]),
-    "pita_fk_assemble": (c_int, [c_void_p] * 9 + [c_float, c_float, c_void_p, c_void_p, c_float, c_float, c_void_p] +
+    "pita_fk_assemble": (c_int, [c_void_p] * 10 + [c_float, c_float, c_void_p, c_void_p, c_float, c_float, c_void_p] +
                          [c_void_p] * 6 + [c_int64, c_int, c_void_p]),
     "pita_quantile_clamp": (c_int, [c_void_p, c_int64, c_int64, c_float, c_void_p]),
     "pita_egnn_sampler_run": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_uint64, c_uint64,

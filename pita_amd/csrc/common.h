@@ -1,6 +1,8 @@
 // Shared host/device helpers for libpita_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
+#include <unordered_map>
 
 #include <cstdarg>
 #include <cstdint>
@@ -52,6 +54,22 @@ struct PerDevice {
   T v[kMaxDevices] = {};
   T& get() { return v[current_device_slot()]; }
 };
+
+// The dynamic-LDS limit of a kernel (hipFuncAttributeMaxDynamicSharedMemorySize) is state of (device, kernel function),
+// not of a handle: two handles that share an instantiation but need different sizes (other n_layers / n_particles) must
+// not lower each other's limit, and a cache "this handle configured it" goes stale when another handle configures the
+// same kernel smaller.  One table per device: kernel -> largest size configured; the attribute is only ever raised.
+inline hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes) {
+  static std::mutex mu;
+  static std::unordered_map<const void*, size_t> configured[kMaxDevices];
+  std::lock_guard<std::mutex> lock(mu);
+  auto& m = configured[current_device_slot()];
+  const auto it = m.find(kernel);
+  if (it != m.end() && it->second >= bytes) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) m[kernel] = bytes;
+  return e;
+}
 
 // ---- device math with explicit accuracy choices
 // exp2/rcp map to single v_exp_f32 / v_rcp_f32 (about 1 ulp); used where the reference applies

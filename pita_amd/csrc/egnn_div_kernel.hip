@@ -2381,8 +2381,7 @@ static int ensure_marks(pita_egnn_t* net, size_t B, hipStream_t st) {
 
 static int div_launch(const DivShape* s, void (*kernel)(DivParams), pita_egnn_t* net, const DivParams& p, void* stream) {
   const size_t lds = s->lds_bytes(p.n_layers);
-  PITA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds));
+  PITA_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds));
   const long long ngroups = (p.B + s->G - 1) / s->G;
   long long want = (ngroups + s->waves - 1) / s->waves;
   const long long cap = (long long)net->n_cu * s->occ;  // one 4-wave block per CU (one wave per SIMD) unless built for more
@@ -2600,8 +2599,7 @@ extern "C" int pita_egnn_jacobian_trace(pita_egnn_t* net, const float* h, const 
     // remaining directions from the cache
     p.out = nullptr;
     const size_t lds = ts->lds_bytes(L);
-    PITA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ts->kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds));
+    PITA_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(ts->kernel), lds));
     int per_launch = ts->shared ? ts->K * ts->waves : ts->K;
     if (ts->shared && D > first_k) {  // equal shares for the launches the remaining directions need anyway
       const int nl = (D - first_k + per_launch - 1) / per_launch;

@@ -1060,12 +1060,7 @@ int wk_launch(pita_egnn* net, const float* h, const float* x, const float* beta,
   p.coord_scale = net->cfg.coords_range / (float)L;
   p.B = B; p.h = h; p.x = x; p.beta = beta; p.trace = trace; p.out = out;
   p.mark = mark; p.bad_flag = bad_flag; p.bad_seq = bad_seq;
-  static PerDevice<int> attr_set;
-  if (attr_set.get() < s->lds_bytes) {
-    PITA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(s->kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       s->lds_bytes));
-    attr_set.get() = s->lds_bytes;
-  }
+  PITA_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(s->kernel), (size_t)s->lds_bytes));
   long long grid = B < net->n_cu ? B : net->n_cu;  // one workgroup per CU (LDS), walkers strided over the grid
   if (getenv("PITA_WK_GRID")) grid = atoll(getenv("PITA_WK_GRID"));  // development aid
   hipLaunchKernelGGL(s->kernel, dim3((unsigned)grid), dim3(WK_NW * 64), s->lds_bytes, st, p);

@@ -394,13 +394,7 @@ extern "C" int pita_egnn_jvp(pita_egnn_t* net, const float* h, const float* x, c
   p.B = B; p.h = h; p.x = x; p.beta = beta; p.vx = vx; p.dir = dir; p.vh = vh; p.out = out; p.dout = dout;
   p.dot_out = dot_out; p.dot_stride = dot_stride > 0 ? dot_stride : 1; p.dot_off = dot_off; p.diag_acc = diag_acc;
   const size_t lds = s->lds_bytes(p.n_layers);
-  static thread_local PerDevice<const void*> configured_on;  // the opt-in is per device
-  const void*& configured = configured_on.get();
-  if (configured != (const void*)s->kernel) {
-    PITA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(s->kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = (const void*)s->kernel;
-  }
+  PITA_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(s->kernel), lds));
   const long long ngroups = (B + s->G - 1) / s->G;
   long long want = (ngroups + s->waves - 1) / s->waves;
   const long long cap = (long long)net->n_cu * s->occ;  // occ 4-wave blocks per CU

@@ -811,11 +811,9 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
   hipError_t e3 = hipSuccess;
   for (int a = 0; a < 3 && e3 == hipSuccess; ++a)
     for (int b = 0; b < 2 && e3 == hipSuccess; ++b) {
-      e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(shape->kernel[a][b]),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      e3 = ensure_dynamic_lds(reinterpret_cast<const void*>(shape->kernel[a][b]), lds);
       if (e3 == hipSuccess && shape_small)
-        e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(shape_small->kernel[a][b]),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shape_small->lds_bytes(L));
+        e3 = ensure_dynamic_lds(reinterpret_cast<const void*>(shape_small->kernel[a][b]), shape_small->lds_bytes(L));
     }
   if (e3 != hipSuccess) {
     pita_egnn_destroy(net);

@@ -41,6 +41,8 @@ struct VjpParams {
   float* vjp;         // [B, D] J_x D^T cot
   float* dot_h;       // nullable [B]: <cot, dD/dh> -- the reverse sweep also reaches the inputs that depend on h (time
                       // feature, c_in scaling) and the explicit c_s(h), c_out(h): no forward-mode launch needed
+  float* dot_parts;   // nullable [B, 2] (needs dot_h): { c_out <cot, F>,  <cot, d(c_out F)/dh> = dot_h - c_s'(h) <cot, x> }.
+                      // E_theta and dE_theta/dh assembled from these carry no 1/h^2-sized cancellation (fk_kernels.hip)
   float* ws;          // checkpoint scratch: total_waves * ws_f floats
   const int* mark;    // repair pass (nullable): only the walkers marked by vjp_mark_kernel are recomputed and written
   const int* flag;    // repair pass: 0 = nothing was marked, return at once
@@ -185,7 +187,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
     const int ntile = (ncol + 31) >> 5;
     int col[NT], nodei[NT];
     bool valid[NT];
-    float xin[NT][DIM], cot[NT][DIM], c_s[NT], c_in[NT], c_out[NT], hvv[NT], dhacc[NT];
+    float xin[NT][DIM], cot[NT][DIM], c_s[NT], c_in[NT], c_out[NT], hvv[NT], dhacc[NT], facc[NT], cxacc[NT];
     bool a0t[NT], a1t[NT];  // which embedding inputs of this node are the time feature (quirk Q1 layout)
     float posi[NT][DIM], p0i[NT][DIM];
     f32x16 hf[NT];
@@ -203,7 +205,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
       c_in[T] = rs;
       c_out[T] = sqrtf(hv) * rs;
       hvv[T] = hv;
-      dhacc[T] = 0.f;
+      dhacc[T] = 0.f; facc[T] = 0.f; cxacc[T] = 0.f;
       const float tfeat = 0.125f * logf(hv);
 #pragma unroll
       for (int k = 0; k < DIM; ++k) {
@@ -360,7 +362,11 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
           const float dcs = -c_s[T] * c_s[T];                               // d/dh 1/(1+h)
           const float dcin = -0.5f * c_in[T] / op;                          // d/dh (1+h)^-1/2
           const float dcout = 0.5f * c_in[T] / sqrtf(hvv[T]) + sqrtf(hvv[T]) * dcin;
-          dhacc[T] = fmaf(cot[T][k], fmaf(dcs, xin[T][k], dcout * F), dhacc[T]);
+          // the c_s'(h) <cot, x> share is kept apart: it is ~1/h times larger than the rest at small h, and the
+          // assembly of dE/dh cancels it against a closed form (fk_kernels.hip)
+          dhacc[T] = fmaf(cot[T][k], dcout * F, dhacc[T]);
+          facc[T] = fmaf(cot[T][k], c_out[T] * F, facc[T]);
+          cxacc[T] = fmaf(cot[T][k] * dcs, xin[T][k], cxacc[T]);
         }
         pb[T][k] = valid[T] ? c_out[T] * (cot[T][k] - sc / (float)N) : 0.f;  // remove_mean is self-adjoint
       }
@@ -570,7 +576,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
     if (want_h) {
       // through the time feature c_noise = ln(h)/8: t_bar = sum_nodes <h_bar^0, d h^0 / dt>; then one lane per walker
       // adds up its particles' partial sums (both feature halves) in a fixed order
-      float* red = TB;  // [2][NCOLP]
+      float* red = TB;  // [4][NCOLP]: the sweep's sum per feature half, c_out <cot, F>, c_s' <cot, x>
       const f32x16 w0 = lds_vec16(vemb + hh * 16), w1 = lds_vec16(vemb + 32 + hh * 16);
 #pragma unroll
       for (int T = 0; T < NT; ++T) {
@@ -579,14 +585,28 @@ __global__ void __launch_bounds__(WAVES * 64, 1) egnn_vjp_kernel(VjpParams p) {
         for (int r = 0; r < 16; ++r) tb = fmaf(hb[T][r], (a0t[T] ? w0[r] : 0.f) + (a1t[T] ? w1[r] : 0.f), tb);
         const float part = valid[T] ? fmaf(tb, 0.125f / hvv[T], hh == 0 ? dhacc[T] : 0.f) : 0.f;
         red[hh * C::NCOLP + col[T]] = part;
+        if (hh == 0) {
+          red[2 * C::NCOLP + col[T]] = valid[T] ? facc[T] : 0.f;
+          red[3 * C::NCOLP + col[T]] = valid[T] ? cxacc[T] : 0.f;
+        }
       }
       wave_lds_fence();
 #pragma unroll
       for (int T = 0; T < NT; ++T) {
         if (!(valid[T] && hh == 0 && nodei[T] == 0)) continue;
-        float sum = 0.f;
-        for (int q = 0; q < N; ++q) sum += red[col[T] + q] + red[C::NCOLP + col[T] + q];
-        if (!p.mark || p.mark[walker0 + col[T] / N]) p.dot_h[walker0 + col[T] / N] = sum;
+        float sum = 0.f, sum_f = 0.f, sum_x = 0.f;
+        for (int q = 0; q < N; ++q) {
+          sum += red[col[T] + q] + red[C::NCOLP + col[T] + q];
+          sum_f += red[2 * C::NCOLP + col[T] + q];
+          sum_x += red[3 * C::NCOLP + col[T] + q];
+        }
+        if (!p.mark || p.mark[walker0 + col[T] / N]) {
+          p.dot_h[walker0 + col[T] / N] = sum + sum_x;
+          if (p.dot_parts) {
+            p.dot_parts[2 * (walker0 + col[T] / N)] = sum_f;
+            p.dot_parts[2 * (walker0 + col[T] / N) + 1] = sum;
+          }
+        }
       }
       wave_lds_fence();
     }
@@ -640,8 +660,9 @@ static const VjpShape kVjpShapes[] = {
 using namespace pita;
 
 extern "C" int pita_egnn_vjp(pita_egnn_t* net, const float* h, const float* x, const float* beta, const float* cot,
-                             float* out, float* vjp, float* dot_h, int64_t B, void* stream) {
+                             float* out, float* vjp, float* dot_h, float* dot_parts, int64_t B, void* stream) {
   PITA_REQUIRE(net && B >= 0, "pita_egnn_vjp: bad argument");
+  PITA_REQUIRE(dot_h || !dot_parts, "pita_egnn_vjp: dot_parts needs dot_h");
   if (B == 0) return PITA_OK;
   PitaDeviceGuard guard(net->device);
   PITA_REQUIRE(h && x && vjp, "pita_egnn_vjp: null argument");
@@ -655,19 +676,15 @@ extern "C" int pita_egnn_vjp(pita_egnn_t* net, const float* h, const float* x, c
   p.attention = net->cfg.attention; p.tanh_on = net->cfg.tanh; p.feature_layout = net->cfg.feature_layout;
   p.coord_scale = net->cfg.coords_range / (float)net->cfg.n_layers;
   p.B = B; p.h = h; p.x = x; p.beta = beta; p.cot = cot; p.out = out; p.vjp = vjp; p.dot_h = dot_h;
+  p.dot_parts = dot_parts;
   const size_t lds = s->lds_bytes(p.n_layers);
   const int fixed = (p.attention && p.tanh_on && dot_h) ? 1 : 0;
   static const bool force_bf16 = getenv("PITA_VJP_BF16") != nullptr;  // development aid: A/B against the bf16x3 edge GEMMs
   const bool f16 = net->cfg.precision == 2 && !force_bf16;
   p.mats16h = net->d_mats16h;
   hipStream_t st = (hipStream_t)stream;
-  static thread_local PerDevice<const void*> configured_on[2];  // the opt-in is per device
-  auto configure = [&](const void* k, int slot) -> int {
-    const void*& configured = configured_on[slot].get();
-    if (configured != k) {
-      PITA_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      configured = k;
-    }
+  auto configure = [&](const void* k) -> int {
+    PITA_HIP_CHECK(ensure_dynamic_lds(k, lds));
     return PITA_OK;
   };
   const long long ngroups = (B + s->G - 1) / s->G;
@@ -685,7 +702,7 @@ extern "C" int pita_egnn_vjp(pita_egnn_t* net, const float* h, const float* x, c
   p.ws = net->d_ws;
   const auto kernel = s->kernel[fixed];
   if (!f16) {
-    const int rc = configure(reinterpret_cast<const void*>(kernel), 0);
+    const int rc = configure(reinterpret_cast<const void*>(kernel));
     if (rc != PITA_OK) return rc;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(s->waves * 64), lds, st, p);
     PITA_LAUNCH_CHECK();
@@ -704,7 +721,7 @@ extern "C" int pita_egnn_vjp(pita_egnn_t* net, const float* h, const float* x, c
   int* flag = mark + B;
   PITA_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), st));
   const auto kernel16 = s->kernel16[fixed];
-  int rc = configure(reinterpret_cast<const void*>(kernel16), 1);
+  int rc = configure(reinterpret_cast<const void*>(kernel16));
   if (rc != PITA_OK) return rc;
   hipLaunchKernelGGL(kernel16, dim3(grid), dim3(s->waves * 64), lds, st, p);
   PITA_LAUNCH_CHECK();
@@ -713,7 +730,7 @@ extern "C" int pita_egnn_vjp(pita_egnn_t* net, const float* h, const float* x, c
   PITA_LAUNCH_CHECK();
   p.mark = mark;
   p.flag = flag;
-  rc = configure(reinterpret_cast<const void*>(kernel), 0);
+  rc = configure(reinterpret_cast<const void*>(kernel));
   if (rc != PITA_OK) return rc;
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(s->waves * 64), lds, st, p);
   PITA_LAUNCH_CHECK();

@@ -23,9 +23,6 @@ struct pita_egnn_wide {
   size_t jbad_bytes = 0;
   float* d_vjp_ws = nullptr;  // reverse-mode kernel (vector pipe): per-wave checkpoints of the forward sweep
   size_t vjp_ws_bytes = 0;
-  bool vjp_attr = false;    // dynamic-LDS opt-in of the reverse-mode kernel done
-  bool jvp64_attr = false;  // dynamic-LDS opt-in of the matrix-pipe forward-mode kernel done
-  bool vec_attr[2] = {false, false};  // dynamic-LDS opt-in of the vector-pipe kernel done (evaluation / sampler instantiation)
 };
 
 namespace pita {

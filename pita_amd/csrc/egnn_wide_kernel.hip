@@ -1064,16 +1064,13 @@ extern "C" int pita_egnn_wide_eval(pita_egnn_wide_t* net, int what, const float*
   if (rc != PITA_OK) {
   } else if (per_wave * waves > 150 * 1024) {
     rc = fail(PITA_EUNSUPPORTED, "pita_egnn_wide_eval: %d particles need %zu B of LDS per wave", p.n, per_wave);
-  } else if (!net->vec_attr[0] &&
-             hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)(per_wave * waves)) != hipSuccess) {
+  } else if (ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), per_wave * waves) != hipSuccess) {
     rc = fail(PITA_EHIP, "pita_egnn_wide_eval: cannot reserve %zu B of LDS", per_wave * waves);
   } else {
     const long long want = (B + waves - 1) / waves, cap = (long long)net->n_cu * 8;
     const unsigned grid = (unsigned)(want < cap ? want : cap);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(waves * 64), per_wave * waves, (hipStream_t)stream, p);
     if (hipGetLastError() != hipSuccess) rc = fail(PITA_EHIP, "pita_egnn_wide_eval: launch failed");
-    else net->vec_attr[0] = true;
   }
   if (switched) (void)hipSetDevice(prev);
   return rc;
@@ -1133,8 +1130,7 @@ extern "C" int pita_egnn_wide_jvp(pita_egnn_wide_t* net, const float* h, const f
   if (rc != PITA_OK) {
   } else if (per_wave * waves > 150 * 1024) {
     rc = fail(PITA_EUNSUPPORTED, "pita_egnn_wide_jvp: %d particles need %zu B of LDS per wave", p.n, per_wave);
-  } else if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)(per_wave * waves)) != hipSuccess) {
+  } else if (ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), per_wave * waves) != hipSuccess) {
     rc = fail(PITA_EHIP, "pita_egnn_wide_jvp: cannot reserve %zu B of LDS", per_wave * waves);
   } else {
     const long long want = (B + waves - 1) / waves, cap = (long long)net->n_cu * 2;
@@ -1203,16 +1199,13 @@ extern "C" int pita_egnn_wide_sampler_run(pita_egnn_wide_t* net, float* x, int64
   if (rc != PITA_OK) {
   } else if (per_wave * waves > 150 * 1024) {
     rc = fail(PITA_EUNSUPPORTED, "pita_egnn_wide_sampler_run: %d particles need %zu B of LDS per wave", p.n, per_wave);
-  } else if (!net->vec_attr[1] &&
-             hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)(per_wave * waves)) != hipSuccess) {
+  } else if (ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), per_wave * waves) != hipSuccess) {
     rc = fail(PITA_EHIP, "pita_egnn_wide_sampler_run: cannot reserve %zu B of LDS", per_wave * waves);
   } else {
     const long long want = (B + waves - 1) / waves, cap = (long long)net->n_cu * 8;
     const unsigned grid = (unsigned)(want < cap ? want : cap);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(waves * 64), per_wave * waves, st, p);
     if (hipGetLastError() != hipSuccess) rc = fail(PITA_EHIP, "pita_egnn_wide_sampler_run: launch failed");
-    else net->vec_attr[1] = true;
   }
   if (switched) (void)hipSetDevice(prev);
   return rc;
@@ -1256,13 +1249,8 @@ extern "C" int pita_egnn_wide_vjp(pita_egnn_wide_t* net, const float* h, const f
     if (e != hipSuccess) rc = fail(PITA_EHIP, "pita_egnn_wide_vjp: checkpoint buffer: %s", hipGetErrorString(e));
     else net->vjp_ws_bytes = ws_need;
   }
-  if (rc == PITA_OK && !net->vjp_attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(per_wave * waves)) != hipSuccess)
-      rc = fail(PITA_EHIP, "pita_egnn_wide_vjp: cannot reserve %zu B of LDS", per_wave * waves);
-    else
-      net->vjp_attr = true;
-  }
+  if (rc == PITA_OK && ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), per_wave * waves) != hipSuccess)
+    rc = fail(PITA_EHIP, "pita_egnn_wide_vjp: cannot reserve %zu B of LDS", per_wave * waves);
   if (rc == PITA_OK) {
     q.ws = net->d_vjp_ws;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(waves * 64), per_wave * waves, (hipStream_t)stream, q);

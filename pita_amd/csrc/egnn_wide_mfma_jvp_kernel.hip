@@ -366,10 +366,7 @@ int wide64_jvp(pita_egnn_wide* net, const float* h, const float* x, const float*
   if (!s || s->lds_bytes(net->cfg.n_layers) > 160 * 1024) return 1;
   auto kernel = s->kernel[net->cfg.attention ? 1 : 0][net->cfg.tanh ? 1 : 0];
   const size_t lds = s->lds_bytes(net->cfg.n_layers);
-  if (!net->jvp64_attr) {
-    PITA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    net->jvp64_attr = true;
-  }
+  PITA_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds));
   Wide64JvpParams p{};
   p.m16h = net->d_m16h; p.vecs = net->d_vecs64; p.est = net->d_est64;
   p.L = net->cfg.n_layers; p.has_beta = net->cfg.condition_beta;

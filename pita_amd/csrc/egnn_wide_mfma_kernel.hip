@@ -483,12 +483,11 @@ int wide64_prepare(pita_egnn_wide* net, const float* w, const float* he) {
   if (e == hipSuccess) e = hipMemcpy(net->d_vecs64, hv, n_v * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(net->d_est64, hes, (size_t)n * 64 * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(shape->kernel[cfg.attention ? 1 : 0][cfg.tanh ? 1 : 0]),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shape->lds_bytes(L));
+    e = ensure_dynamic_lds(reinterpret_cast<const void*>(shape->kernel[cfg.attention ? 1 : 0][cfg.tanh ? 1 : 0]),
+                           shape->lds_bytes(L));
   for (const auto& t : kWide64Small)
     if (e == hipSuccess && t.n == shape->n && t.dim == shape->dim)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(t.kernel[cfg.attention ? 1 : 0][cfg.tanh ? 1 : 0]),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes(L));
+      e = ensure_dynamic_lds(reinterpret_cast<const void*>(t.kernel[cfg.attention ? 1 : 0][cfg.tanh ? 1 : 0]), t.lds_bytes(L));
   delete[] hm;
   delete[] hv;
   delete[] hes;

@@ -201,10 +201,15 @@ class EGNN_dynamics(nn.Module):
                        "pita_egnn_jacobian_trace")
         return (trace, den) if want_denoiser else trace
 
-    def vjp(self, h_t, x_t, beta, cot=None, want_primal=True, want_dot_h=False):
+    vjp_h_parts = True  # vjp(..., want_h_parts=True) is available
+
+    def vjp(self, h_t, x_t, beta, cot=None, want_primal=True, want_dot_h=False, want_h_parts=False):
         """(D, J_x D^T cot): the denoiser and its reverse-mode derivative for a per-walker cotangent (default: x_t
         itself, which is what grad_x E_theta needs).  One launch (pita_egnn_vjp) instead of dim JVP launches.
-        ``want_dot_h``: also return <cot, dD/dh> [B] from the same sweep -> (D, vjp, dot_h)."""
+        ``want_dot_h``: also return <cot, dD/dh> [B] from the same sweep -> (D, vjp, dot_h).
+        ``want_h_parts`` (with want_dot_h): also [B, 2] = (c_out <cot, F>, <cot, d(c_out F)/dh>), the split of the same
+        derivative that pita_fk_assemble turns into E_theta and dE_theta/dh without cancellation at small h
+        -> (D, vjp, dot_h, parts)."""
         x_t = _lib.dev_tensor(x_t, "x_t")
         B = x_t.shape[0]
         h_t = _lib.dev_tensor(h_t, "h_t").reshape(-1).expand(B).contiguous()
@@ -214,9 +219,14 @@ class EGNN_dynamics(nn.Module):
         out = torch.empty_like(x_t) if want_primal else None
         vjp = torch.empty_like(x_t)
         dot_h = torch.empty(B, device=x_t.device) if want_dot_h else None
+        if want_h_parts and not want_dot_h:
+            raise ValueError("want_h_parts needs want_dot_h")
+        parts = torch.empty(B, 2, device=x_t.device) if want_h_parts else None
         _lib.check(_lib.lib().pita_egnn_vjp(self._native(x_t.device), h_t.data_ptr(), x_t.data_ptr(), _lib.ptr(b),
-                                            _lib.ptr(cot), _lib.ptr(out), vjp.data_ptr(), _lib.ptr(dot_h), B,
-                                            _lib.stream_ptr(x_t.device)), "pita_egnn_vjp")
+                                            _lib.ptr(cot), _lib.ptr(out), vjp.data_ptr(), _lib.ptr(dot_h),
+                                            _lib.ptr(parts), B, _lib.stream_ptr(x_t.device)), "pita_egnn_vjp")
+        if want_h_parts:
+            return out, vjp, dot_h, parts
         return (out, vjp, dot_h) if want_dot_h else (out, vjp)
 
     def sampler_run(self, x, step_tab, n_steps, noise=None, seed=0, walker_offset=0, step0=0, remove_mean=True,

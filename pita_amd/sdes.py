@@ -171,9 +171,11 @@ class VEReverseSDE:
         dE_theta/dt need.  Backbones without ``vjp`` fall back to dim + 1 forward-mode launches."""
         if not hasattr(model, "vjp"):
             D_E, _, jtx, dot_h = self._denoiser_jacobian_terms(model, ht, x, beta, True)
-            return D_E, jtx, dot_h
+            return D_E, jtx, dot_h, None
+        if getattr(model, "vjp_h_parts", False):  # + the split of <x, dD/dh> that keeps dE/dh free of cancellation
+            return model.vjp(ht, x, beta, want_dot_h=True, want_h_parts=True)
         D_E, jtx, dot_h = model.vjp(ht, x, beta, want_dot_h=True)  # <x, dD/dh> rides on the reverse sweep
-        return D_E, jtx, dot_h
+        return D_E, jtx, dot_h, None
 
     def _score_divergence_terms(self, model, ht, x, beta):
         """D and trace(J_x D) of the score net's denoiser from the multi-direction divergence kernel (dim / K launches;
@@ -233,13 +235,13 @@ class VEReverseSDE:
         gamma = float(gamma_energy.reshape(-1)[0]) if isinstance(gamma_energy, torch.Tensor) else float(gamma_energy)
         dg = gamma_energy_schedule.dgamma_dt(t) if dgamma_dt is None else dgamma_dt
         dgamma = float(dg.reshape(-1)[0]) if isinstance(dg, torch.Tensor) else float(dg)
-        D_E, jtx_E, dot_h = self._energy_gradient_terms(self.energy_net.net, ht, x, beta)
+        D_E, jtx_E, dot_h, h_parts = self._energy_gradient_terms(self.energy_net.net, ht, x, beta)
         D_S, trace_S = self._score_divergence_terms(self.score_net.model, ht, x, beta)
         drift_X = torch.empty_like(x)
         drift_A, div_bt, cross, dUdt, Ut = (torch.empty(B, device=x.device) for _ in range(5))
         _lib.check(_lib.lib().pita_fk_assemble(
             x.data_ptr(), ht.data_ptr(), g2.data_ptr(), dhdt.data_ptr(), D_E.data_ptr(), jtx_E.data_ptr(),
-            dot_h.data_ptr(), D_S.data_ptr(), trace_S.data_ptr(), gamma, dgamma,
+            dot_h.data_ptr(), _lib.ptr(h_parts), D_S.data_ptr(), trace_S.data_ptr(), gamma, dgamma,
             _lib.ptr(beta_b if pb_e else None), _lib.ptr(beta_b if pb_s else None), pin_w, pin_dw, _lib.ptr(logp_t),
             drift_X.data_ptr(), drift_A.data_ptr(), div_bt.data_ptr(), cross.data_ptr(), dUdt.data_ptr(), Ut.data_ptr(),
             B, D, _lib.stream_ptr(x.device)), "pita_fk_assemble")

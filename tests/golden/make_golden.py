@@ -672,7 +672,7 @@ def gen_traj_debias_end():
          drift_A=np.stack([t.drift_A.reshape(B).detach().numpy() for t in terms]))
 
 
-def gen_traj_debias_long():
+def gen_traj_debias_long(weights="egnn_weights_trainedlike.npz", dt_mala=1e-13, name="em_traj_lj13_debias_long.npz", dt_alt=None):
     """PITA's DEFAULT regime at the LJ13 experiment's settings (configs/experiment/lj13.yaml:24-42 with
     model/energytemp.yaml:64-85) over a real horizon: ``debias_inference=True``, ``resampling_interval=1`` (an event
     after EVERY step of the window), two inference chunks per step (per-chunk 0.9-quantile clamp, sdes.py:230),
@@ -682,7 +682,7 @@ def gen_traj_debias_long():
     ``randn_like`` -> pcg_noise(seed), ``torch.rand`` (one float64 uniform per resampling event, utils.py:112) ->
     PCG64(seed + 4), MALA ``randn_like`` -> pcg_noise(seed + 2), MALA ``rand_like`` -> PCG64(seed + 3).
     ``sample_cat_sys`` is wrapped to record the parent ids of every event."""
-    wt = dict(np.load(os.path.join(HERE, "egnn_weights_trainedlike.npz")))
+    wt = dict(np.load(os.path.join(HERE, weights)))
     sde, sched = build_lj13_stack(wt, debias=True)
     N, B, chunk, seed, end = 200, 64, 32, 20261004, 160
     n_mala = 5
@@ -690,7 +690,7 @@ def gen_traj_debias_long():
     integ = sde_integration.WeightedSDEIntegrator(
         sde=sde, num_integration_steps=N, start_resampling_step=0, end_resampling_step=end, lightning_module=FakeLM(),
         partial_annealing_factor_schedule=None, resampling_interval=1, num_negative_time_steps=0,
-        post_mcmc_steps=n_mala, adaptive_mcmc=True, dt_negative_time=1e-13, batch_size=chunk, no_grad=True,
+        post_mcmc_steps=n_mala, adaptive_mcmc=True, dt_negative_time=dt_mala, batch_size=chunk, no_grad=True,
         should_mean_free=True, resample_at_end=True)
     e_raw = LJ(39, 13, 3, data_path="", temperature=1.0)
 
@@ -700,12 +700,16 @@ def gen_traj_debias_long():
         is_molecule, n_particles, n_spatial_dim = True, 13, 3
 
         plain_calls = []  # walkers of the calls without force: [0] end-of-trajectory reweighting (:163), [1] MALA's first (:418)
+        force_calls = []  # mala_proposal (:28-45) asks for the force at the chain's walkers, then at the proposal: [2k] = x of step k
 
         def __call__(self, x, return_force=False):
             if not return_force and len(self.plain_calls) < 2:
                 self.plain_calls.append(x.detach().clone().numpy())
+            if return_force:
+                self.force_calls.append(x.detach().clone().numpy())
             return e_raw(x.detach(), return_force=return_force)
 
+    Detached.plain_calls, Detached.force_calls = [], []
     e = Detached()
     noise = pcg_noise(seed, N, B, 39)
     mala_noise = pcg_noise(seed + 2, n_mala, B, 39)
@@ -754,20 +758,50 @@ def gen_traj_debias_long():
     sde_integration.sample_cat_sys = rec_cat
     try:
         x, logw, uniq, terms, acc = integ.integrate_sde(x1.clone(), e, gamma, inverse_temperature=1.0)
+        alt = None
+        if dt_alt is not None:  # the same chain (same normals and uniforms) from the same walkers at a second step size
+            counts, calls = dict(cnt), list(e.force_calls)
+            cnt["rn"], cnt["ru"] = 2 * N, 0
+            xa, acc_a = integ.metropolis_hastings_mala_adaptive(torch.from_numpy(e.plain_calls[1].copy()), e, dt_init=dt_alt,
+                                                                return_acceptance_rate=True)
+            alt = dict(x_final_alt=xa.detach().numpy(), mala_acc_alt=np.asarray(acc_a), dt_mala_alt=dt_alt)
+            cnt.update(counts)
+            Detached.force_calls = e.force_calls = calls
     finally:
         torch.randn_like, torch.rand, torch.rand_like = real[1:4]
         sde_integration.sample_cat_sys = real[4]
     # the reference's MALA draws one normal tensor in mala_proposal and one uniform tensor per step
     assert cnt == {"f": 2 * N, "rn": 2 * N + n_mala, "u": end + 1, "ru": n_mala}, cnt
     assert len(ids_all) == end + 1 and len(acc) == n_mala
-    out = dict(seed=seed, N=N, B=B, chunk=chunk, end=end, n_mala=n_mala, dt_mala=1e-13, x1=x1.numpy(),
+    # the chain's walkers entering every MALA step + the final ones; a walker whose proposal was accepted moved by
+    # ~sqrt(dt) (remove_mean of a rejected one moves it by rounding only): the accept mask of every step
+    assert len(e.force_calls) == 2 * n_mala and all(c.shape == (B, 39) for c in e.force_calls)  # every log p finite: no reordering (:414-461)
+    x_mala = np.stack([e.force_calls[2 * k] for k in range(n_mala)] + [x.detach().numpy()])
+    moved = np.abs(x_mala[1:] - x_mala[:-1]).max(-1)
+    mala_accept = moved > 1e-3 * np.sqrt(dt_mala)
+    assert np.allclose(mala_accept.mean(1), np.asarray(acc), atol=1e-6), (mala_accept.mean(1), acc)
+    out = dict(seed=seed, N=N, B=B, chunk=chunk, end=end, n_mala=n_mala, dt_mala=dt_mala, x1=x1.numpy(),
+               x_mala=x_mala, mala_accept=mala_accept, logp_post_end=e_raw(torch.from_numpy(e.plain_calls[1])).numpy(),
                x_at=np.stack(xs), at=np.arange(0, N, 20), x_final=x.detach().numpy(), x_pre_end=e.plain_calls[0],
                x_post_end=e.plain_calls[1],
                logweights=logw.detach().numpy(), num_unique=np.asarray(uniq), ids=np.stack(ids_all).astype(np.int16),
                mala_acc=np.asarray(acc), prior_scale=scale, gamma=4 / 3, beta=1.0, sigma_min=0.05)
     for nm in ("drift_A", "divergence_score", "cross_term", "dUt_dt"):
         out[nm] = np.stack([getattr(t, nm).reshape(B).detach().numpy() for t in terms])
-    save("em_traj_lj13_debias_long.npz", **out)
+    if alt is not None:
+        out.update(alt)
+    save(name, **out)
+
+
+def gen_traj_debias_long_init():
+    """The same run on the seed-12345 INITIALISATION weights: a backbone whose output is small leaves the walkers near
+    the EDM skip connection's Gaussian, so the run does NOT collapse -- log p of the walkers after the end-of-trajectory
+    event is finite and of moderate size (-505 .. -755), and the five accept decisions per walker are decided by the
+    arithmetic, not by the sign of a rounding difference.  MALA at dt_negative_time = 1e-5, where the decisions are MIXED
+    (acceptance 0.41 .. 0.44; the accept mask of every step is stored), and the same chain once more at 4e-4 (the
+    step size of post_lj13.npz), where the LJ forces at these walkers make every one of the 320 decisions a rejection."""
+    gen_traj_debias_long(weights="egnn_weights_seed12345.npz", dt_mala=1e-5, name="em_traj_lj13_debias_long_init.npz",
+                         dt_alt=4e-4)
 
 
 def gen_debias_variants():
@@ -897,6 +931,6 @@ def gen_traj_gmm():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["schedules", "lj", "lj_smooth", "gmm", "egnn", "egnn_ad2cat", "egnn_ad2cat_sizes", "egnn_aldp", "mlp", "prior", "resample", "traj_nodebias", "traj_1000",
-                             "traj_debias", "traj_debias_end", "traj_debias_long", "debias_variants", "post", "post55", "traj_1000_lj55", "traj_gmm"]
+                             "traj_debias", "traj_debias_end", "traj_debias_long", "traj_debias_long_init", "debias_variants", "post", "post55", "traj_1000_lj55", "traj_gmm"]
     for w in which:
         globals()["gen_" + w]()

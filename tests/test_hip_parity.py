@@ -892,6 +892,12 @@ def test_egnn_batch_edges(pa, golden, B):
     assert rel(out, ref) < 2e-5
 
 
+# config C1 (GMM target, MLP score net) against the reference's run: first-step drift, final walkers after 100 steps, fused
+# sampler vs the per-step path.  Measured on MI355X 3.8e-10 / 1.7e-7 / 2.6e-8 (profiles/r05_parity_measured.txt); the
+# bounds are 4 x that, floored at one fp32 rounding
+_C1_BOUNDS = (1.2e-7, 7e-7, 1.2e-7)
+
+
 # ------------------------------------------------------------------------------- MLP
 def test_mlp_golden(pa, golden):
     from pita_amd import mlp
@@ -921,13 +927,17 @@ def test_mlp_golden(pa, golden):
                                      should_mean_free=False, record_terms=True)
     xf, logw, uniq, terms, acc = integ.integrate_sde(cu(gt["x1"]), pa.GMM(), pa.ConstantAnnealingFactorSchedule(1.0),
                                                      inverse_temperature=1.0, noise=cu(gt["noise"]))
-    assert rel(terms[0].drift_X, gt["drift_X"][0]) < 1e-4
-    assert rel(xf, gt["x_final"]) < 1e-2
+    # measured on MI355X (printed; profiles/r05_parity_measured.txt): bounds are 4 x the measured deviations
+    print(f"[c1/gmm] first-step drift rel-L2 vs reference {rel(terms[0].drift_X, gt['drift_X'][0]):.2e}, final walkers after "
+          f"{N} steps {rel(xf, gt['x_final']):.2e}")
+    assert rel(terms[0].drift_X, gt["drift_X"][0]) < _C1_BOUNDS[0]
+    assert rel(xf, gt["x_final"]) < _C1_BOUNDS[1]
     # the fused MLP sampler (pita_mlp_sampler_run: all steps in one launch) against the per-step path and the golden
     integ.record_terms = False
     xfu, *_ = integ.integrate_sde(cu(gt["x1"]), pa.GMM(), pa.ConstantAnnealingFactorSchedule(1.0),
                                   inverse_temperature=1.0, noise=cu(gt["noise"]))
-    assert rel(xfu, xf) < 1e-3 and rel(xfu, gt["x_final"]) < 1e-2
+    print(f"[c1/gmm] fused sampler vs per-step path {rel(xfu, xf):.2e}, vs reference {rel(xfu, gt['x_final']):.2e}")
+    assert rel(xfu, xf) < _C1_BOUNDS[2] and rel(xfu, gt["x_final"]) < _C1_BOUNDS[1]
 
 
 @pytest.mark.parametrize("pb", [False, True])
@@ -2096,6 +2106,21 @@ def test_vjp_vs_oracle(pa, golden):
                         want_tangent=False, dot_out=dj)
                 np.testing.assert_allclose(dh.cpu().numpy(), dj.cpu().numpy(), rtol=1e-4,
                                            atol=1e-4 * float(dj.abs().mean()))
+            # the split of the same derivative (dot_parts): c_out <cot, F> and <cot, d(c_out F)/dh>, against the fp64
+            # oracle's backbone output; together with the closed-form c_s'(h) <cot, x> share they are dot_h again
+            _, vj3, dh3, parts = net.vjp(h.cuda(), x.cuda(), beta.cuda(), cot=None if c is None else c.cuda(),
+                                         want_dot_h=True, want_h_parts=True)
+            assert torch.equal(vj3, vj2) and torch.equal(dh3, dh)
+            hd = h.double().requires_grad_(True)
+            c_s, c_in, c_out, c_noise = O.edm_coeffs(hd)
+            s1 = c_out * (bb(c_noise, c_in[:, None] * x.double(), beta.double()) * cc).sum(1)
+            (s2,) = torch.autograd.grad(s1.sum(), hd)
+            np.testing.assert_allclose(parts[:, 0].cpu().numpy(), s1.detach().numpy(), rtol=2e-5,
+                                       atol=2e-5 * float(s1.detach().abs().mean()), err_msg=f"{n} {B} {tag}")
+            np.testing.assert_allclose(parts[:, 1].cpu().numpy(), s2.numpy(), rtol=5e-5, atol=5e-5 * float(s2.abs().mean()),
+                                       err_msg=f"{n} {B} {tag}")
+            whole = parts[:, 1].cpu().double() - (x.double() * cc).sum(1) / (1 + h.double()) ** 2
+            np.testing.assert_allclose(dh.cpu().numpy(), whole.numpy(), rtol=1e-5, atol=1e-5 * float(whole.abs().mean()))
 
 
 def test_vjp_f16_edge_gemms_and_marked_walker_repair(pa, golden):
@@ -2397,17 +2422,25 @@ def test_debiased_resample_at_end_golden(pa, golden):
                                               noise=cu(g["noise"]), resample_u=[float(u[0]) for u in g["u"]])
     assert uniq == list(g["num_unique"])
     assert logw.shape == (N + 1, 12)
-    np.testing.assert_allclose(logw[:N].cpu().numpy(), g["logweights"][:N], rtol=1e-2, atol=1e-2)
-    np.testing.assert_allclose(logw[N].cpu().numpy(), g["logweights"][N], rtol=2e-4)
-    assert rel(x, g["x_final"]) < 3e-3
+    # deviations from the reference's fp32 run, measured on MI355X (printed; profiles/r05_parity_measured.txt); bounds 4 x
+    lw, want = logw.cpu().numpy(), g["logweights"]
+    d_run = float(np.abs(lw[:N] - want[:N]).max() / max(np.abs(want[:N]).mean(), 1e-30))
+    d_end = float(np.abs(lw[N] - want[N]).max() / np.abs(want[N]).mean())
+    print(f"[debias_end] running log-weights max |HIP - reference| / mean |reference| {d_run:.2e}, end-of-trajectory "
+          f"log-weights {d_end:.2e}, final walkers rel-L2 {rel(x, g['x_final']):.2e}")
+    assert d_run < _END_BOUNDS[0] and d_end < _END_BOUNDS[1] and rel(x, g["x_final"]) < _END_BOUNDS[2]
 
 
-def _long_stack(pa, golden):
+# measured 8.4e-6 / 2.3e-7 / 1.8e-6
+_END_BOUNDS = (3.4e-5, 1e-6, 7.2e-6)
+
+
+def _long_stack(pa, golden, weights="egnn_weights_trainedlike.npz"):
     import copy
 
     from pita_amd.energy_net import EnergyNet
 
-    w = golden("egnn_weights_trainedlike.npz")
+    w = golden(weights)
     net = make_net(pa, 13, 3, w)
     sched = pa.ElucidatingNoiseSchedule(sigma_min=0.05, sigma_max=80.0, rho=7)
     sde = pa.VEReverseSDE(noise_schedule=sched, score_net=pa.ScoreNet(net), energy_net=EnergyNet(copy.deepcopy(net)),
@@ -2415,26 +2448,76 @@ def _long_stack(pa, golden):
     return sde, sched, pa.ConstantAnnealingFactorSchedule(4 / 3)
 
 
-def test_debiased_default_regime_long_golden(pa, golden, monkeypatch):
+_LONG = {"trainedlike": ("em_traj_lj13_debias_long.npz", "egnn_weights_trainedlike.npz"),
+         "init": ("em_traj_lj13_debias_long_init.npz", "egnn_weights_seed12345.npz")}
+_TERMS = ("drift_A", "divergence_score", "cross_term", "dUt_dt")
+
+
+def _long_terms_truth(g, w):
+    """fp64 oracle on the ten recorded walker sets of a long fixture (the walkers ENTERING steps 0, 20, ..., 180, which the
+    reference's own fp32 terms of those steps were computed from): {term: [10, B]} per inference chunk of 32."""
+    w64 = {k: T(v).double() for k, v in w.items()}
+    bb = lambda cn, xs, b: O.egnn_forward(w64, cn, xs, b, 13, 3)
+    osched, ogam = O.Elucidating(0.05, 80.0, 7), O.GammaConstant(4 / 3)
+    N, B, chunk = (int(g[k]) for k in ("N", "B", "chunk"))
+    times = torch.linspace(1.0, 0.0, N + 1)[:-1]
+    out = {nm: [] for nm in _TERMS}
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(min(nthreads, 16))
+    try:
+        for k, s in enumerate(g["at"]):
+            x = T(g["x_at"][k]).double()
+            parts = [O.f_debiased(bb, bb, osched, ogam, times[int(s)].double(), x[lo:lo + chunk], 1.0)
+                     for lo in range(0, B, chunk)]
+            for nm in _TERMS:
+                out[nm].append(torch.cat([getattr(p_, nm) for p_ in parts]).numpy())
+    finally:
+        torch.set_num_threads(nthreads)
+    return {nm: np.stack(v) for nm, v in out.items()}
+
+
+@pytest.mark.parametrize("which", ["trainedlike", "init"])
+def test_debiased_default_regime_long_golden(pa, golden, monkeypatch, which):
     """PITA's DEFAULT regime at the LJ13 experiment's settings over a real horizon, against the reference's own run
     (em_traj_lj13_debias_long.npz; configs/experiment/lj13.yaml:24-42, model/energytemp.yaml:64-85): debiased drift,
     a resampling event after EVERY step of the window [0, 160), two inference chunks of 32 (per-chunk 0.9-quantile
-    clamp), resample_at_end, 5 adaptive MALA steps at dt = 1e-13; N = 200, B = 64, the fixture's PCG64 noise and
-    uniforms.  Through WeightedSDEIntegrator.integrate_sde:
+    clamp), resample_at_end, 5 adaptive MALA steps; N = 200, B = 64, the fixture's PCG64 noise and uniforms.
+
+    (1) The weight-drift terms to the standard of the headline kernel: on the ten recorded walker sets the fp64 oracle is
+        the truth, and err(HIP, fp64) <= 4 x err(reference fp32, fp64) for every term of every set (both printed).
+    (2) Through WeightedSDEIntegrator.integrate_sde:
       * the parent ids of all 161 events, event by event.  A differing id must be a +-1 neighbour with the event's
         uniform within fp32 rounding of the bin edge (counted; at most 2 % of the events may have one), and the
         reference's ids are then fed forward so the run stays on the recorded trajectory and EVERY later event is still
         compared exactly;
-      * the weight-drift terms (drift_A after the per-chunk clamp, divergence, cross term, dU/dt) of all 200 steps;
-      * the walkers entering steps 0, 20, ..., 180, the end-of-trajectory log-weights, the final walkers."""
+      * the weight-drift terms of all 200 steps, the walkers entering steps 0, 20, ..., 180, the end-of-trajectory
+        log-weights and the final walkers, bounded at 4 x the deviation measured on MI355X (printed).
+    (3) ``init`` (seed-12345 initialisation weights; em_traj_lj13_debias_long_init.npz): the run does not collapse -- log p
+        after the end-of-trajectory event is -505 .. -755 -- so from the reference's recorded pre-event walkers the
+        event's walkers (x_post_end) are reproduced EXACTLY, and the accept MASK of each of the five MALA steps at
+        dt = 1e-5 (mixed decisions) and the acceptance rates at 4e-4 (all rejected) equal the reference's."""
     from tests._long_fixture import ids_mismatch_is_bin_edge_tie, long_fixture_draws
 
     import pita_amd.sde_integration as si
 
-    g = golden("em_traj_lj13_debias_long.npz")
+    init = which == "init"
+    g = golden(_LONG[which][0])
     N, B, chunk, end, n_mala = (int(g[k]) for k in ("N", "B", "chunk", "end", "n_mala"))
     noise, mala_noise, mala_u, us = long_fixture_draws(g)
-    sde, sched, gam = _long_stack(pa, golden)
+    sde, sched, gam = _long_stack(pa, golden, _LONG[which][1])
+    energy = pa.LennardJonesEnergy(39, 13, 3)
+    times = torch.linspace(1.0, 0.0, N + 1)[:-1]
+
+    # (1) per-term accuracy against fp64 on the recorded walker sets
+    truth = _long_terms_truth(g, golden(_LONG[which][1]))
+    for k, s in enumerate(g["at"]):
+        terms = sde.f(times[int(s)], cu(g["x_at"][k]), 1.0, gam, None, energy, 1, clamp_chunk=chunk)
+        for nm in _TERMS:
+            e_ref, e_hip = rel(g[nm][int(s)], truth[nm][k]), rel(getattr(terms, nm), truth[nm][k])
+            print(f"[long/{which}] step {int(s):3d} {nm:16s}: HIP vs fp64 {e_hip:.2e}, reference vs fp64 {e_ref:.2e}")
+            assert e_hip <= 4 * e_ref, (int(s), nm, e_hip, e_ref)
+
+    # (2) the whole run through the integrator
     integ = pa.WeightedSDEIntegrator(sde=sde, num_integration_steps=N, start_resampling_step=0, end_resampling_step=end,
                                      resampling_interval=1, num_negative_time_steps=0, post_mcmc_steps=n_mala,
                                      adaptive_mcmc=True, dt_negative_time=float(g["dt_mala"]), batch_size=chunk,
@@ -2462,27 +2545,91 @@ def test_debiased_default_regime_long_golden(pa, golden, monkeypatch):
 
     monkeypatch.setattr(si, "sample_cat_sys", forced_cat)
     sde.f = rec_f
-    x, logw, uniq, _, acc = integ.integrate_sde(cu(g["x1"]), pa.LennardJonesEnergy(39, 13, 3), gam, inverse_temperature=1.0,
-                                                noise=cu(noise), resample_u=[float(u) for u in us],
-                                                mala_noise=cu(mala_noise), mala_uniforms=cu(mala_u))
+    try:
+        x, logw, uniq, _, acc = integ.integrate_sde(cu(g["x1"]), energy, gam, inverse_temperature=1.0,
+                                                    noise=cu(noise), resample_u=[float(u) for u in us],
+                                                    mala_noise=cu(mala_noise), mala_uniforms=cu(mala_u))
+    finally:
+        sde.f = real_f
     assert len(events) == end + 1 and len(seen["terms"]) == N
     n_tie = sum(1 for e in events if not e)
     assert n_tie <= max(1, (end + 1) // 50), f"{n_tie} of {end + 1} events needed the bin-edge allowance"
+    # deviations from the reference's own fp32 run along the trajectory: measured on MI355X (printed), bounds 4 x that
+    bound_terms, bound_x = _LONG_BOUNDS[which]
+    worst, worst_at = {nm: 0.0 for nm in _TERMS}, {nm: 0 for nm in _TERMS}
     for s in range(N):
-        for nm in ("drift_A", "divergence_score", "cross_term", "dUt_dt"):
+        for nm in _TERMS:
             want = g[nm][s]
-            np.testing.assert_allclose(getattr(seen["terms"][s], nm).cpu().numpy(), want, rtol=3e-3,
-                                       atol=3e-3 * float(np.abs(want).mean()), err_msg=f"step {s} {nm}")
-    for k in range(len(g["at"])):
-        assert rel(seen["x"][k], g["x_at"][k]) < 3e-3, f"walkers entering step {int(g['at'][k])}"
+            dev_ = float(np.abs(getattr(seen["terms"][s], nm).cpu().numpy() - want).max() / np.abs(want).mean())
+            if dev_ > worst[nm]:
+                worst[nm], worst_at[nm] = dev_, s
+    worst_x = max(rel(seen["x"][k], g["x_at"][k]) for k in range(len(g["at"])))
+    print(f"[long/{which}] along the run, max |HIP - reference| / mean |reference| per term: "
+          + ", ".join(f"{nm} {v:.2e} (step {worst_at[nm]})" for nm, v in worst.items())
+          + f"; walkers entering the recorded steps {worst_x:.2e}, final walkers {rel(x, g['x_final']):.2e}, "
+          f"{n_tie} bin-edge ties")
+    for nm in _TERMS:
+        assert worst[nm] < bound_terms, (nm, worst[nm])
+    assert worst_x < bound_x
     assert logw.shape == (N + 1, B)
     np.testing.assert_array_equal(logw[:N].cpu().numpy(), 0.0)  # an event (or the closed window) resets a every step
     np.testing.assert_allclose(logw[N].cpu().numpy(), g["logweights"][N], rtol=2e-4)
     assert uniq == list(g["num_unique"])  # the fed-forward ids are the reference's
-    assert rel(x, g["x_final"]) < 3e-3
-    # log p ~ -1e10 .. -1e21 on the collapsed final walkers: the 5 accept decisions per walker are signs of rounding
-    # differences, so only the shape of the result is pinned here (post_lj13.npz pins the chain's arithmetic)
-    assert len(acc) == n_mala and all(0.0 <= r <= 1.0 for r in acc)
+    assert len(acc) == n_mala
+    if not init:
+        assert rel(x, g["x_final"]) < bound_x
+        # log p ~ -1e10 .. -1e21 on the collapsed final walkers: the 5 accept decisions per walker are signs of rounding
+        # differences, so only the shape of the result is pinned here (the init fixture pins the decisions)
+        assert all(0.0 <= r <= 1.0 for r in acc)
+        return
+    assert acc == [float(r) for r in g["mala_acc"]]
+    assert rel(x, g["x_final"]) < bound_x
+
+    # (3) the end-of-trajectory event and the chain from the reference's recorded pre-event walkers.  Walkers frozen
+    # (start_resampling_step = N, :278-280) and not re-centred, so the event sees the recorded walkers bit for bit.
+    captured = []
+    integ2 = pa.WeightedSDEIntegrator(sde=sde, num_integration_steps=N, start_resampling_step=N, end_resampling_step=end,
+                                      resampling_interval=1, num_negative_time_steps=0, post_mcmc_steps=n_mala,
+                                      adaptive_mcmc=True, dt_negative_time=float(g["dt_mala"]), batch_size=chunk,
+                                      resample_at_end=True, should_mean_free=False)
+    real_mala = integ2.metropolis_hastings_mala_adaptive
+
+    def rec_mala(xm, *a, **k):
+        captured.append(xm.clone())
+        return real_mala(xm, *a, **k)
+
+    integ2.metropolis_hastings_mala_adaptive = rec_mala
+    events.clear()
+    events.extend([True] * end)  # forced_cat's event counter: the end-of-trajectory event is number `end`
+    x2, logw2, uniq2, _, acc2 = integ2.integrate_sde(cu(g["x_pre_end"]), energy, gam, inverse_temperature=1.0,
+                                                     resample_u=[float(us[end])], mala_noise=cu(mala_noise),
+                                                     mala_uniforms=cu(mala_u))
+    assert events[end], "the end-of-trajectory event's parent ids differ from the reference's"
+    np.testing.assert_array_equal(captured[0].cpu().numpy(), g["x_post_end"])
+    np.testing.assert_allclose(energy(captured[0]).cpu().numpy(), g["logp_post_end"], rtol=5e-6)
+    np.testing.assert_allclose(logw2[N].cpu().numpy(), g["logweights"][N], rtol=2e-4)
+    assert acc2 == [float(r) for r in g["mala_acc"]] and rel(x2, g["x_final"]) < 1e-6
+    # the accept mask of every step: the chain re-run with 1 .. 5 steps (deterministic in its draws); an accepted
+    # proposal moved the walker by ~sqrt(dt), a rejected one only by the re-centring's rounding
+    prev = captured[0]
+    for k in range(1, n_mala + 1):
+        integ2.post_mcmc_steps = k
+        xk, rk = real_mala(captured[0].clone(), energy, dt_init=float(g["dt_mala"]), return_acceptance_rate=True,
+                           noise=cu(mala_noise), uniforms=cu(mala_u))
+        moved = (xk - prev).abs().amax(1).cpu().numpy() > 1e-3 * float(g["dt_mala"]) ** 0.5
+        np.testing.assert_array_equal(moved, g["mala_accept"][k - 1], err_msg=f"accept mask of MALA step {k - 1}")
+        assert rel(xk, g["x_mala"][k]) < 1e-6 and rk == [float(r) for r in g["mala_acc"][:k]]
+        prev = xk
+    integ2.post_mcmc_steps = n_mala
+    xa, ra = real_mala(captured[0].clone(), energy, dt_init=float(g["dt_mala_alt"]), return_acceptance_rate=True,
+                       noise=cu(mala_noise), uniforms=cu(mala_u))
+    assert ra == [float(r) for r in g["mala_acc_alt"]] and rel(xa, g["x_final_alt"]) < 1e-6
+
+
+# bounds of part (2) above: 4 x the deviations measured on MI355X (profiles/r05_parity_measured.txt) -- (terms, walkers).
+# Measured: trained-like 3.3e-6 (divergence, step 199) / 2.2e-7; init 7.4e-4 (dU/dt, step 197: there the REFERENCE's fp32
+# dU/dt is the less accurate of the two -- at step 180 it is 4.0e-5 from fp64, the HIP value 1.5e-6) / 2.4e-7
+_LONG_BOUNDS = {"trainedlike": (1.4e-5, 9e-7), "init": (3e-3, 1e-6)}
 
 
 def test_debiased_default_regime_long_free_run(pa, golden):

@@ -15,7 +15,9 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 def _kernels(obj):
     fb, co = "/tmp/_kr_test.fb", "/tmp/_kr_test.co"
-    subprocess.run([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fb}", obj], check=True, capture_output=True)
+    # (an explicit output file: objcopy without one rewrites its input, and a touched object makes the next build() rebuild)
+    subprocess.run([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fb}", obj, "/tmp/_kr_test.o"], check=True,
+                   capture_output=True)
     subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fb}", f"--output={co}",
                     "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], check=True, capture_output=True)
     txt = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
@@ -58,3 +60,22 @@ def test_register_and_scratch_budgets():
             assert r["scratch"] <= 192, (name, r)
         elif name.startswith("lj13_") or name.startswith("pair_"):
             assert r["scratch"] == 0, (name, r)
+
+
+@pytest.mark.skipif(not os.path.exists(f"{LLVM}/llvm-objdump"), reason="needs the ROCm LLVM binutils")
+def test_walker_resident_kernel_is_built_without_packed_fp32():
+    """egnn_div_walker_kernel.hip must be compiled with packed fp32 vector instructions off (build.py REQUIRED_FILE_FLAGS):
+    with them hipcc's code for this kernel gave rare run-to-run differences on MI355X -- the low half of a v_pk_mul_f32
+    result wrong in lanes 48..63 with intact inputs (profiles/r05_walker_packed_fp32_hazard.txt).  Read from the object:
+    no v_pk_*_f32 in the device code, 256 registers (two 8-wave workgroups do not fit otherwise), bounded scratch."""
+    import pita_amd.build as build
+
+    build.build(verbose=False)
+    assert not build.FALLBACK_OBJECTS, build.FALLBACK_OBJECTS
+    obj = os.path.join(ROOT, "pita_amd", "csrc", "egnn_div_walker_kernel.o")
+    k = _kernels(obj)
+    r = k["egnn_div_walker_kernel<13, 3>"]
+    assert r["vgpr"] + r["agpr"] <= 256 and r["scratch"] <= 256, r
+    asm = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "/tmp/_kr_test.co"], check=True, capture_output=True, text=True).stdout
+    assert "v_mfma_f32_16x16x32_f16" in asm
+    assert not re.search(r"v_pk_(mul|add|fma)_f32", asm)

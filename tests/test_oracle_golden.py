@@ -392,7 +392,8 @@ def test_traj_debias_resample_at_end(golden):
     assert rel(x.numpy(), g["x_final"]) < 2e-3
 
 
-def test_traj_debias_long_default_regime(golden):
+@pytest.mark.parametrize("which", ["trainedlike", "init"])
+def test_traj_debias_long_default_regime(golden, which):
     """PITA's default regime at the LJ13 experiment's settings (em_traj_lj13_debias_long.npz: the reference's
     integrate_sde, debiased, an event after EVERY step of [0, 160), two clamp chunks of 32, resample_at_end, 5 adaptive
     MALA steps at dt = 1e-13; N = 200, B = 64).  The oracle restarts from the ten recorded walker sets (the x entering
@@ -400,11 +401,21 @@ def test_traj_debias_long_default_regime(golden):
     every step against the reference's, and the parent ids of every event IDENTICAL to the reference's (the reference's
     ids are fed forward, so a segment never drifts off the recorded trajectory); then the end-of-trajectory reweighting
     from the recorded pre-event walkers and the MALA chain.  (The full 200-step run is the GPU test's; on this CPU it
-    would take minutes.)"""
+    would take minutes.)
+
+    ``init``: the same run on the seed-12345 initialisation weights (em_traj_lj13_debias_long_init.npz), which does not
+    collapse: log p after the end-of-trajectory event is -505 .. -755, so the MALA accept decisions are arithmetic, and
+    the accept MASK of every step and the walkers after every step are compared exactly / tightly, at dt = 1e-5 (mixed
+    decisions) and at 4e-4 (all rejected)."""
     from tests._long_fixture import ids_mismatch_is_bin_edge_tie, long_fixture_draws
 
-    g = golden("em_traj_lj13_debias_long.npz")
-    bb = _lj13_backbone(golden)
+    init = which == "init"
+    g = golden("em_traj_lj13_debias_long_init.npz" if init else "em_traj_lj13_debias_long.npz")
+    if init:
+        w = {k: T(v) for k, v in golden("egnn_weights_seed12345.npz").items()}
+        bb = lambda cn, xs, b: O.egnn_forward(w, cn, xs, b, 13, 3)
+    else:
+        bb = _lj13_backbone(golden)
     sched, gam = O.Elucidating(0.05, 80.0, 7), O.GammaConstant(4 / 3)
     N, B, chunk, end = (int(g[k]) for k in ("N", "B", "chunk", "end"))
     noise, mala_noise, mala_u, us = long_fixture_draws(g)
@@ -448,14 +459,24 @@ def test_traj_debias_long_default_regime(golden):
     # 5 adaptive MALA steps at dt = 1e-13 (quirk Q9).  log p is ~ -1e10 .. -1e21 on these collapsed walkers, so every
     # accept decision is the sign of a rounding difference: rates are compared loosely, x tightly (moves are ~3e-7).
     lf = lambda xx: O.lj_logp_force(xx, 13, 3)
-    lp, dtm = O.lj_logp(x, 13, 3), float(g["dt_mala"])
-    for k in range(int(g["n_mala"])):
-        x, lp, acc = O.mala_step(x, lp, lf, dtm, T(mala_noise[k]), torch.log(T(mala_u[k])))
-        x = O.remove_mean(x, 13, 3)
-        r = acc.float().mean().item()
-        assert abs(r - g["mala_acc"][k]) < 0.25
-        dtm = dtm * 1.1 if r > 0.55 else dtm / 1.1
-    assert rel(x.numpy(), g["x_final"]) < 1e-5
+    x_post = x
+    for dt0, tag in ((float(g["dt_mala"]), ""),) + (((float(g["dt_mala_alt"]), "_alt"),) if init else ()):
+        x, lp, dtm = x_post, O.lj_logp(x_post, 13, 3), dt0
+        if init:
+            np.testing.assert_allclose(lp.numpy(), g["logp_post_end"], rtol=1e-6)
+        for k in range(int(g["n_mala"])):
+            x, lp, acc = O.mala_step(x, lp, lf, dtm, T(mala_noise[k]), torch.log(T(mala_u[k])))
+            x = O.remove_mean(x, 13, 3)
+            r = acc.float().mean().item()
+            if init:  # decided by finite log-densities: the mask itself, and the chain's walkers after the step
+                assert r == g["mala_acc" + tag][k]
+                if not tag:
+                    np.testing.assert_array_equal(acc.numpy().astype(bool), g["mala_accept"][k])
+                    assert rel(x.numpy(), g["x_mala"][k + 1]) < 1e-6
+            else:
+                assert abs(r - g["mala_acc"][k]) < 0.25
+            dtm = dtm * 1.1 if r > 0.55 else dtm / 1.1
+        assert rel(x.numpy(), g["x_final" + tag]) < (1e-6 if init else 1e-5)
 
 
 @pytest.mark.parametrize("n", [13, 55])
