@@ -744,7 +744,7 @@ def main():
         sde64 = pita_amd.VEReverseSDE(noise_schedule=sched, score_net=sn64, energy_net=_EnergyNet(_copy.deepcopy(net64)),
                                       debias_inference=True)
         xd = pita_amd.Prior(scale=3.0, n_particles=n, spatial_dim=d, device=dev, seed=7).sample(B)
-        td = torch.tensor(0.5, device=dev)
+        td = torch.tensor(0.5)  # host scalar, as the integrator passes the step time (same path as the LJ legs)
         sde64.f(td, xd, 1.0, gam, None, None, clamp_chunk=512)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -908,7 +908,7 @@ def main():
                                 "note": "the timed launches are bare pita_egnn_sampler_run calls along the grid; `e2e` below is "
                                         "the whole integrate_sde"}
         if world == 1 and not args.no_e2e:
-            out["e2e"] = e2e_legs(pita_amd, net, cfg, dev, B, NGRID, 100 if n <= 13 else 0)
+            out["e2e"] = e2e_legs(pita_amd, net, cfg, dev, B, NGRID, 100 if n <= 13 else 20)
         if world == 1 and not args.no_cpu_baseline:
             # ~10-20 s of CPU work: the cost per walker-step grows with the number of edges
             steps = args.cpu_steps or max(4, int(300 * 156 / (n * (n - 1))))

@@ -307,6 +307,9 @@ template <int N, int DIM, int KIND, bool UNIT_RM>
 __global__ void __launch_bounds__(256) ring_descent_kernel(float* __restrict__ x, const float* __restrict__ noise,
                                                            long long B, PairParams p, DescentParams q) {
   using R = Ring<N, DIM>;
+  // the accept counters and seq_sums' shadow-lane handling below are written for the quad and the whole-wave mappings;
+  // the DPP-row mapping (13 particles on 16 lanes) is validated for the energy kernel only
+  static_assert(R::STRIDE == 4 || R::STRIDE == 64, "descent / MALA chains: quad or whole-wave walkers only");
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float* tab = sm + wave * R::TAB_F;
@@ -372,6 +375,9 @@ template <int N, int DIM, int KIND, bool UNIT_RM>
 __global__ void __launch_bounds__(256) ring_mala_kernel(float* __restrict__ x, float* __restrict__ logp, long long B,
                                                         PairParams p, MalaParams q) {
   using R = Ring<N, DIM>;
+  // the accept counters and seq_sums' shadow-lane handling below are written for the quad and the whole-wave mappings;
+  // the DPP-row mapping (13 particles on 16 lanes) is validated for the energy kernel only
+  static_assert(R::STRIDE == 4 || R::STRIDE == 64, "descent / MALA chains: quad or whole-wave walkers only");
   extern __shared__ __attribute__((aligned(16))) float sm[];
   __shared__ int cnt[4];
   __shared__ int total_acc;

@@ -251,13 +251,17 @@ class WeightedSDEIntegrator:
         iterable of float64 uniforms, one per resampling event; ``mala_noise`` [steps, B, D] / ``mala_uniforms``
         [steps, B]: the proposal normals and accept uniforms of the post-processing MALA chain (parity hooks;
         single rank)."""
-        self._mala_draws = (mala_noise, mala_uniforms)
         if resampling_interval is None:
             resampling_interval = self.resampling_interval
         N = self.num_integration_steps
         x1 = _lib.dev_tensor(x1, "x1")
         dev = x1.device
         comm = _Comm(self.lightning_module)
+        mala_draws = (mala_noise, mala_uniforms)
+        if comm.world > 1 and (mala_noise is not None or mala_uniforms is not None):
+            # the hooks are shaped for ONE chain over the whole batch; refuse before the trajectory is integrated
+            raise ValueError("mala_noise / mala_uniforms are single-rank parity hooks (world size is "
+                             f"{comm.world}): every rank draws its own Philox stream instead")
         Bg = x1.shape[0]
         Bl = Bg // comm.world  # sde_integration.py:227
         off = comm.rank * Bl
@@ -293,7 +297,7 @@ class WeightedSDEIntegrator:
         if getattr(self.sde, "debias_inference", False):
             return self._integrate_debiased(x, comm, tab_h, times, noise, key, off, Bl, Bg, n, d, mean_free,
                                             energy_function, annealing_factor_schedule, inverse_temperature,
-                                            resampling_interval, u_iter)
+                                            resampling_interval, u_iter, mala_draws)
 
         s = start
         bounds = events + [N - 1]
@@ -331,13 +335,13 @@ class WeightedSDEIntegrator:
             fn = self.metropolis_hastings_mala_adaptive if self.adaptive_mcmc else self.metropolis_hastings_mala
             kw = dict(dt_init=self.dt_negative_time) if self.adaptive_mcmc else {}
             x, acceptance_rate_list = fn(x, energy_function, return_acceptance_rate=True, walker_offset=off, comm=comm,
-                                         noise=self._mala_draws[0], uniforms=self._mala_draws[1], **kw)
+                                         noise=mala_draws[0], uniforms=mala_draws[1], **kw)
         x = self._gather_final(x, comm, Bl)  # X1: the only collective on the resampling-free path
         return x, logweights, _host_counts(num_unique_idxs), sde_terms_all, acceptance_rate_list
 
     # ------------------------------------------------------------------ debiased regime (per step; section 8(f) N1)
     def _integrate_debiased(self, x, comm, tab_h, times, noise, key, off, Bl, Bg, n, d, mean_free, energy_function,
-                            gamma_schedule, beta, resampling_interval, u_iter):
+                            gamma_schedule, beta, resampling_interval, u_iter, mala_draws=(None, None)):
         """Feynman-Kac weighted integration (sde_integration.py:131-152,214-297 with sdes.py:151-239): per step the
         drift of x and of the log-weights a per inference chunk, Euler-Maruyama update, window gates, global
         systematic resampling when due.  Resampling is global like the reference's: weights and walkers are
@@ -371,6 +375,9 @@ class WeightedSDEIntegrator:
             if st8 is not None:
                 vs = [None if v is None else _lib.dev_tensor(v, "SDETerms field").contiguous()
                       for v in (terms.drift_A, terms.divergence_score, terms.cross_term, terms.dUt_dt)]
+                for v in vs:  # the kernel reads Bl entries of each field
+                    if v is not None and v.numel() != Bl:
+                        raise ValueError(f"SDETerms field has {v.numel()} entries, expected one per walker ({Bl})")
                 _lib.check(L.pita_moments4(*(_lib.ptr(v) for v in vs), Bl, st8[step].data_ptr(), st), "pita_moments4")
             a = a + terms.drift_A * float(row[_lib.ST_DT])
             if step >= self.end_resampling_step:
@@ -409,7 +416,7 @@ class WeightedSDEIntegrator:
             fn = self.metropolis_hastings_mala_adaptive if self.adaptive_mcmc else self.metropolis_hastings_mala
             kw = dict(dt_init=self.dt_negative_time) if self.adaptive_mcmc else {}
             x, acceptance_rate_list = fn(x, energy_function, return_acceptance_rate=True, walker_offset=off, comm=comm,
-                                         noise=self._mala_draws[0], uniforms=self._mala_draws[1], **kw)
+                                         noise=mala_draws[0], uniforms=mala_draws[1], **kw)
         return self._gather_final(x, comm, Bl), logweights, _host_counts(num_unique_idxs), sde_terms_all, acceptance_rate_list
 
     def _gather_final(self, x, comm, Bl):

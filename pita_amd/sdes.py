@@ -126,14 +126,17 @@ class VEReverseSDE:
         """``clamp_chunk`` (extension): evaluate the whole batch in one set of launches but apply the 0.9-quantile
         clamp of the weight drift per chunk of that many walkers -- what the reference gets by calling ``f`` once per
         inference chunk (sde_integration.py:312-343, sdes.py:230), without its per-chunk launch overhead."""
+        if self.debias_inference and isinstance(t, torch.Tensor) and t.dim() == 0 and t.device.type != "cpu":
+            # a 0-dim DEVICE step time is the same thing as the integrator's host scalar: one read up front, then the
+            # scalar path -- the schedule is evaluated by the same (host) code either way, so both give the same bits
+            t = t.detach().cpu()
         gamma_energy = gamma_energy_schedule.gamma(t)  # gamma_score is overwritten by it (sdes.py:142-143)
         if not self.debias_inference:
             t = _per_walker(t, x)
             if isinstance(gamma_energy, torch.Tensor):
                 gamma_energy = gamma_energy.to(x.device)
             return self.f_not_debiased(t, x, beta, gamma_energy)
-        # gamma and dgamma/dt enter the assembly kernel as scalars: taken from the step time AS GIVEN -- a host scalar
-        # (the integrator's) costs nothing, a device tensor costs one synchronisation each
+        # gamma and dgamma/dt enter the assembly kernel as scalars, taken from the (host) step time
         dgamma = gamma_energy_schedule.dgamma_dt(t) if t.dim() == 0 else None
         # a host scalar also gives h(t), g(t)^2 and dh/dt as three fills instead of a dozen element-wise launches on [B]
         sched_scalars = None

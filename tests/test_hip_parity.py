@@ -1941,6 +1941,34 @@ def _walker_variant(pa, w, variant):
     return net
 
 
+def test_handles_of_different_depth_share_kernels(pa, golden):
+    """The dynamic-LDS limit of a kernel is state of (device, kernel function): two live handles that share the
+    instantiations (same particle system and switches) but need different sizes -- 4 layers and 2 layers of per-layer
+    vectors -- must not lower each other's limit.  The deeper handle runs, then the shallower one configures the same
+    kernels smaller, then the deeper one again: same bits as before, on every entry point that opts in to LDS."""
+    w = golden("egnn_weights_trainedlike.npz")
+    deep, shallow = _walker_variant(pa, w, "layers4"), _walker_variant(pa, w, "layers2")
+    B = 29
+    gen = torch.Generator().manual_seed(5)
+    h = torch.tensor([0.01, 0.3, 2.0, 40.0])[torch.arange(B) % 4].cuda()
+    x = O.remove_mean(torch.randn(B, 39, generator=gen) * 1.5, 13, 3).cuda()
+    beta = (torch.rand(B, generator=gen) + 0.7).cuda()
+
+    def everything(net):
+        out = [net(0.125 * torch.log(h), x / (1 + h).sqrt()[:, None], beta)]
+        out += list(net.vjp(h, x, beta, want_dot_h=True))
+        out += list(net.jvp(h, x, beta, direction=3))
+        out += list(net.jacobian_trace(h, x, beta, want_denoiser=True))
+        return [o for o in out if o is not None]
+
+    first = everything(deep)
+    small = everything(shallow)
+    again = everything(deep)
+    assert all(torch.equal(a, b) for a, b in zip(first, again))
+    assert all(bool(torch.isfinite(o).all()) for o in first + small)
+    assert all(torch.equal(a, b) for a, b in zip(small, everything(shallow)))
+
+
 @pytest.mark.parametrize("weights", ["egnn_weights_trainedlike.npz", "egnn_weights_seed12345.npz"])
 @pytest.mark.parametrize("variant", ["default", "no_attention", "no_tanh", "layers2", "layers4"])
 def test_walker_resident_trace_vs_oracle_and_cached_path(pa, golden, monkeypatch, weights, variant):

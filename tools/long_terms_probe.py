@@ -1,7 +1,7 @@
 """Dev probe: per-component errors of the debiased weight drift at one recorded walker set of a long fixture."""
 import sys, os
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import pita_amd as pa
 from tests import test_hip_parity as H

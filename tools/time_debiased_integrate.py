@@ -5,7 +5,7 @@ sys.path.insert(0, ".")
 import pita_amd
 from pita_amd.energy_net import EnergyNet
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-N = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 200  # a real grid: ten steps over the whole schedule throw walkers out of the f16 range
 w = dict(np.load("tests/golden/egnn_weights_trainedlike.npz"))
 net = pita_amd.EGNN_dynamics(13, 3, hidden_nf=32, n_layers=3, recurrent=True, tanh=True, attention=True,
                              condition_time=True, condition_temperature=True, agg="sum")
