@@ -2218,6 +2218,10 @@ def test_vjp_network_variants(pa, golden, variant):
             np.testing.assert_allclose(out[2].cpu().numpy(), gh.numpy(), rtol=5e-5, atol=5e-5 * float(gh.abs().mean()))
 
 
+# drift_X, weight-drift terms, final walkers, log-weights: measured 6.4e-8 / 2.0e-7 / 7.3e-7 / 3.8e-6
+_DEBIAS8_BOUNDS = (2.6e-7, 8e-7, 3e-6, 1.6e-5)
+
+
 def test_debiased_terms_and_trajectory_golden(pa, golden):
     """Feynman-Kac drift terms at identical inputs and the 8-step weighted trajectory with resampling, against the
     reference run stored in em_traj_lj13_debias.npz (autograd + vmap(jacrev) there, HIP JVPs here)."""
@@ -2234,11 +2238,14 @@ def test_debiased_terms_and_trajectory_golden(pa, golden):
     gam = pa.ConstantAnnealingFactorSchedule(4 / 3)
     x1 = cu(g["x1"])
     terms = sde.f(torch.tensor(1.0).cuda(), x1, 1.0, gam, None, None, resampling_interval=2)
-    assert rel(terms.drift_X, g["drift_X"][0]) < 2e-4
-    np.testing.assert_allclose(terms.divergence_score.cpu().numpy(), g["divergence_score"][0], rtol=3e-3, atol=2e-2)
-    np.testing.assert_allclose(terms.cross_term.cpu().numpy(), g["cross_term"][0], rtol=3e-3, atol=2e-2)
-    np.testing.assert_allclose(terms.dUt_dt.cpu().numpy(), g["dUt_dt"][0], rtol=3e-3, atol=2e-2)
-    np.testing.assert_allclose(terms.drift_A.cpu().numpy(), g["drift_A"][0], rtol=3e-3, atol=2e-2)
+    # deviations from the reference's fp32 values at identical inputs: measured on MI355X (printed;
+    # profiles/r05_parity_measured.txt), bounds 4 x measured
+    dev = {nm: float(np.abs(getattr(terms, nm).cpu().numpy() - g[nm][0]).max() / np.abs(g[nm][0]).mean())
+           for nm in ("divergence_score", "cross_term", "dUt_dt", "drift_A")}
+    print(f"[debias8] first step, max |HIP - reference| / mean |reference|: drift_X rel-L2 {rel(terms.drift_X, g['drift_X'][0]):.2e}, "
+          + ", ".join(f"{k} {v:.2e}" for k, v in dev.items()))
+    assert rel(terms.drift_X, g["drift_X"][0]) < _DEBIAS8_BOUNDS[0]
+    assert all(v < _DEBIAS8_BOUNDS[1] for v in dev.values()), dev
     N = int(g["N"])
     integ = pa.WeightedSDEIntegrator(sde=sde, num_integration_steps=N, start_resampling_step=1, end_resampling_step=7,
                                      resampling_interval=2, num_negative_time_steps=0, post_mcmc_steps=0, batch_size=12)
@@ -2246,8 +2253,9 @@ def test_debiased_terms_and_trajectory_golden(pa, golden):
     x, logw, uniq, _, _ = integ.integrate_sde(x1, e, gam, inverse_temperature=1.0, noise=cu(g["noise"]),
                                               resample_u=[float(u[0]) for u in g["u"]])
     assert uniq == list(g["num_unique"])
-    assert rel(x, g["x_final"]) < 3e-3
-    np.testing.assert_allclose(logw.cpu().numpy(), g["logweights"], rtol=1e-2, atol=1e-2)
+    d_lw = float(np.abs(logw.cpu().numpy() - g["logweights"]).max() / np.abs(g["logweights"]).mean())
+    print(f"[debias8] after {N} steps: walkers rel-L2 {rel(x, g['x_final']):.2e}, log-weights max dev / mean {d_lw:.2e}")
+    assert rel(x, g["x_final"]) < _DEBIAS8_BOUNDS[2] and d_lw < _DEBIAS8_BOUNDS[3]
     # whole-batch evaluation with a per-chunk clamp == one call per chunk (the reference's loop)
     xa = pa.Prior(scale=3.0, n_particles=13, spatial_dim=3, seed=4).sample(24)
     t = torch.tensor(0.4).cuda()
@@ -2356,6 +2364,9 @@ class _Foreign(torch.nn.Module):
         return self.net.forward(t, x, beta)
 
 
+_VARIANT_BOUNDS = (8.5e-7, 8e-6)  # drift_X, weight-drift terms: measured <= 2.1e-7 / <= 2.0e-6 over the six (variant, t) cases
+
+
 @pytest.mark.parametrize("name,pin,pb,sch", [("pin", True, False, "elucidating"), ("pb", False, True, "elucidating"),
                                              ("pinpb_geo", True, True, "geometric")])
 def test_debiased_variants_golden(pa, golden, name, pin, pb, sch):
@@ -2381,11 +2392,13 @@ def test_debiased_variants_golden(pa, golden, name, pin, pb, sch):
     for ti, tv in enumerate(g["t"]):
         terms = sde.f(torch.tensor(float(tv)).cuda(), x, beta, gam, None, e, resampling_interval=1)
         key = f"{name}_t{ti}_"
-        assert rel(terms.drift_X, g[key + "drift_X"]) < 3e-4, key
-        for nm in ("drift_A", "divergence_score", "cross_term", "dUt_dt"):
-            ref = g[key + nm]
-            np.testing.assert_allclose(getattr(terms, nm).cpu().numpy(), ref, rtol=3e-3, atol=3e-3 * np.abs(ref).max(),
-                                       err_msg=key + nm)
+        # measured on MI355X (printed; profiles/r05_parity_measured.txt), bounds 4 x the largest measured deviation
+        dev = {nm: float(np.abs(getattr(terms, nm).cpu().numpy() - g[key + nm]).max() / np.abs(g[key + nm]).max())
+               for nm in ("drift_A", "divergence_score", "cross_term", "dUt_dt")}
+        print(f"[variants/{name}] t = {float(tv):.2f}: drift_X rel-L2 {rel(terms.drift_X, g[key + 'drift_X']):.2e}, max |HIP - "
+              "reference| / max |reference|: " + ", ".join(f"{k} {v:.2e}" for k, v in dev.items()))
+        assert rel(terms.drift_X, g[key + "drift_X"]) < _VARIANT_BOUNDS[0], key
+        assert all(v < _VARIANT_BOUNDS[1] for v in dev.values()), (key, dev)
     if pin:
         with pytest.raises(ValueError):
             sde.f(torch.tensor(0.5).cuda(), x, beta, gam, None, None)  # pinning needs the target
