@@ -1002,6 +1002,10 @@ def lj13_stack(pa, golden, **kw):
     return sde, sched, net
 
 
+# final walkers, first drift, worst drift along the run, fused vs per-step: measured 1.7e-7 / 1.0e-8 / 3.3e-7 / 1.7e-7
+_TRAJ20_BOUNDS = (6.8e-7, 1.2e-7, 1.4e-6, 6.8e-7)
+
+
 def test_traj_golden_fused_and_stepwise(pa, golden):
     g = golden("em_traj_lj13_nodebias.npz")
     sde, sched, net = lj13_stack(pa, golden)
@@ -1016,14 +1020,19 @@ def test_traj_golden_fused_and_stepwise(pa, golden):
                                          post_mcmc_steps=0, batch_size=16, record_terms=rec)
         x, logw, uniq, terms, acc = integ.integrate_sde(cu(g["x1"]), e, gam, inverse_temperature=1.0, noise=noise)
         outs[rec] = x
-        assert rel(x, g["x_final"]) < 2e-4
+        # measured on MI355X (printed; profiles/r05_parity_measured.txt); bounds 4 x measured
+        print(f"[traj20/{'per-step' if rec else 'fused'}] final walkers vs the reference's rel-L2 {rel(x, g['x_final']):.2e}")
+        assert rel(x, g["x_final"]) < _TRAJ20_BOUNDS[0]
         assert logw.shape == (N, 32) and float(logw.abs().max()) == 0 and uniq == [32] * N and acc == []
         if rec:
             assert len(terms) == N
-            assert rel(terms[0].drift_X, g["drift_X"][0]) < 1e-4  # per-step drift at identical inputs
-            for k in range(N):
-                assert rel(terms[k].drift_X, g["drift_X"][k]) < 3e-3, k
-    assert rel(outs[False], outs[True]) < 1e-5  # fused launch == per-step launches
+            worst = max(rel(terms[k].drift_X, g["drift_X"][k]) for k in range(N))
+            print(f"[traj20/per-step] drift at identical inputs (step 0) {rel(terms[0].drift_X, g['drift_X'][0]):.2e}, worst step "
+                  f"along the run {worst:.2e}")
+            assert rel(terms[0].drift_X, g["drift_X"][0]) < _TRAJ20_BOUNDS[1]  # per-step drift at identical inputs
+            assert worst < _TRAJ20_BOUNDS[2]
+    print(f"[traj20] fused launch vs per-step launches {rel(outs[False], outs[True]):.2e}")
+    assert rel(outs[False], outs[True]) < _TRAJ20_BOUNDS[3]  # fused launch == per-step launches
     # drift_out of the fused kernel, one step from the golden state
     tab = pa.sde_integration.build_step_table(sched, gam, torch.linspace(1.0, 0.0, N + 1)[:-1], 1.0 / N, 1.0, 1.0)
     x = cu(g["x1"]).clone()
@@ -2428,17 +2437,26 @@ def test_debiased_terms_other_systems_vs_oracle(pa, golden, n, d, B):
     wed = {k: v.double() for k, v in we.items()}
     bs = lambda cn, xs, b: O.egnn_forward(ws, cn, xs, b, n, d)
     be = lambda cn, xs, b: O.egnn_forward(wed, cn, xs, b, n, d)
+    ws32, we32 = {k: T(v) for k, v in w.items()}, {k: v.float() for k, v in we.items()}
+    bs32 = lambda cn, xs, b: O.egnn_forward(ws32, cn, xs, b, n, d)
+    be32 = lambda cn, xs, b: O.egnn_forward(we32, cn, xs, b, n, d)
     osched, ogam = O.Elucidating(0.05, 80.0, 7), O.GammaLinear(1.5, 1.0)
     for tv in (0.15, 0.6):
         hv = float(sched.h(torch.tensor(tv)))
         x = O.remove_mean(torch.randn(B, n * d, generator=gen) * (1 + hv ** 0.5), n, d)
         terms = sde.f(torch.tensor(tv).cuda(), x.cuda(), 1.25, gam, None, None, resampling_interval=1, clamp_chunk=B)
         ref = O.f_debiased(bs, be, osched, ogam, torch.tensor(tv, dtype=torch.float64), x.double(), 1.25)
-        assert rel(terms.drift_X, ref.drift_X) < 3e-4, (n, tv)
-        for nm in ("drift_A", "divergence_score", "cross_term", "dUt_dt"):
-            r = getattr(ref, nm).numpy()
-            np.testing.assert_allclose(getattr(terms, nm).cpu().numpy(), r, rtol=3e-3, atol=3e-3 * np.abs(r).max(),
-                                       err_msg=f"{n} {tv} {nm}")
+        # the same standard as LJ13's: the oracle in float32 is the reference's arithmetic (op for op), its distance from
+        # the float64 oracle the reference's own error; the HIP terms may be at most 4 x as far (floor: one fp32 rounding
+        # of a sum of n * d terms)
+        r32 = O.f_debiased(bs32, be32, osched, ogam, torch.tensor(tv), x, 1.25)
+        names = ("drift_X", "drift_A", "divergence_score", "cross_term", "dUt_dt")
+        e_refs = {nm: rel(getattr(r32, nm), getattr(ref, nm)) for nm in names}
+        typical = float(np.median(list(e_refs.values())))  # 3 .. 9 walkers: one term's fp32 error can be lucky-small
+        for nm in names:
+            e_hip, e_ref = rel(getattr(terms, nm), getattr(ref, nm)), e_refs[nm]
+            print(f"[other/{n}x{d}] t = {tv}: {nm:16s} HIP vs fp64 {e_hip:.2e}, fp32 reference arithmetic vs fp64 {e_ref:.2e}")
+            assert e_hip <= 4 * max(e_ref, typical), (n, tv, nm, e_hip, e_ref, typical)
 
 
 def test_debiased_resample_at_end_golden(pa, golden):
