@@ -892,6 +892,9 @@ def main():
             "roofline": roof,
             "roofline_force": force_rl,
         }
+        # sources the build compiled WITHOUT their optional per-file flags (slower kernels there); [] = none, None = no record
+        from pita_amd import build as _build
+        out["build_fallback_objects"] = _build.fallback_objects()
         if world > 1:
             out["per_rank"] = per_rank
             out["rccl_ranks_seen"] = ident["rccl_ranks_seen"]

@@ -89,6 +89,15 @@ def build(force=False, verbose=True, extra_flags=()):
     return LIB
 
 
+def fallback_objects():
+    """Sources of the library on disk that were compiled WITHOUT their optional per-file flags (slower kernels in those
+    files), as recorded by the build that produced it; None when the record is missing."""
+    path = os.path.join(CSRC, "build_fallbacks.txt")
+    if not os.path.exists(path):
+        return None
+    return [ln.strip() for ln in open(path) if ln.strip()]
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print("built", LIB)
