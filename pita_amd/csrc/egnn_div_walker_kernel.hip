@@ -1062,7 +1062,10 @@ int wk_launch(pita_egnn* net, const float* h, const float* x, const float* beta,
   p.mark = mark; p.bad_flag = bad_flag; p.bad_seq = bad_seq;
   PITA_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(s->kernel), (size_t)s->lds_bytes));
   long long grid = B < net->n_cu ? B : net->n_cu;  // one workgroup per CU (LDS), walkers strided over the grid
-  if (getenv("PITA_WK_GRID")) grid = atoll(getenv("PITA_WK_GRID"));  // development aid
+  if (const char* g = getenv("PITA_WK_GRID")) {  // development aid / test hook: the result must not depend on the grid
+    const long long want = atoll(g);
+    if (want > 0 && want <= 65535) grid = want;
+  }
   hipLaunchKernelGGL(s->kernel, dim3((unsigned)grid), dim3(WK_NW * 64), s->lds_bytes, st, p);
   PITA_LAUNCH_CHECK();
   return PITA_OK;
