@@ -338,6 +338,14 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) egnn_kernel(EgnnParams p) {
           }
           const int cbase = col[T] - nodei[T];
 
+          // Issue priority inside the edge (round 5).  Two waves share a SIMD and one vector issue port.  An edge alternates
+          // between phases that can issue every cycle -- the three 16-wide SiLUs: 16 exp, 16 rcp and their packed adds /
+          // multiplies, all independent -- and phases whose next instruction is rarely ready: the two dense layers (six
+          // dependent matrix instructions with the operand split threaded between them), the two 8-link dot chains, the
+          // gathers.  With equal priorities a wave in a SiLU takes every other issue slot from a partner that is in a
+          // dependent phase, and the partner's matrix chain -- and with it the matrix pipe -- waits.  The SiLUs run at
+          // priority 0, everything else at 1: the wave with the scarce instruction goes first, the SiLU fills what is left.
+          // Same instructions, same bits; 108.3 -> 102.5 ms per 100 steps on one box (profiles/r05_sampler_issue_priority.txt).
           for (int dd = 1; dd < N; ++dd) {
             asm volatile("" ::: "memory");  // keep the per-edge LDS vector loads inside the loop (VGPR budget)
             int j = nodei[T] + dd;
@@ -355,9 +363,13 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) egnn_kernel(EgnnParams p) {
             // edge MLP layer 1 (:232-237,:270-271): Wa h_i + Wb h_j + b1, then one k-step [w_r|w_e]·[radial;ea]
             f32x16 m = Ai + lds_vec16(PB + cj * PBS + hh * 16);
             m = __builtin_amdgcn_mfma_f32_32x32x2f32(a_re, hh ? ea : radial, m, 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
             if (PREC == 2) silu16_out(m); else silu16(m);
+            __builtin_amdgcn_s_setprio(1);
             m = w2f.mul(m, lds_vec16(vl + V_B2 * EH));
+            __builtin_amdgcn_s_setprio(0);
             if (PREC == 2) silu16_acc(m); else silu16(m);
+            __builtin_amdgcn_s_setprio(1);
             if (p.attention) {  // :259-260,:273-275
               const float att = fast_sigmoid(xhalf_sum(dot16(lds_vec16(vl + V_WATT * EH), m)) + b_att);
               m *= att;
@@ -366,7 +378,9 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) egnn_kernel(EgnnParams p) {
             for (int r = 0; r < 16; ++r) agg[r] = fmaf(m[r], aggw, agg[r]);  // node_model aggregation (:284)
             // coordinate head (:245-256,:297-298)
             f32x16 c1 = wc1f.mul(m, lds_vec16(vl + V_BC1 * EH));
+            __builtin_amdgcn_s_setprio(0);
             if (PREC == 2) silu16_acc(c1); else silu16(c1);
+            __builtin_amdgcn_s_setprio(1);
             float cs = xhalf_sum(dot16(lds_vec16(vl + V_WC2 * EH), c1));
             if (p.tanh_on) cs = accurate_tanh(cs) * p.coord_scale;
             // 1 / (|d| + 1) on the transcendental unit (v_sqrt_f32, v_rcp_f32: ~1 ulp each) instead of the IEEE
