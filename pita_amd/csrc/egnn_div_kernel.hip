@@ -1827,8 +1827,15 @@ __global__ void __launch_bounds__(NW * 64, 1) egnn_div_tangent_shared_kernel(Div
                 }
               }
               u32x4 xs[K][2][2];
+              // issue priority (round 5, as in egnn_kernel.hip's edge): the operand split is 32 K independent half-rate
+              // instructions, everything around it waits for single instructions to become ready (ring reads, the matrix
+              // chain, the dot products).  At the lower priority it fills the slots the SIMD partner's dependent phases
+              // leave instead of taking every other one: 19.94 -> 19.05 ms per trace, same bits
+              // (profiles/r05_tangent_issue_priority.txt)
+              __builtin_amdgcn_s_setprio(0);
 #pragma unroll
               for (int d = 0; d < K; ++d) WFrag<2>::split(dz[d], xs[d]);
+              __builtin_amdgcn_s_setprio(1);
 #pragma unroll
               for (int d = 0; d < K; ++d) dz[d] = w2f.mul_split(xs[d], zero16);
               {
