@@ -169,3 +169,47 @@ def test_count_distinct_parents_without_host_unique():
     assert all(isinstance(c, torch.Tensor) and c.dim() == 0 for c in counts)
     got = _host_counts([7] + counts)  # python ints pass through, device scalars are fetched in one transfer
     assert got[0] == 7 and got[1:] == [len(np.unique(c.numpy())) for c in cases]
+
+
+def test_step_table_is_cached_by_value_not_by_object():
+    """build_step_table keeps the last few tables keyed by the VALUES that determine them (both schedules' class and
+    parameters, the time grid, dt, diffusion scale, beta): an equal schedule object gets an equal table without the
+    per-step host loop, any changed parameter a fresh one, and writing into a returned table does not reach the cache."""
+    import torch
+
+    import pita_amd
+    from pita_amd import sde_integration as si
+
+    si._STEP_TABLES.clear()
+    times = torch.linspace(1.0, 0.0, 41)[:-1]
+    mk = lambda smin=0.05: pita_amd.ElucidatingNoiseSchedule(sigma_min=smin, sigma_max=80.0, rho=7)
+    gam = pita_amd.ConstantAnnealingFactorSchedule(4 / 3)
+    fresh = si._build_step_table(mk(), gam, times, 1 / 40, 1.0, 1.0)
+    a = si.build_step_table(mk(), gam, times, 1 / 40, 1.0, 1.0)
+    assert len(si._STEP_TABLES) == 1 and torch.equal(a, fresh)
+    a[0, 0] = 123.0  # the caller's copy
+    b = si.build_step_table(mk(), pita_amd.ConstantAnnealingFactorSchedule(4 / 3), times.clone(), 1 / 40, 1.0, 1.0)
+    assert len(si._STEP_TABLES) == 1 and torch.equal(b, fresh)
+    for other in (si.build_step_table(mk(0.01), gam, times, 1 / 40, 1.0, 1.0),
+                  si.build_step_table(mk(), pita_amd.ConstantAnnealingFactorSchedule(1.5), times, 1 / 40, 1.0, 1.0),
+                  si.build_step_table(mk(), gam, times, 1 / 40, 1.0, 1.3),
+                  si.build_step_table(mk(), gam, torch.linspace(0.5, 0.0, 41)[:-1], 0.5 / 40, 1.0, 1.0)):
+        assert not torch.equal(other, fresh)
+    assert len(si._STEP_TABLES) == 5
+    for k in range(12):  # bounded
+        si.build_step_table(mk(0.02 + 0.001 * k), gam, times, 1 / 40, 1.0, 1.0)
+    assert len(si._STEP_TABLES) <= 8
+
+    class Odd:  # a schedule that carries a tensor is not cached (its value is not a plain key)
+        def __init__(self):
+            self.w = torch.ones(2)
+
+        def h(self, t):
+            return t + 1.0
+
+        def g(self, t):
+            return t * 0 + 1.0
+
+    n = len(si._STEP_TABLES)
+    si.build_step_table(Odd(), gam, times, 1 / 40, 1.0, 1.0)
+    assert len(si._STEP_TABLES) == n
