@@ -79,3 +79,20 @@ def test_walker_resident_kernel_is_built_without_packed_fp32():
     asm = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "/tmp/_kr_test.co"], check=True, capture_output=True, text=True).stdout
     assert "v_mfma_f32_16x16x32_f16" in asm
     assert not re.search(r"v_pk_(mul|add|fma)_f32", asm)
+
+
+@pytest.mark.skipif(not os.path.exists(f"{LLVM}/llvm-objdump"), reason="needs the ROCm LLVM binutils")
+def test_issue_priorities_are_in_the_built_kernels():
+    """Round 5: the fused sampler's three SiLUs per edge and the block-shared tangent kernel's operand split run at the lower
+    issue priority (s_setprio; DESIGN 4.1 viii: -6 % / -4.5 %, bit-identical results).  The scalar instructions must be in
+    the objects that ship: six per unrolled edge and column tile in the sampler, two per edge item in the tangent kernel."""
+    import pita_amd.build as build
+
+    build.build(verbose=False)
+    for obj, needle, least in (("egnn_kernel.o", "egnn_kernelILi13ELi3ELi7ELi4ELi2ELb1ELi2E", 18),
+                               ("egnn_div_kernel.o", "egnn_div_tangent_shared_kernelILi13ELi3ELi2ELi8ELi2E", 2)):
+        _kernels(os.path.join(ROOT, "pita_amd", "csrc", obj))  # leaves the device code object in /tmp/_kr_test.co
+        asm = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "/tmp/_kr_test.co"], check=True, capture_output=True, text=True).stdout
+        start = asm.index(f"<_ZN4pita{len(needle.split('IL')[0])}{needle}")
+        body = asm[start:asm.index("s_endpgm", start)]
+        assert body.count("s_setprio") >= least, (obj, body.count("s_setprio"))
