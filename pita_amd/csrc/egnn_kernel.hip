@@ -30,6 +30,9 @@
 //     traffic per walker-step is ~0 and there is no per-step tail/launch cost.
 //   * the last layer's node update and the embedding_out head are dead in the reference
 //     (egnn_temp_conditioned.py:80,189: h_final is discarded) and are skipped.
+//   * two waves share a SIMD (OCC = 2, 256 registers each).  Inside an edge the three 16-wide SiLUs -- the only phases that
+//     can issue every cycle -- run at issue priority 0, the dependent phases (matrix chains with their operand splits, dot
+//     chains, gathers) at 1 (s_setprio): the partner's scarce instruction goes first, the SiLU fills what is left.
 #include "egnn_common.h"
 
 namespace pita {
