@@ -2607,11 +2607,10 @@ extern "C" int pita_egnn_jacobian_trace(pita_egnn_t* net, const float* h, const 
     p.out = nullptr;
     const size_t lds = ts->lds_bytes(L);
     PITA_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(ts->kernel), lds));
-    int per_launch = ts->shared ? ts->K * ts->waves : ts->K;
-    if (ts->shared && D > first_k) {  // equal shares for the launches the remaining directions need anyway
-      const int nl = (D - first_k + per_launch - 1) / per_launch;
-      per_launch = (D - first_k + nl - 1) / nl;
-    }
+    // full launches first, the remainder last (LJ13: 16, 16, 7).  Round 4 dealt the directions out in equal shares (13, 13,
+    // 13); on the round-5 kernel full launches are 2 % faster per trace for LJ13 (18.35 vs 18.73 ms, four runs each on one
+    // box) and the same for 22 and 55 particles (profiles/r05_tangent_issue_priority.txt)
+    const int per_launch = ts->shared ? ts->K * ts->waves : ts->K;
     const long long tgrid = !ts->shared ? grid : (total_waves * groups_per_wave < (long long)net->n_cu
                                                       ? total_waves * groups_per_wave : (long long)net->n_cu);
     for (int d0 = first_k; d0 < D; d0 += per_launch) {
