@@ -49,8 +49,12 @@ _STEP_TABLES = {}  # key -> table; the last few (schedule, grid) combinations of
 
 def _schedule_key(obj):
     """Hashable identity of a schedule by VALUE (class + plain-number attributes); None when it carries anything else."""
+    try:
+        attrs = vars(obj)
+    except TypeError:  # no __dict__ (slots, builtins): not cacheable by value
+        return None
     items = []
-    for k, v in sorted(vars(obj).items()):
+    for k, v in sorted(attrs.items()):
         if isinstance(v, (bool, int, float, str, type(None))):
             items.append((k, v))
         else:
