@@ -231,7 +231,7 @@ def debiased_leg(pita_amd, net, cfg, dev, B, with_cpu):
     return out
 
 
-def e2e_legs(pita_amd, net, cfg, dev, B, n_plain, n_default):
+def e2e_legs(pita_amd, net, cfg, dev, B, n_plain, n_default, chunk=512):
     """End-to-end numbers at the metric's own length, through the plug-in class (never inside `value`):
     `not_debiased`   ONE WeightedSDEIntegrator.integrate_sde (sde_integration.py:98-212): B walkers x n_plain steps from
                      Prior.sample, per-step moments on, resampling off, the f16 repair pass as it falls along the real schedule;
@@ -257,7 +257,7 @@ def e2e_legs(pita_amd, net, cfg, dev, B, n_plain, n_default):
             continue  # the reference's default regime with MALA needs a molecule target with forces (sde_integration.py:397)
         sde = pita_amd.VEReverseSDE(noise_schedule=sched, score_net=pita_amd.ScoreNet(net),
                                     energy_net=EnergyNet(copy.deepcopy(net)) if debias else None, debias_inference=debias)
-        kw = dict(resampling_interval=1, batch_size=512, resample_at_end=True, post_mcmc_steps=5, adaptive_mcmc=True,
+        kw = dict(resampling_interval=1, batch_size=chunk, resample_at_end=True, post_mcmc_steps=5, adaptive_mcmc=True,
                   dt_negative_time=1e-13) if debias else dict(resampling_interval=-1, post_mcmc_steps=0)
         integ = pita_amd.WeightedSDEIntegrator(sde=sde, num_integration_steps=N, start_resampling_step=0,
                                                end_resampling_step=int(0.9 * N) if debias else N, num_negative_time_steps=0,
@@ -272,10 +272,12 @@ def e2e_legs(pita_amd, net, cfg, dev, B, n_plain, n_default):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         res = integ.integrate_sde(x1, energy, gam, inverse_temperature=1.0)
+        host = time.perf_counter() - t0  # the host's share: integrate_sde has returned, the device may still be working
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         xf = res[0]
-        out[name] = {"walkers": B, "steps": N, "seconds": dt, "ms_per_step": dt * 1e3 / N, "value": B * N / dt,
+        out[name] = {"walkers": B, "steps": N, "seconds": dt, "host_seconds": host, "ms_per_step": dt * 1e3 / N,
+                     "value": B * N / dt,
                      "unit": "walker-steps/s", "finite": bool(torch.isfinite(xf).all()),
                      "what": ("one WeightedSDEIntegrator.integrate_sde from Prior.sample: per-step moments on, resampling off, "
                               "no MCMC") if not debias else
@@ -285,6 +287,28 @@ def e2e_legs(pita_amd, net, cfg, dev, B, n_plain, n_default):
         if debias:
             out[name]["distinct_parents_last_event"] = int(res[2][-1]) if len(res[2]) else None
             out[name]["mala_acceptance"] = [float(a) for a in res[4]]
+    return out
+
+
+def small_batch_legs(pita_amd, net, cfg, dev, sizes=(512, 2048, 5000, 16384), n_plain=1000, n_default=100):
+    """The reference's OWN operating points (never inside `value`): PITA generates num_eval_samples = 2 048 walkers
+    (configs/experiment/lj13.yaml:32; 5 000 in model/energytemp.yaml:69, num_samples_to_generate_per_epoch 2 000 at :122) in
+    inference chunks of 512 (lj13.yaml:27) -- far fewer walkers than one MI355X holds.  Per batch size: the whole
+    integrate_sde in both regimes (e2e_legs: 1 000 not-debiased steps; 100 steps of the default regime with chunks of 512),
+    the fraction of the full-batch rate, and how the fused sampler's mapping fills the chip at that size."""
+    import torch
+
+    out = {"sizes": {}, "what": "whole WeightedSDEIntegrator.integrate_sde per batch size, both regimes; rates relative to the "
+                                "same legs at the config's full batch are in `frac_of_full_batch` when `e2e` ran"}
+    for B in sizes:
+        legs = e2e_legs(pita_amd, net, cfg, dev, B, n_plain, n_default, chunk=min(512, B))
+        g, waves, slots = net.sampler_mapping(B, dev)
+        legs["sampler_mapping"] = {"walkers_per_wave_group": g, "waves": waves, "resident_wave_slots": slots,
+                                   "wave_slot_fill": waves / slots}
+        for leg in legs.values():
+            leg.pop("what", None)
+        out["sizes"][str(B)] = legs
+        torch.cuda.synchronize()
     return out
 
 
@@ -591,6 +615,8 @@ def main():
     ap.add_argument("--timeout-s", type=float, default=300.0,
                     help="deadline of init_process_group: a rank whose peers never arrive exits with code 3")
     ap.add_argument("--no-e2e", action="store_true", help="skip the whole-integrate_sde legs behind the timed region")
+    ap.add_argument("--no-small-batch", action="store_true",
+                    help="skip the small-batch legs (the reference's own 512 ... 16 384 walkers) behind the timed region")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / timing protocol only, no kernels and no GPU (gloo): CPU test of the "
                          "multi-rank path; the JSON carries value null")
@@ -912,6 +938,14 @@ def main():
                                         "the whole integrate_sde"}
         if world == 1 and not args.no_e2e:
             out["e2e"] = e2e_legs(pita_amd, net, cfg, dev, B, NGRID, 100 if n <= 13 else 20)
+        if world == 1 and not args.no_small_batch and args.config == "lj13":
+            sb = small_batch_legs(pita_amd, net, cfg, dev)
+            full = out.get("e2e") or {}
+            for legs in sb["sizes"].values():
+                for name in ("not_debiased", "default_regime"):
+                    if name in legs and name in full:
+                        legs[name]["frac_of_full_batch"] = legs[name]["value"] / full[name]["value"]
+            out["small_batch"] = sb
         if world == 1 and not args.no_cpu_baseline:
             # ~10-20 s of CPU work: the cost per walker-step grows with the number of edges
             steps = args.cpu_steps or max(4, int(300 * 156 / (n * (n - 1))))

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PITA_ABI_VERSION 10
+#define PITA_ABI_VERSION 11
 
 enum {
   PITA_OK = 0,
@@ -364,6 +364,14 @@ int pita_egnn_sampler_run(pita_egnn_t* net, float* x, int64_t B, const float* st
  * (32 768 flop each), mfma32: v_mfma_f32_32x32x2_f32 (4 096 flop each). */
 int pita_egnn_sampler_work(const pita_egnn_t* net, int64_t B, double* mfma16_per_walker_step,
                            double* mfma32_per_walker_step);
+
+/* How pita_egnn_sampler_run maps a batch of B walkers onto the device (bench.py `small_batch`: the reference generates
+ * num_eval_samples = 2 048 walkers in inference chunks of 512, configs/experiment/lj13.yaml:27,32 -- far fewer than the
+ * chip holds): walkers_per_group = walkers packed into one wavefront's column tiles (the small-group mapping is chosen
+ * when the regular one would leave SIMDs with a single wave), waves = wavefronts the launch starts, wave_slots = wavefronts
+ * of this kernel the device can hold at once (CUs x resident blocks x waves per block). */
+int pita_egnn_sampler_mapping(const pita_egnn_t* net, int64_t B, int* walkers_per_group, int64_t* waves,
+                              int64_t* wave_slots);
 
 /* ---------------------------------------------------------------- MLP backbone (K6)
  * replaces MyMLP.forward (mlp.py:244-267) / MyMLPTemperature.forward (:501-524) incl. the

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpita_hip.so")
 
 STEP_STRIDE = 16
-ABI_VERSION = 10
+ABI_VERSION = 11
 ST_CS, ST_CIN, ST_COUT, ST_CNOISE, ST_H, ST_G2, ST_GAMMA, ST_DT, ST_NOISE_SCALE, ST_SQRT_DT, ST_BETA = range(11)
 
 
@@ -106,6 +106,7 @@ _PROTOS = {
     "pita_egnn_sampler_run": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_uint64, c_uint64,
                                       c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "pita_egnn_sampler_work": (c_int, [c_void_p, c_int64, POINTER(c_double), POINTER(c_double)]),
+    "pita_egnn_sampler_mapping": (c_int, [c_void_p, c_int64, POINTER(c_int), POINTER(c_int64), POINTER(c_int64)]),
     "pita_mlp_create": (c_int, [POINTER(c_void_p), POINTER(MlpConfig), c_void_p, c_int64, c_void_p]),
     "pita_mlp_destroy": (c_int, [c_void_p]),
     "pita_mlp_num_weights": (c_int64, [POINTER(MlpConfig)]),

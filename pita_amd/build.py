@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpita_hip.so")
-SOURCES = ["abi.hip", "energy_kernels.hip", "ring_kernels.hip", "ff_kernel.hip", "egnn_kernel.hip", "egnn_wide_kernel.hip", "egnn_wide_mfma_kernel.hip", "egnn_wide_mfma_jvp_kernel.hip", "egnn_jvp_kernel.hip", "egnn_vjp_kernel.hip", "egnn_div_kernel.hip", "egnn_div_walker_kernel.hip", "fk_kernels.hip", "mlp_kernel.hip", "sampler_kernels.hip"]
+SOURCES = ["abi.hip", "energy_kernels.hip", "ring_kernels.hip", "ff_kernel.hip", "egnn_kernel.hip", "egnn_wide_kernel.hip", "egnn_wide_mfma_kernel.hip", "egnn_wide_mfma_jvp_kernel.hip", "egnn_jvp_kernel.hip", "egnn_vjp_kernel.hip", "egnn_div_kernel.hip", "fk_kernels.hip", "mlp_kernel.hip", "sampler_kernels.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FALLBACK_OBJECTS = []  # sources whose optional per-file flags the toolchain rejected in this build
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
@@ -20,14 +20,12 @@ PER_FILE_FLAGS = {"egnn_wide_mfma_kernel.hip": ["-mllvm", "-amdgpu-mfma-vgpr-for
                   "egnn_wide_mfma_jvp_kernel.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                   # reverse-mode kernel (one wave per SIMD, resident weight fragments parked in AGPRs): 5.74 -> 5.22 ms
                   "egnn_vjp_kernel.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
-# REQUIRED per-file flags (correctness, never dropped by the retry below).  egnn_div_walker_kernel.hip: no packed fp32
-# vector instructions.  With hipcc's v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 in that kernel (8 waves per workgroup,
-# v_mfma_f32_16x16x32_f16 chains, two waves per SIMD) one result in ~1e4 walkers differed from run to run: the LOW half of a
-# packed result wrong in lanes 48..63 with all its inputs intact (profiles/r05_walker_packed_fp32_hazard.txt; the
-# instruction-level probes under tools/ubench/ rule out the matrix-instruction and LDS wait states).  Without packed
-# instructions: 0 differing results in 6e5 walker evaluations.
-REQUIRED_FILE_FLAGS = {"egnn_div_walker_kernel.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]}
-# (egnn_div_kernel.hip: the same treatment gained 4 % on the LJ55 trace, nothing on LJ13, and ONE instantiation --
+# REQUIRED per-file flags (correctness, never dropped by the retry below).  None today.  Round 5's walker-resident trace
+# kernel needed "-Xclang -target-feature -Xclang -packed-fp32-ops" (rare run-to-run differences with hipcc's packed fp32
+# code, profiles/r05_walker_packed_fp32_hazard.txt); that kernel lost to the cached path and lives in tools/ubench/ now.
+# tests/test_hip_parity.py::test_default_path_full_batch_rerun soaks the kernels that do ship, full batch, bit for bit.
+REQUIRED_FILE_FLAGS = {}
+# (egnn_div_kernel.hip: compiling without packed fp32 gained 4 % on the LJ55 trace, nothing on LJ13, and ONE instantiation --
 # egnn_div_fast_kernel<4,2,8,4,3,1>, the DW4 writer -- then faulted with a memory aperture violation: bisected to the
 # combination of this experimental option with the AGPR-parked fragments in that kernel; either alone is fine there.
 # Not adopted for that file.  Every instantiation of the two files above is exercised by the GPU tests: a mis-compile of

@@ -395,13 +395,5 @@ struct pita_egnn {
   int div_seq = 0;               // sequence number of the last launch that could mark walkers
   void* d_bk = nullptr;          // precision 2 sampler: walker backup + owed-moments markers for the repair launch
   size_t bk_bytes = 0;
-  void* d_wk = nullptr;          // walker-resident trace kernel (egnn_div_walker_kernel.hip): its own weight packing, or null
 };
 
-namespace pita {
-// egnn_div_walker_kernel.hip
-int wk_pack_create(pita_egnn* net, const pita_egnn_config* cfg, const float* w);
-bool wk_available(const pita_egnn* net);
-int wk_launch(pita_egnn* net, const float* h, const float* x, const float* beta, float* trace, float* out, long long B,
-              int* mark, int* bad_flag, int bad_seq, hipStream_t st);
-}  // namespace pita

@@ -2463,29 +2463,6 @@ extern "C" int pita_egnn_jacobian_trace(pita_egnn_t* net, const float* h, const 
   if (!s) return fail(PITA_EUNSUPPORTED, "pita_egnn_jacobian_trace: no kernel for this particle system");
   hipStream_t st = (hipStream_t)stream;
   PITA_HIP_CHECK(hipMemsetAsync(trace, 0, sizeof(float) * (size_t)B, st));
-  if (wk_available(net)) {
-    // walker-resident kernel (egnn_div_walker_kernel.hip): all D directions in ONE launch, no primal cache; walkers the
-    // f16 path cannot represent are marked and recomputed by the bf16x3 kernel, its own K directions at a time
-    {
-      const int rc0 = ensure_marks(net, (size_t)B, st);
-      if (rc0 != PITA_OK) return rc0;
-    }
-    int* bad_flag = net->d_mark + net->mark_bytes / sizeof(int);
-    const int seq = ++net->div_seq;
-    int rc = wk_launch(net, h, x, beta, trace, denoiser_out, B, net->d_mark, bad_flag, seq, st);
-    if (rc != PITA_OK) return rc;
-    DivParams r{};
-    r.mats16 = net->d_mats16; r.mats16h = net->d_mats16h; r.vecs = net->d_vecs; r.vecs_h = net->d_vecs_h;
-    r.vecs_div = net->d_vecs_div;
-    r.n_layers = L; r.in_nf = net->cfg.in_node_nf;
-    r.attention = net->cfg.attention; r.tanh_on = net->cfg.tanh; r.feature_layout = net->cfg.feature_layout;
-    r.coord_scale = net->cfg.coords_range / (float)L;
-    r.B = B; r.h = h; r.x = x; r.beta = beta; r.diag_acc = trace; r.no_mean = 1;
-    r.mark = net->d_mark; r.bad_flag = bad_flag; r.bad_seq = seq;
-    r.repair = 1; r.dir0 = 0; r.ndir = D; r.nchunk = (D + s->K - 1) / s->K; r.out = denoiser_out;
-    if (getenv("PITA_WK_NOREPAIR")) return PITA_OK;  // development aid: marked walkers keep a zero trace
-    return div_launch(s, s->kernel, net, r, stream);
-  }
   const DivTanShape* ts = div_fast_enabled(net) ? find_div_tan_shape(n, dim, L) : nullptr;
   if (!ts || ts->G != s->G || (!ts->shared && ts->waves != s->waves) || D <= s->K) {
     const int K = pita_egnn_div_directions(net);

@@ -836,13 +836,6 @@ extern "C" int pita_egnn_create(pita_egnn_t** out, const pita_egnn_config* cfg, 
     pita_egnn_destroy(net);
     return fail(PITA_EHIP, "pita_egnn_create: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e3));
   }
-  {  // weight packing of the walker-resident trace kernel (particle systems it is instantiated for)
-    const int rc = wk_pack_create(net, cfg, w);
-    if (rc != PITA_OK) {
-      pita_egnn_destroy(net);
-      return rc;
-    }
-  }
   *out = net;
   return PITA_OK;
 }
@@ -861,7 +854,6 @@ extern "C" int pita_egnn_destroy(pita_egnn_t* net) {
   (void)hipFree(net->d_bk);
   (void)hipFree(net->d_mark);
   (void)hipFree(net->d_divcache);
-  (void)hipFree(net->d_wk);
   delete net;
   return PITA_OK;
 }
@@ -965,6 +957,21 @@ extern "C" int pita_egnn_sampler_work(const pita_egnn_t* net, int64_t B, double*
     *mfma16_per_walker_step = ((F16_NODE_LAYERS ? f16d : 12.0) * node_dense + f16d * edge_dense) / (double)B;
     *mfma32_per_walker_step = kstep / (double)B;
   }
+  return PITA_OK;
+}
+
+extern "C" int pita_egnn_sampler_mapping(const pita_egnn_t* net, int64_t B, int* walkers_per_group, int64_t* waves,
+                                         int64_t* wave_slots) {
+  PITA_REQUIRE(net && B > 0 && walkers_per_group && waves && wave_slots, "pita_egnn_sampler_mapping: bad argument");
+  const EgnnShape* s = shape_for(net, B);  // the same arithmetic as egnn_launch (mode 3)
+  const size_t lds = s->lds_bytes(net->cfg.n_layers);
+  int blocks_per_cu = (int)((160 * 1024) / lds);
+  blocks_per_cu = blocks_per_cu < 1 ? 1 : (blocks_per_cu > s->occ ? s->occ : blocks_per_cu);
+  const long long ngroups = (B + s->G - 1) / s->G;
+  const long long want = (ngroups + s->waves - 1) / s->waves, cap = (long long)net->n_cu * blocks_per_cu;
+  *walkers_per_group = s->G;
+  *waves = (want < cap ? want : cap) * s->waves;
+  *wave_slots = cap * s->waves;
   return PITA_OK;
 }
 

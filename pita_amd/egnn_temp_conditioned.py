@@ -252,6 +252,14 @@ class EGNN_dynamics(nn.Module):
                    "pita_egnn_sampler_work")
         return a.value, b.value
 
+    def sampler_mapping(self, B, device):
+        """(walkers per wavefront group, wavefronts launched, resident wavefront slots) of the fused sampler at batch B
+        (pita_egnn_sampler_mapping)."""
+        g, w, s = ctypes.c_int(), ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(_lib.lib().pita_egnn_sampler_mapping(self._native(device), int(B), ctypes.byref(g), ctypes.byref(w),
+                                                        ctypes.byref(s)), "pita_egnn_sampler_mapping")
+        return g.value, w.value, s.value
+
 
 def _as_batch(v, B, device):
     if isinstance(v, torch.Tensor):

@@ -1,3 +1,10 @@
+// RECORDED NEGATIVE (round 5; moved out of the product library in round 6).  This file is kept as documentation of the
+// walker-resident mapping and of its algebra; it is NOT built into libpita_hip.so any more.  It was wired into the library
+// through three hooks (commit e5f94e2 has them): pita::wk_pack_create() from pita_egnn_create (egnn_kernel.hip), the
+// wk_available()/wk_launch() branch at the top of pita_egnn_jacobian_trace (egnn_div_kernel.hip), and pita_egnn::d_wk
+// (egnn_common.h), behind PITA_DIV_WALKER=1, compiled with -Xclang -target-feature -Xclang -packed-fp32-ops.  Measured:
+// 30.4 ms per 65 536-walker LJ13 trace against 19.0 for the cached path (profiles/r05_walker_*.txt).
+//
 // Walker-resident exact trace of the EDM-preconditioned EGNN denoiser's Jacobian for gfx950: ONE launch for all N dim unit
 // directions, the directions are the COLUMN dimension of the matrix instructions, nothing is cached in HBM.
 //
