@@ -312,6 +312,39 @@ def small_batch_legs(pita_amd, net, cfg, dev, sizes=(512, 2048, 5000, 16384), n_
     return out
 
 
+def e2e_multi_rank(pita_amd, net, cfg, dev, B, world, n_steps, gather_fn):
+    """Several ranks: ONE WeightedSDEIntegrator.integrate_sde over the GLOBAL batch (world x B walkers from Prior.sample;
+    every rank integrates its slice, sde_integration.py:227-233, one final all-gather), timed per rank behind the timed
+    region -- the wall seconds of every rank, so that a weak-scaling loss of the whole call can be attributed (slow rank,
+    the collective, or neither) without a second run.  Never inside `value`."""
+    import torch
+
+    n, d = cfg["n"], cfg["d"]
+    sched = pita_amd.ElucidatingNoiseSchedule(sigma_min=cfg["sigma_min"], sigma_max=80.0, rho=7)
+    gam = pita_amd.ConstantAnnealingFactorSchedule(4 / 3)
+    energy = make_target(pita_amd, cfg, dev)
+    scale = float((sched.h(torch.tensor(1.0)) / gam.gamma(torch.tensor(1.0))) ** 0.5)
+    sde = pita_amd.VEReverseSDE(noise_schedule=sched, score_net=pita_amd.ScoreNet(net), debias_inference=False)
+    integ = pita_amd.WeightedSDEIntegrator(sde=sde, num_integration_steps=n_steps, start_resampling_step=0,
+                                           end_resampling_step=n_steps, num_negative_time_steps=0, resampling_interval=-1,
+                                           post_mcmc_steps=0)
+    x1 = pita_amd.Prior(scale=scale, n_particles=n, spatial_dim=d, device=dev, seed=12345).sample(world * B)
+    integ.integrate_sde(x1.clone(), energy, gam, inverse_temperature=1.0)  # warm-up: handles, step table, communicator
+    torch.cuda.synchronize()
+    torch.distributed.barrier()
+    t0 = time.perf_counter()
+    res = integ.integrate_sde(x1, energy, gam, inverse_temperature=1.0)
+    torch.cuda.synchronize()
+    mine = time.perf_counter() - t0
+    walls = gather_fn(torch.tensor([mine], dtype=torch.float64)).reshape(world).tolist()
+    slow = max(walls)
+    return {"what": "one integrate_sde over the global batch (rank slices + one final all-gather), not debiased, per-step "
+                    "moments on; wall seconds of every rank",
+            "global_walkers": world * B, "steps": n_steps, "per_rank_wall_s": walls, "seconds": slow,
+            "ms_per_step": 1e3 * slow / n_steps, "value": world * B * n_steps / slow, "unit": "walker-steps/s",
+            "gathered_rows": int(res[0].shape[0]), "finite": bool(torch.isfinite(res[0]).all())}
+
+
 def debiased_cpu_baseline(net, cfg, xc):
     """The oracle's debiased drift (autograd + vmap(jacrev)) on a bounded sample, timed on the host cores."""
     import torch
@@ -456,10 +489,10 @@ def resample_exchange_leg(comm, x, every, B, world, rank, ids_fn, sync, events=3
     import torch
 
     gen = torch.Generator().manual_seed(77)
-    per_event, rows = [], []
+    per_event, rows, sent, splits = [], [], [], None
     for e in range(events + 1):  # the first event is a warm-up (communicator set-up)
         a = (0.5 * torch.randn(B, generator=gen)).to(x.device)  # one step's log-weights: spread ~0.5 (fixture: 0.3-1)
-        comm.rows_received = 0
+        comm.rows_received = comm.rows_sent = 0
         sync()
         t0 = time.perf_counter()
         ag = comm.all_gather(a)
@@ -469,9 +502,17 @@ def resample_exchange_leg(comm, x, every, B, world, rank, ids_fn, sync, events=3
         if e > 0:
             per_event.append(time.perf_counter() - t0)
             rows.append(int(comm.rows_received))
+            sent.append(int(comm.rows_sent))
+            splits = getattr(comm, "last_splits", None)
     return {"every": every, "events_timed": events, "ms_per_event_this_rank": [round(1e3 * t, 4) for t in per_event],
             "rows_received_from_other_ranks": rows, "rows_per_rank": B,
             "bytes_received_per_event": [r * x.shape[1] * 4 for r in rows],
+            # what this rank actually put on the wire per event: the uneven all_to_all_single's input splits to OTHER ranks
+            # (round 6; the reference all-gathers (world - 1) * B rows to every rank every step, sde_integration.py:248-258)
+            "rows_sent_to_other_ranks": sent, "bytes_sent_per_event": [r * x.shape[1] * 4 for r in sent],
+            "log_weight_allgather_bytes_per_event": 4 * B * (world - 1),
+            "reference_allgather_bytes_per_event": (world - 1) * B * x.shape[1] * 4,
+            "last_event_rows_by_peer": splits,
             "amortised_ms_per_step": 1e3 * sum(per_event) / len(per_event) / max(every, 1),
             "note": "log-weight all-gather + global systematic resampling + one uneven all_to_all_single "
                     "(_Comm.exchange_rows); not inside the timed region, not part of `value`"}, x
@@ -826,6 +867,9 @@ def main():
         # for the slowest rank to arrive, which is what a rank loses to the collective)
         per_rank = rank_breakdown(world, gather64, wall, sum(launch_ms) * 1e-3, evs[n_launch].elapsed_time(ev_ag) * 1e-3)
     assert torch.isfinite(x).all(), "sampler produced non-finite walkers"
+    e2e_ranks = None
+    if world > 1 and not args.no_e2e:
+        e2e_ranks = e2e_multi_rank(pita_amd, net, cfg, dev, B, world, NGRID, gather64)
     if world > 1 and args.resample_every > 0:
         from pita_amd.sde_integration import _Comm
         from pita_amd.utils import sample_cat_sys
@@ -928,6 +972,8 @@ def main():
             out["distinct_devices"] = ident["distinct_devices"]
             if exchange is not None:
                 out["resample_exchange"] = exchange
+            if e2e_ranks is not None:
+                out["e2e"] = {"not_debiased": e2e_ranks}
         if ad2cat is not None:
             out["ad2cat_backbone"] = ad2cat
         # which part of the reference's 1 000-step grid the timed region covered (t_k = 1 - k / 1000)

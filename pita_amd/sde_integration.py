@@ -184,6 +184,9 @@ class _Comm:
         else:
             torch.distributed.all_to_all_single(recv, send, output_split_sizes=out_split, input_split_sizes=in_split)
         self.rows_received = getattr(self, "rows_received", 0) + sum(counts[r]) - counts[r][r]
+        # what this rank put on the wire (rows to other ranks; the split it kept for itself never leaves the device)
+        self.rows_sent = getattr(self, "rows_sent", 0) + sum(in_split) - in_split[r]
+        self.last_splits = {"sent_to": in_split, "received_from": out_split}
         # the received rows are ordered by (source rank, position in my slice); my slice's runs are ordered by position
         fl = first[r * Bl:(r + 1) * Bl]
         jl = torch.nonzero(fl).reshape(-1)

@@ -164,6 +164,13 @@ def test_bench_gpus_flag_launches_that_many_ranks():
     assert ex["every"] == 1 and len(ex["ms_per_event_this_rank"]) == ex["events_timed"] == 3
     assert all(0 <= r <= ex["rows_per_rank"] for r in ex["rows_received_from_other_ranks"])
     assert ex["amortised_ms_per_step"] > 0
+    # round 6: what the rank put on the wire, from the uneven all_to_all_single's own split sizes -- with two ranks what
+    # rank 0 sends is what rank 1 receives, never more than a shard, and far below the reference's all-gather of every walker
+    assert len(ex["rows_sent_to_other_ranks"]) == 3 and all(0 <= r <= ex["rows_per_rank"] for r in ex["rows_sent_to_other_ranks"])
+    assert ex["bytes_sent_per_event"] == [r * 3 * 4 for r in ex["rows_sent_to_other_ranks"]]
+    assert ex["reference_allgather_bytes_per_event"] == ex["rows_per_rank"] * 3 * 4
+    sp = ex["last_event_rows_by_peer"]
+    assert len(sp["sent_to"]) == 2 and sum(sp["received_from"]) >= ex["rows_received_from_other_ranks"][-1]
     r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run"], capture_output=True, text=True,
                         timeout=300, env=env)
     assert r1.returncode == 0 and json.loads(r1.stdout.strip().splitlines()[-1])["n_gpus"] == 1

@@ -65,3 +65,8 @@ def test_bench_two_ranks_on_one_device():
     ex = out["resample_exchange"]
     assert ex["rows_per_rank"] == 1024 and len(ex["ms_per_event_this_rank"]) == 3
     assert all(0 < r <= 1024 for r in ex["rows_received_from_other_ranks"])
+    assert all(0 < r <= 1024 for r in ex["rows_sent_to_other_ranks"]) and ex["bytes_sent_per_event"][0] == ex["rows_sent_to_other_ranks"][0] * 39 * 4
+    # round 6: the whole integrate_sde over the global batch, wall seconds of every rank (attribution of a scaling loss)
+    e2 = out["e2e"]["not_debiased"]
+    assert e2["global_walkers"] == 2048 and e2["gathered_rows"] == 2048 and e2["finite"] and len(e2["per_rank_wall_s"]) == 2
+    assert all(w > 0 for w in e2["per_rank_wall_s"]) and e2["seconds"] == max(e2["per_rank_wall_s"])
