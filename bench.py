@@ -115,6 +115,19 @@ def make_target(pa, cfg, dev):
                             device=dev)
 
 
+def cpu_model():
+    """Model string of the host CPU (the CPU baseline states core count AND CPU model)."""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline(cfg, n_walkers, n_steps, seed=12345):
     """The oracle (torch-CPU restatement of the reference's sampler, kind = "port") timed on this
     host's cores on a bounded sample of the same workload."""
@@ -154,7 +167,8 @@ def cpu_baseline(cfg, n_walkers, n_steps, seed=12345):
         O.integrate_sde(cfg_run, x1, drift, sched.g, noise_fn, n, d)
         dt = time.perf_counter() - t0
     torch.set_num_threads(all_threads)
-    return {"value": n_walkers * n_steps / dt, "unit": "walker-steps/s", "cores": nthr,
+    return {"value": n_walkers * n_steps / dt, "unit": "walker-steps/s", "cores": nthr, "cpu_model": cpu_model(),
+            "logical_cpus": os.cpu_count(),
             "kind": "port", "sample": f"oracle integrate_sde, {n}x{d}D EGNN h32x3, {n_walkers} walkers x {n_steps} steps, "
             f"torch-CPU fp32, {dt:.1f} s with {nthr} threads (host has {os.cpu_count()} logical CPUs)"}
 
@@ -360,7 +374,7 @@ def debiased_cpu_baseline(net, cfg, xc):
     t0 = time.perf_counter()
     O.f_debiased(bb, bb, osched, ogam, torch.tensor(0.5), xc, 1.0)
     dtc = time.perf_counter() - t0
-    return {"value": nb / dtc, "unit": "walker-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": nb / dtc, "unit": "walker-steps/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model(), "kind": "port",
             "sample": f"oracle f_debiased (autograd + vmap(jacrev)), {nb} walkers x 1 step, {dtc:.1f} s"}
 
 

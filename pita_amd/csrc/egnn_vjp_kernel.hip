@@ -654,6 +654,17 @@ static const VjpShape kVjpShapes[] = {
     PITA_VJP_SHAPE(22, 3, 4, 4),
     PITA_VJP_SHAPE(55, 3, 1, 4),
 };
+// Latency mapping for batches that underfill the chip (round 6).  The reference's own operating point is 2 048 walkers
+// (configs/experiment/lj13.yaml:32): seven walkers per wave make 293 waves on 1 024 SIMDs, each walking three column tiles
+// -- 492 us per launch, 40 % of a debiased step there.  Two walkers per wave (one column tile) fill every SIMD once.
+static const VjpShape kVjpShapesSmall[] = {
+    PITA_VJP_SHAPE(13, 3, 2, 4),
+};
+// column-tile passes of the busiest wave: (groups per wave) x (tiles per group)
+static long long vjp_passes(const VjpShape& s, long long B, long long wave_slots) {
+  const long long ngroups = (B + s.G - 1) / s.G;
+  return ((ngroups + wave_slots - 1) / wave_slots) * ((s.G * s.n + 31) / 32);
+}
 
 }  // namespace pita
 
@@ -671,6 +682,10 @@ extern "C" int pita_egnn_vjp(pita_egnn_t* net, const float* h, const float* x, c
   for (const auto& c : kVjpShapes)
     if (c.n == net->cfg.n_particles && c.dim == net->cfg.n_dim) s = &c;
   if (!s) return fail(PITA_EUNSUPPORTED, "pita_egnn_vjp: no kernel for this particle system");
+  for (const auto& c : kVjpShapesSmall)  // fewer tile passes on the busiest wave with the small groups: take them
+    if (c.n == s->n && c.dim == s->dim &&
+        vjp_passes(c, B, (long long)net->n_cu * c.waves) < vjp_passes(*s, B, (long long)net->n_cu * s->waves))
+      s = &c;
   VjpParams p{};
   p.mats16 = net->d_mats16; p.vecs = net->d_vecs; p.n_layers = net->cfg.n_layers; p.in_nf = net->cfg.in_node_nf;
   p.attention = net->cfg.attention; p.tanh_on = net->cfg.tanh; p.feature_layout = net->cfg.feature_layout;

@@ -44,7 +44,7 @@ def classify(mn, ops):
 
 
 fb, co = "/tmp/_kh.fb", "/tmp/_kh.co"
-subprocess.run([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fb}", obj], check=True, capture_output=True)
+subprocess.run([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fb}", obj, "/tmp/_kh.o"], check=True, capture_output=True)
 subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fb}", f"--output={co}",
                 "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], check=True, capture_output=True)
 dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--demangle", co], check=True, capture_output=True, text=True).stdout

@@ -1,0 +1,409 @@
+// Go / no-go micro-kernel (round 6) for the DIRECTION-SPLIT exact-trace mapping of DESIGN.md 8.1:
+// the MIDDLE layer of the tangent sweep, one workgroup of four waves (one per SIMD) per walker, every wave owning ONE column
+// tile of unit directions (39 directions dealt 10 + 10 + 10 + 9 over four 16-column tiles) for ALL 13 nodes -- tangents of
+// different directions never meet, so the waves share nothing but the PRIMAL: the per-edge matrix
+//     M_ij = [ diag(a) W_2 diag(b) + m' p^T ; c_k q^T ]      (35 x 32, three 16-row blocks, f16 two-piece A fragments)
+// which is built ONCE per edge (each wave builds every fourth edge from five 32-vectors of a per-walker primal stream in
+// global memory -- the stand-in for what the cache writer would store) and handed to the other waves through a
+// double-buffered LDS slot.  Per edge and wave: 9 v_mfma_f32_16x16x32_f16 against the wave's PRIVATE B fragments of
+// W_b dH_j (LDS, written once per layer), six + two ds_read_b128.  Per node: the partial sums of M over a node's edges are
+// exchanged through LDS (Abar_i (W_a dH_i) by linearity), the K = 64 position product, the node model, the next B fragments.
+// Gate (the review's): <= 20 us per walker and CU for this layer.  Development aid; results in profiles/r06_div_dir_mid.txt.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o tools/ubench/div_dir_mid tools/ubench/div_dir_mid.hip
+//   tools/ubench/div_dir_mid [walkers per block]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int N = 13, NE = N * (N - 1);     // nodes, ordered edges
+constexpr int EB = 4;                       // edges per batch = waves per block (each wave builds one)
+constexpr int NBATCH = NE / EB;             // 39
+constexpr int M_BYTES = 3 * 2 * 1024;       // one edge's A fragments: [row block 3][piece 2][lane 64][16 B]
+constexpr int ZB_NODE_B = 2 * 1024;         // one node's B fragments of one wave: [piece][lane][16 B]
+constexpr int PRIMAL_F = 160;               // floats per edge in the primal stream: a[32] m'[32] b[32] p[32] c[4] pad
+
+__device__ __forceinline__ f16x8 as_h8(u32x4 v) { return __builtin_bit_cast(f16x8, v); }
+__device__ __forceinline__ float rem_lo(unsigned pk, float x) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(x));
+  return r;
+}
+__device__ __forceinline__ float rem_hi(unsigned pk, float x) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(x));
+  return r;
+}
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const unsigned p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2 * q], v[2 * q + 1]}, f16x2));
+    const float ra = rem_lo(p1, v[2 * q]), rb = rem_hi(p1, v[2 * q + 1]);
+    hi[q] = p1;
+    lo[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{ra, rb}, f16x2));
+  }
+}
+struct Frag { u32x4 hi, lo; };
+__device__ __forceinline__ f32x4 mma3(const Frag& a, const Frag& b, f32x4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(a.lo), as_h8(b.hi), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(a.hi), as_h8(b.lo), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(a.hi), as_h8(b.hi), c, 0, 0, 0);
+  return c;
+}
+struct WMat { Frag f[2]; };
+__device__ __forceinline__ void load_w(WMat& w, const u32x4* __restrict__ g, int mat, int lane) {
+  const u32x4* p = g + (size_t)mat * 256 + lane;
+  w.f[0].hi = p[0]; w.f[0].lo = p[64]; w.f[1].hi = p[128]; w.f[1].lo = p[192];
+}
+__device__ __forceinline__ void gemm(const WMat& w, const Frag& x, f32x4 (&acc)[2]) {
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) acc[rb] = mma3(w.f[rb], x, acc[rb]);
+}
+__device__ __forceinline__ void to_frag(const f32x4 (&acc)[2], Frag& x) {
+  const float v[8] = {acc[0].x, acc[0].y, acc[0].z, acc[0].w, acc[1].x, acc[1].y, acc[1].z, acc[1].w};
+  split8(v, x.hi, x.lo);
+}
+
+struct Params {
+  const u32x4* wfrag;   // [6 matrices][2 rb][2 pieces][64 lanes] f16 fragments: Wa Wb W2(unused) Wn1a Wn1b Wn2
+  const float* w2f;     // [64 lanes][16] fp32 fragment of W_2 (A layout)
+  const float* primal;  // [blocks][walkers][NE][PRIMAL_F]: the per-edge primal vectors (read once: real HBM traffic)
+  const float* rtab;    // [64 lanes][48] R_i coefficients (L2 resident; the real kernel derives them from geometry)
+  const float* init;    // random numbers
+  float* out;           // [blocks][256] sink
+  long long* cyc;       // [blocks][4][8] phase cycles
+  int walkers;          // per block
+};
+
+__global__ void __launch_bounds__(256, 1) dir_mid_kernel(Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* zb = lds;                                 // [4 waves][N][ZB_NODE_B]   private B fragments
+  unsigned char* mbuf = zb + 4 * N * ZB_NODE_B;            // [2][EB][M_BYTES]          shared A fragments of M
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r16 = lane & 15, g = lane >> 4;
+  for (int i = threadIdx.x; i < (4 * N * ZB_NODE_B + 2 * EB * M_BYTES) / 4; i += 256)
+    reinterpret_cast<unsigned*>(lds)[i] = 0x3c003c00u + ((i * 2654435761u) & 0x03ff03ffu);
+  __syncthreads();
+  float w2[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) w2[q] = p.w2f[lane * 16 + q];
+  f32x4 dH[N][2];   // tangent features of ALL nodes for this wave's 16 directions
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+      for (int q = 0; q < 4; ++q) dH[n][rb][q] = p.init[(threadIdx.x * 97 + n * 8 + rb * 4 + q) & 4095] - 0.5f;
+  Frag dpos[2];     // position tangents as B fragments, K = 64 (two k-steps), private, in registers
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+    for (int q = 0; q < 4; ++q) { dpos[ks].hi[q] = 0x3c003c00u + ((lane * 7 + q) & 0xff); dpos[ks].lo[q] = 0x10001000u + (lane & 0xff); }
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  unsigned char* myzb = zb + wave * N * ZB_NODE_B;
+  long long tN = 0, tB = 0, tM = 0, tW = 0, tF = 0;
+
+  // partial sums of M over the edges THIS wave built for the current node (rows 0..31: 16 values, rows 32..: 8)
+  float abar[24];
+
+  // the five primal vectors of one edge, as this lane needs them: a, m' by row (r16, r16 + 16), b, p by k (8 g .. 8 g + 7), c_k.
+  // Loaded from global memory THREE batches (one node) ahead of their use: an HBM read is 2-5 k cycles, a batch ~1 k
+  struct Pre { float a0, a1, m0, m1, ck; f32x4 b0, b1, p0, p1; };
+  auto fetch = [&](const float* __restrict__ f, Pre& r) {
+    r.a0 = f[r16]; r.a1 = f[16 + r16]; r.m0 = f[32 + r16]; r.m1 = f[48 + r16];
+    r.b0 = *reinterpret_cast<const f32x4*>(f + 64 + 8 * g); r.b1 = *reinterpret_cast<const f32x4*>(f + 64 + 8 * g + 4);
+    r.p0 = *reinterpret_cast<const f32x4*>(f + 96 + 8 * g); r.p1 = *reinterpret_cast<const f32x4*>(f + 96 + 8 * g + 4);
+    r.ck = f[128 + (r16 & 3)];
+  };
+  auto build = [&](const Pre& r, unsigned char* dst) {
+    const float a0 = r.a0, a1 = r.a1, m0 = r.m0, m1 = r.m1;
+    const f32x4 b0 = r.b0, b1 = r.b1, p0 = r.p0, p1 = r.p1;
+    const float ck = r.ck * (r16 < 3 ? 1.0f : 0.0f);
+    const float bk[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    const float pk[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+    u32x4* d = reinterpret_cast<u32x4*>(dst) + lane;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const float a = rb ? a1 : a0, mp = rb ? m1 : m0;
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        v[q] = fmaf(a, w2[rb * 8 + q], mp * pk[q]) * bk[q];
+        abar[rb * 8 + q] += v[q];
+      }
+      u32x4 hi, lo;
+      split8(v, hi, lo);
+      d[(rb * 2) * 64] = hi;
+      d[(rb * 2 + 1) * 64] = lo;
+    }
+    {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        v[q] = ck * pk[q];
+        abar[16 + q] += v[q];
+      }
+      u32x4 hi, lo;
+      split8(v, hi, lo);
+      d[4 * 64] = hi;
+      d[5 * 64] = lo;
+    }
+  };
+
+  for (int it = 0; it < p.walkers; ++it) {
+    const float* prim = p.primal + ((size_t)blockIdx.x * p.walkers + it) * NE * PRIMAL_F;
+    long long t0 = __builtin_amdgcn_s_memtime();
+    // ---- node phase (private): Z^B_n = W_b dH_n -> this wave's B fragments
+    {
+      WMat wb;
+      load_w(wb, p.wfrag, 1, lane);
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        Frag x;
+        to_frag(dH[n], x);
+        f32x4 z[2] = {zero4, zero4};
+        gemm(wb, x, z);
+        Frag o;
+        to_frag(z, o);
+        u32x4* dst = reinterpret_cast<u32x4*>(myzb + n * ZB_NODE_B) + lane;
+        dst[0] = o.hi;
+        dst[64] = o.lo;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 24; ++q) abar[q] = 0.f;
+    Pre pre[3];
+    {
+      Pre first;
+      fetch(prim + (size_t)wave * PRIMAL_F, first);                 // batch 0 (exposed once per walker and layer)
+#pragma unroll
+      for (int k = 1; k <= 3; ++k) fetch(prim + (size_t)(k * EB + wave) * PRIMAL_F, pre[k % 3]);   // batches 1, 2, 3
+      build(first, mbuf + wave * M_BYTES);
+    }
+    long long t1 = __builtin_amdgcn_s_memtime();
+    __syncthreads();
+    long long t2 = __builtin_amdgcn_s_memtime();
+    tN += t1 - t0; tW += t2 - t1;
+    // ---- edge phase: node by node, three batches of four edges per node
+#pragma unroll 1
+    for (int i = 0; i < N; ++i) {
+      f32x4 acc[3] = {zero4, zero4, zero4};
+      long long ta = __builtin_amdgcn_s_memtime();
+#pragma unroll
+      for (int bb = 0; bb < 3; ++bb) {
+        const int b = 3 * i + bb;
+        long long tb0 = __builtin_amdgcn_s_memtime();
+        // build MY edge of the next batch into the other slot from the registers fetched a node ago, then refill them
+        if (b + 1 < NBATCH) {
+          build(pre[(bb + 1) % 3], mbuf + (((b + 1) & 1) * EB + wave) * M_BYTES);
+          if (b + 4 < NBATCH) fetch(prim + (size_t)((b + 4) * EB + wave) * PRIMAL_F, pre[(bb + 1) % 3]);
+        }
+        long long tb1 = __builtin_amdgcn_s_memtime();
+        // consume batch b: four edges (i, j)
+        const unsigned char* mb = mbuf + ((b & 1) * EB) * M_BYTES;
+#pragma unroll
+        for (int q = 0; q < EB; ++q) {
+          const int jj = bb * EB + q, j = jj + (jj >= i);
+          const u32x4* ma = reinterpret_cast<const u32x4*>(mb + q * M_BYTES) + lane;
+          const u32x4* zs = reinterpret_cast<const u32x4*>(myzb + j * ZB_NODE_B) + lane;
+          Frag B, A0, A1, A2;
+          B.hi = zs[0]; B.lo = zs[64];
+          A0.hi = ma[0]; A0.lo = ma[64]; A1.hi = ma[128]; A1.lo = ma[192]; A2.hi = ma[256]; A2.lo = ma[320];
+          acc[0] = mma3(A0, B, acc[0]);
+          acc[1] = mma3(A1, B, acc[1]);
+          acc[2] = mma3(A2, B, acc[2]);
+        }
+        long long tb2 = __builtin_amdgcn_s_memtime();
+        __syncthreads();
+        long long tb3 = __builtin_amdgcn_s_memtime();
+        tB += tb1 - tb0; tM += tb2 - tb1; tW += tb3 - tb2;
+      }
+      long long tf0 = __builtin_amdgcn_s_memtime();
+      // ---- node finish.  (1) exchange the partial sums of M over node i's edges: every wave built three of the twelve
+      // (NOTE: with the one-batch look-ahead above the sums already contain the first edge of node i + 1 built by this wave;
+      // a real kernel keeps two sets -- same instruction count, so the micro-kernel does not bother)
+      {
+        float* xs = reinterpret_cast<float*>(mbuf + (((3 * i + 2) & 1) * EB) * M_BYTES);   // the slot consumed last: free now
+        f32x4* me = reinterpret_cast<f32x4*>(xs) + wave * 64 + lane;   // [q][wave][lane]: 16-byte lane stride, conflict-free
+#pragma unroll
+        for (int q = 0; q < 6; ++q) me[q * 256] = f32x4{abar[4 * q], abar[4 * q + 1], abar[4 * q + 2], abar[4 * q + 3]};
+#pragma unroll
+        for (int q = 0; q < 24; ++q) abar[q] = 0.f;
+        __syncthreads();
+        float tot[24];
+#pragma unroll
+        for (int q = 0; q < 24; ++q) tot[q] = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const f32x4* o = reinterpret_cast<const f32x4*>(xs) + w * 64 + lane;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) {
+            const f32x4 v = o[q * 256];
+            tot[4 * q] += v.x; tot[4 * q + 1] += v.y; tot[4 * q + 2] += v.z; tot[4 * q + 3] += v.w;
+          }
+        }
+        __syncthreads();   // the slot is rebuilt by the next batch
+        // Acc += Abar_i (W_a dH_i)
+        Frag xh;
+        to_frag(dH[0], xh);   // the node being finished is always dH[0]: the array is rotated by one node below (104 moves per
+                              // node -- a register-resident dH of all 13 nodes cannot be indexed by a run-time node)
+        WMat wa;
+        load_w(wa, p.wfrag, 0, lane);
+        f32x4 za[2] = {zero4, zero4};
+        gemm(wa, xh, za);
+        Frag xa;
+        to_frag(za, xa);
+        Frag ab[3];
+        {
+          const float v0[8] = {tot[0], tot[1], tot[2], tot[3], tot[4], tot[5], tot[6], tot[7]};
+          const float v1[8] = {tot[8], tot[9], tot[10], tot[11], tot[12], tot[13], tot[14], tot[15]};
+          const float v2[8] = {tot[16], tot[17], tot[18], tot[19], tot[20], tot[21], tot[22], tot[23]};
+          split8(v0, ab[0].hi, ab[0].lo);
+          split8(v1, ab[1].hi, ab[1].lo);
+          split8(v2, ab[2].hi, ab[2].lo);
+        }
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) acc[rb] = mma3(ab[rb], xa, acc[rb]);
+        // (2) Acc += R_i dPos, K = 64: A from a coefficient table (real kernel: geometry x alpha), B = dpos in registers
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+          for (int rb = 0; rb < 3; ++rb) {
+            const float* rp = p.rtab + lane * 48 + (ks * 3 + rb) * 8;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(rp), a1 = *reinterpret_cast<const f32x4*>(rp + 4);
+            const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            Frag rm;
+            split8(v, rm.hi, rm.lo);
+            acc[rb] = mma3(rm, dpos[ks], acc[rb]);
+          }
+        }
+        // (3) node model: dH_i += W_n2 (g_n o (W_n1a dH_i + W_n1b Acc_i)); rows 32.. update the position tangent
+        WMat wn;
+        f32x4 zn[2] = {zero4, zero4};
+        load_w(wn, p.wfrag, 3, lane);
+        gemm(wn, xh, zn);
+        Frag xg;
+        {
+          const f32x4 a2[2] = {acc[0], acc[1]};
+          to_frag(a2, xg);
+        }
+        load_w(wn, p.wfrag, 4, lane);
+        gemm(wn, xg, zn);
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.init + ((i * 32 + 4 * g) & 4092)), g1 = *reinterpret_cast<const f32x4*>(p.init + ((i * 32 + 16 + 4 * g) & 4092));
+        zn[0] *= g0; zn[1] *= g1;
+        Frag xz;
+        to_frag(zn, xz);
+        load_w(wn, p.wfrag, 5, lane);
+        f32x4 nh[2] = {zero4, zero4};
+        gemm(wn, xz, nh);
+        {
+          f32x4 upd[2];
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb) upd[rb] = (dH[0][rb] + nh[rb]) * (1.0f / 64.0f);
+          upd[0] += acc[2] * (1.0f / 4096.0f);
+#pragma unroll
+          for (int n = 0; n + 1 < N; ++n) { dH[n][0] = dH[n + 1][0]; dH[n][1] = dH[n + 1][1]; }
+          dH[N - 1][0] = upd[0]; dH[N - 1][1] = upd[1];
+        }
+        // position tangent of node i back into the K = 64 fragments (one of the 16 dwords per lane changes)
+        dpos[i & 1].hi[i & 3] ^= (__float_as_uint(acc[2].x) >> 20) & 0x00030003u;
+      }
+      long long tf1 = __builtin_amdgcn_s_memtime();
+      tF += tf1 - tf0;
+      (void)ta;
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) s += dH[n][rb].x + dH[n][rb].y + dH[n][rb].z + dH[n][rb].w;
+  p.out[blockIdx.x * 256 + threadIdx.x] = s;
+  if (lane == 0) {
+    long long* c = p.cyc + (blockIdx.x * 4 + wave) * 8;
+    c[0] = tN; c[1] = tB; c[2] = tM; c[3] = tW; c[4] = tF;
+  }
+}
+
+int main(int argc, char** argv) {
+  const int walkers = argc > 1 ? atoi(argv[1]) : 64;
+  hipDeviceProp_t prop;
+  CHECK(hipGetDeviceProperties(&prop, 0));
+  const int blocks = prop.multiProcessorCount;
+  std::vector<float> init(4096), w2(64 * 16), rt(64 * 48);
+  std::vector<unsigned> wf(6 * 256 * 4);
+  srand(1);
+  for (auto& v : init) v = (float)(rand() & 0xffffff) / 16777216.0f;
+  for (auto& v : w2) v = ((float)(rand() & 0xffffff) / 16777216.0f - 0.5f) * 0.35f;
+  for (auto& v : rt) v = ((float)(rand() & 0xffffff) / 16777216.0f - 0.5f) * 0.1f;
+  for (size_t i = 0; i < wf.size(); ++i) {
+    const bool lo = ((i / 4 / 64) & 1) != 0;
+    const unsigned short a = (unsigned short)((lo ? 0x0a00 : 0x3000) + (rand() & 0x3ff) + ((rand() & 1) << 15));
+    const unsigned short b = (unsigned short)((lo ? 0x0a00 : 0x3000) + (rand() & 0x3ff) + ((rand() & 1) << 15));
+    wf[i] = a | ((unsigned)b << 16);
+  }
+  const size_t prim_n = (size_t)blocks * walkers * NE * PRIMAL_F;
+  std::vector<float> prim(prim_n);
+  for (size_t i = 0; i < prim_n; ++i) prim[i] = 0.1f + 0.4f * init[(i * 2654435761u) & 4095];
+  float *d_init, *d_w2, *d_out, *d_prim, *d_rt;
+  unsigned* d_wf;
+  long long* d_cyc;
+  CHECK(hipMalloc(&d_init, init.size() * 4));
+  CHECK(hipMalloc(&d_w2, w2.size() * 4));
+  CHECK(hipMalloc(&d_rt, rt.size() * 4));
+  CHECK(hipMalloc(&d_wf, wf.size() * 4));
+  CHECK(hipMalloc(&d_prim, prim_n * 4));
+  CHECK(hipMalloc(&d_out, blocks * 256 * 4));
+  CHECK(hipMalloc(&d_cyc, blocks * 32 * 8));
+  CHECK(hipMemcpy(d_init, init.data(), init.size() * 4, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(d_w2, w2.data(), w2.size() * 4, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(d_rt, rt.data(), rt.size() * 4, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(d_wf, wf.data(), wf.size() * 4, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(d_prim, prim.data(), prim_n * 4, hipMemcpyHostToDevice));
+  Params p{reinterpret_cast<const u32x4*>(d_wf), d_w2, d_prim, d_rt, d_init, d_out, d_cyc, walkers};
+  const size_t lds = 4 * N * ZB_NODE_B + 2 * EB * M_BYTES;
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dir_mid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  printf("direction-split middle layer: 4 waves per walker (one 16-column direction tile each), M built once per edge and shared through LDS;\n"
+         "%d walkers per CU, %d CUs, LDS %zu B per workgroup, primal stream %.1f KB per walker\n", walkers, blocks, lds, NE * PRIMAL_F * 4 / 1024.0);
+  std::vector<float> first;
+  for (int rep = 0; rep < 6; ++rep) {
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(dir_mid_kernel, dim3(blocks), dim3(256), lds, 0, p);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    CHECK(hipGetLastError());
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<float> cur((size_t)blocks * 256);
+    CHECK(hipMemcpy(cur.data(), d_out, cur.size() * 4, hipMemcpyDeviceToHost));
+    size_t nd = 0;
+    if (first.empty()) first = cur;
+    else for (size_t i = 0; i < cur.size(); ++i) nd += (memcmp(&cur[i], &first[i], 4) != 0);
+    std::vector<long long> cyc(blocks * 32);
+    CHECK(hipMemcpy(cyc.data(), d_cyc, cyc.size() * 8, hipMemcpyDeviceToHost));
+    printf("rep %d: %.3f ms = %.2f us per walker and CU => 65 536 walkers: %.2f ms for this layer  (%zu outputs differ from rep 0)\n", rep, ms,
+           1e3 * ms / walkers, 65536.0 / blocks * (ms / walkers), nd);
+    const double per = 1.0 / ((double)blocks * walkers);
+    for (int w = 0; w < 4; ++w) {
+      double s[5] = {0, 0, 0, 0, 0};
+      for (int bl = 0; bl < blocks; ++bl)
+        for (int k = 0; k < 5; ++k) s[k] += cyc[(bl * 4 + w) * 8 + k];
+      if (rep == 0 || rep == 5)
+        printf("   wave %d, s_memtime ticks per walker: node phase %.0f | building M %.0f | edge products %.0f | at barriers %.0f | node finish %.0f\n",
+               w, s[0] * per, s[1] * per, s[2] * per, s[3] * per, s[4] * per);
+    }
+  }
+  float sink;
+  CHECK(hipMemcpy(&sink, d_out, 4, hipMemcpyDeviceToHost));
+  printf("sink %g\n", sink);
+  return 0;
+}
