@@ -2279,6 +2279,9 @@ static const DivTanShape kDivTan[] = {
 constexpr int kDivTanOwned = 3;  // the first kDivTanOwned entries are the wave-owned fallbacks
 static const DivTanShape kDivTanAlt[] = {PITA_DIVTAN_SHAPE(13, 3, 2, 4, 4), PITA_DIVTAN_SHAPE(22, 3, 1, 4, 4),
                                          PITA_DIVTAN_SHAPE(55, 3, 1, 4, 3), PITA_DIVSHR_SHAPE(13, 3, 2, 12, 1)};
+// (Round 6, measured and removed: seven / six waves per block -- every wave's tangent tables are 10.75 KB of LDS, so fewer waves
+// leave FOUR ring slots instead of three -- LJ55 trace 610 -> 855 / 903 ms at 32 768 walkers, LJ13 18.4 -> 25.0 ms with seven
+// waves: the launches are bound by the waves' own work, not by the ring's depth; profiles/r06_tangent_waves_per_block_ab.txt.)
 static const DivTanShape* find_div_tan_shape(int n, int dim, int n_layers) {
   static const bool off = getenv("PITA_DIV_NOCACHE") != nullptr;  // development aid: A/B against the cache-free path
   if (off) return nullptr;
