@@ -2028,6 +2028,24 @@ def test_default_path_full_batch_rerun(pa, golden):
         for nm, u, v in zip(names, first, drift()):
             nd = int((u != v).reshape(B, -1).any(1).sum())
             assert nd == 0, f"debiased drift rerun {rerun}: {nm} differs for {nd} of {B} walkers"
+    # the reference's own batch (num_eval_samples = 2 048, lj13.yaml:32): the small-batch mappings -- two walkers per wave in
+    # the sampler and (round 6) in the reverse-mode kernel -- through the same drift, four reruns
+    Bs = 2048
+    xs_, hs_, bs_ = xm[:Bs].contiguous(), ht[:Bs].contiguous(), beta[:Bs].contiguous()
+
+    def drift_small():
+        out = list(net.jacobian_trace(hs_, xs_, bs_, want_denoiser=True))
+        out += [o for o in sde.energy_net.net.vjp(hs_, xs_, bs_, want_dot_h=True, want_h_parts=True) if o is not None]
+        return [o.clone() for o in out]
+
+    first_s = drift_small()
+    # (another reverse-mode instantiation runs here: same values to fp32 rounding, DESIGN 2 "determinism")
+    assert rel(first_s[3], first[3][:Bs]) < 2e-6 and rel(first_s[0], first[0][:Bs]) < 2e-6
+    for rerun in range(4):
+        for nm, u, v in zip(names, first_s, drift_small()):
+            assert torch.equal(u, v), f"small-batch drift rerun {rerun}: {nm} differs"
+    a = net.sampler_run(x0[:Bs].clone(), tab, N, seed=11)
+    assert torch.equal(a, net.sampler_run(x0[:Bs].clone(), tab, N, seed=11))
     # LJ55 at the C5 shard
     net55 = make_net(pa, 55, 3, golden("egnn_weights_trainedlike.npz"))
     B55, N55 = 32768, 20

@@ -91,7 +91,7 @@ def test_alp_energy_facade_and_system_xml_fixture():
 
 
 def test_committed_bench_lines_follow_survey_8d():
-    """The committed bench lines of the current and the previous round (profiles/r05_bench_<config>.json, r04_...) can be
+    """The committed bench lines of the current and the previous round (profiles/r06_bench_<config>.json, r05_...) can be
     recomputed from their own fields by SURVEY 8(d)'s formulas: roofline.achieved = algorithmic flops per launch / launch
     time, frac = achieved / peak, value = walkers x steps / (steps x ms_per_step), PMC traffic >= algorithmic bytes; the
     rocprofv3 kernel-stats summary of the same command (profiles/<round>_kernel_stats_<config>.csv) agrees with the
@@ -103,8 +103,8 @@ def test_committed_bench_lines_follow_survey_8d():
 
     prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     alg = {"lj13": 4196608.0, "dw4": None, "aldp22": None, "lj55": None}  # LJ13: 2 098 304 MAC x 2
-    for rnd, cfg in (("r04", "lj13"), ("r04", "dw4"), ("r04", "aldp22"), ("r04", "lj55"), ("r05", "lj13"), ("r05", "dw4"),
-                     ("r05", "aldp22"), ("r05", "lj55")):
+    for rnd, cfg in (("r05", "lj13"), ("r05", "dw4"), ("r05", "aldp22"), ("r05", "lj55"), ("r06", "lj13"), ("r06", "dw4"),
+                     ("r06", "aldp22"), ("r06", "lj55")):
         path = os.path.join(prof, f"{rnd}_bench_{cfg}.json")
         line = json.loads([ln for ln in open(path) if ln.startswith("{")][-1])
         r = line["roofline"]
@@ -120,6 +120,20 @@ def test_committed_bench_lines_follow_survey_8d():
             assert r["traffic"] >= r["algorithmic_bytes_per_launch"] == 2 * B * line["config"]["walkers_per_gpu"] // B * 0 + r["algorithmic_bytes_per_launch"]
         cb = line["cpu_baseline"]
         assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+        if rnd >= "r06":  # core count AND CPU model; the reference's own batch sizes beside the metric's
+            assert cb["cpu_model"] and cb["logical_cpus"] >= cb["cores"]
+            if cfg == "lj13":
+                sb = line["small_batch"]["sizes"]
+                assert set(sb) == {"512", "2048", "5000", "16384"}
+                for Bs, legs in sb.items():
+                    m = legs["sampler_mapping"]
+                    assert 0 < m["wave_slot_fill"] <= 1 and m["waves"] <= m["resident_wave_slots"]
+                    for leg in ("not_debiased", "default_regime"):
+                        e = legs[leg]
+                        assert e["finite"] and e["walkers"] == int(Bs) and 0 < e["frac_of_full_batch"] <= 1.05
+                        assert abs(e["value"] - e["walkers"] * e["steps"] / e["seconds"]) < 1e-6 * e["value"]
+                # the review's bar: the not-debiased 2 048-walker trajectory at >= 25 % of the full-batch rate
+                assert sb["2048"]["not_debiased"]["frac_of_full_batch"] >= 0.25
         if rnd >= "r05":
             g = line["steps_of_grid"]
             assert g["grid_steps"] >= 1 and 0 <= g["first"] < g["grid_steps"] and 0 <= g["last"] < g["grid_steps"]

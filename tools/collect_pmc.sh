@@ -10,11 +10,11 @@ OUT="$PWD/gpurun_out/$TAG"
 REPO="$PWD"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--config $CFG --steps 200 --warmup 100 --no-cpu-baseline --no-debiased --no-e2e $*"
+ARGS="--config $CFG --steps 200 --warmup 100 --no-cpu-baseline --no-debiased --no-e2e --no-small-batch $*"
 python3 bench.py --config "$CFG" "$@" > "$OUT/bench_$CFG.json" 2> "$OUT/bench_$CFG.err"
 # the stats pass runs the bench's default protocol (1 000 timed steps in 100-step launches after 100 warm-up steps) so that
 # its per-kernel average is over 11 launches, not dominated by the first, cold one
-ARGS_STATS="--config $CFG --steps 1000 --warmup 100 --no-cpu-baseline --no-debiased --no-e2e $*"
+ARGS_STATS="--config $CFG --steps 1000 --warmup 100 --no-cpu-baseline --no-debiased --no-e2e --no-small-batch $*"
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$CFG" -- python3 "$REPO/bench.py" $ARGS_STATS > "$OUT/bench_under_rocprof_$CFG.json" 2> "$OUT/rocprof_$CFG.err" )
 WALK=$(python3 -c "import json;print(json.load(open('$OUT/bench_$CFG.json'))['config']['walkers_per_gpu'])")
 P1="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
