@@ -486,6 +486,12 @@ int pita_systematic_resample(const float* logits, int64_t B, double u0, int64_t*
 int pita_gather_rows(const float* src, const int64_t* ids, float* out, int64_t B, int D,
                      void* stream);
 
+/* Number of distinct parents of one resampling event, max(1, #{i : ids[i] != ids[(i - 1) mod B]}), written to the device
+ * word `out` (no host synchronisation): the ids of a systematic resampling are non-decreasing up to the cyclic rotation by
+ * the event's uniform (utils.py:111-120), so every distinct parent is one cyclic run.  Replaces
+ * len(np.unique(choice)) of sde_integration.py:295. */
+int pita_count_runs(const int64_t* ids, int64_t B, int64_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -133,6 +133,7 @@ _PROTOS = {
     "pita_resample_workspace_bytes": (c_size_t, [c_int64]),
     "pita_systematic_resample": (c_int, [c_void_p, c_int64, c_double, c_void_p, c_void_p, c_void_p]),
     "pita_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "pita_count_runs": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
 }
 
 EXPORTS = tuple(_PROTOS)

@@ -416,9 +416,35 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restric
   }
 }
 
+// distinct parents of a systematic resampling = cyclic runs of the id vector (ids are non-decreasing up to the rotation by the
+// event's uniform): one block, integer sums -- replaces roll + != + cast + sum + clamp (five launches) behind every event
+__global__ void __launch_bounds__(1024) count_runs_kernel(const long long* __restrict__ ids, long long B,
+                                                          long long* __restrict__ out) {
+  __shared__ unsigned part[16];
+  unsigned c = 0;
+  for (long long i = threadIdx.x; i < B; i += 1024) c += ids[i] != ids[i == 0 ? B - 1 : i - 1] ? 1u : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned t = 0;
+    for (int w = 0; w < 16; ++w) t += part[w];
+    *out = t < 1u ? 1 : (long long)t;
+  }
+}
+
 }  // namespace pita
 
 using namespace pita;
+
+extern "C" int pita_count_runs(const int64_t* ids, int64_t B, int64_t* out, void* stream) {
+  PITA_REQUIRE(ids && out && B >= 1, "pita_count_runs: bad argument");
+  hipLaunchKernelGGL(count_runs_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const long long*)ids, (long long)B,
+                     (long long*)out);
+  PITA_LAUNCH_CHECK();
+  return PITA_OK;
+}
 
 extern "C" int pita_em_step(float* x, const float* drift, const float* noise, int64_t B, int n, int d, float dt,
                             float noise_scale, float sqrt_dt, uint64_t seed, uint64_t walker_offset, int64_t step,

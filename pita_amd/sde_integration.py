@@ -201,7 +201,13 @@ def _count_distinct(ids):
     ids are non-decreasing up to the cyclic rotation by the event's uniform (utils.py:111-120), so every distinct parent
     is one cyclic run: distinct = max(1, number of positions whose cyclic predecessor differs).  The reference takes
     ``len(np.unique(choice))`` on the host every step (sde_integration.py:295)."""
-    return (ids != torch.roll(ids, 1)).sum().clamp_min(1)
+    if ids.is_cuda:  # one launch (pita_count_runs) instead of roll + != + cast + sum + clamp
+        ids = ids.contiguous()
+        out = torch.empty((), device=ids.device, dtype=torch.int64)
+        _lib.check(_lib.lib().pita_count_runs(ids.data_ptr(), ids.numel(), out.data_ptr(), _lib.stream_ptr(ids.device)),
+                   "pita_count_runs")
+        return out
+    return (ids != torch.roll(ids, 1)).sum().clamp_min(1)  # host tensors: the gloo / dry-run paths
 
 
 def _host_counts(counts):
@@ -392,7 +398,8 @@ class WeightedSDEIntegrator:
         N = self.num_integration_steps
         dev = x.device
         L = _lib.lib()
-        a = torch.zeros(Bl, device=dev)
+        zero_a = torch.zeros(Bl, device=dev)  # never written to: every update of `a` makes a new tensor
+        a = zero_a
         logweights, num_unique_idxs, sde_terms_all = [], [], []
         bs = self.batch_size or Bl
         st4 = st8 = None
@@ -404,7 +411,7 @@ class WeightedSDEIntegrator:
             t = times[step]  # host scalar: the schedules' scalars (gamma, dgamma/dt) are then read without a device sync
             row = tab_h[step]
             if step < self.start_resampling_step:  # walkers frozen, weights zero (:278-280)
-                a = torch.zeros_like(a)
+                a = zero_a
                 logweights.append(comm.all_gather(a))
                 num_unique_idxs.append(Bg)
                 continue
@@ -422,9 +429,9 @@ class WeightedSDEIntegrator:
                     if v is not None and v.numel() != Bl:
                         raise ValueError(f"SDETerms field has {v.numel()} entries, expected one per walker ({Bl})")
                 _lib.check(L.pita_moments4(*(_lib.ptr(v) for v in vs), Bl, st8[step].data_ptr(), st), "pita_moments4")
-            a = a + terms.drift_A * float(row[_lib.ST_DT])
+            a = torch.add(a, terms.drift_A, alpha=float(row[_lib.ST_DT]))  # a + drift_A dt in one launch
             if step >= self.end_resampling_step:
-                a = torch.zeros_like(a)
+                a = zero_a
             n_unique = Bg
             due = not (resampling_interval == -1 or (step + 1) % resampling_interval != 0
                        or step >= self.end_resampling_step)
@@ -434,7 +441,7 @@ class WeightedSDEIntegrator:
                 ids, _ = sample_cat_sys(ag.shape[0], ag, u)
                 n_unique = _count_distinct(ids)
                 x = comm.exchange_rows(x, ids, Bl)
-                a = torch.zeros_like(a)
+                a = zero_a
             if mean_free:
                 x = remove_mean(x, n, d)
             logweights.append(comm.all_gather(a))

@@ -1203,6 +1203,27 @@ def test_resample_golden(pa, golden, case):
     assert torch.equal(got, x[torch.as_tensor(want).cuda()])
 
 
+def test_count_runs_kernel_equals_np_unique(pa):
+    """pita_count_runs (round 6: the distinct-parent count of a resampling event in ONE launch instead of roll + != + cast +
+    sum + clamp) against len(np.unique(ids)) -- sde_integration.py:295 -- on reference-shaped id vectors: constant, strictly
+    increasing, runs that wrap around the end, and the kernel's own ids at 1, 2, 1 000, 65 536 and 262 144 walkers."""
+    from pita_amd.sde_integration import _count_distinct, _host_counts
+    from pita_amd.utils import sample_cat_sys
+
+    gen = torch.Generator().manual_seed(3)
+    cases = [torch.zeros(17, dtype=torch.int64), torch.arange(9), torch.tensor([3, 3, 4, 7, 7, 0, 0, 3]),
+             torch.tensor([5, 5, 5, 1, 1, 5]), torch.zeros(1, dtype=torch.int64), torch.arange(5000)]
+    cases = [c.cuda() for c in cases]
+    for B in (1, 2, 1000, 65536, 262144):
+        for spread in (0.1, 3.0, 30.0):
+            logits = (torch.randn(B, generator=gen) * spread).cuda()
+            for u0 in (0.0, 0.37, 0.999):
+                cases.append(sample_cat_sys(B, logits, torch.tensor([u0], dtype=torch.float64))[0])
+    counts = [_count_distinct(c) for c in cases]
+    assert all(c.is_cuda and c.dim() == 0 and c.dtype == torch.int64 for c in counts)
+    assert _host_counts(list(counts)) == [len(np.unique(c.cpu().numpy())) for c in cases]
+
+
 def test_resample_global_batch_of_config_c5(pa):
     """262 144 walkers (config C5's global batch): ids against the oracle, sortedness, every id a valid walker; the
     multi-block passes are timed (printed) so the cost of a global resampling event is on record."""
