@@ -213,6 +213,14 @@ int pita_ff_create(pita_ff_t** out, const pita_ff_config* cfg);
 int pita_ff_destroy(pita_ff_t* ff);
 int pita_ff_logp_force(pita_ff_t* ff, const float* x, float* logp, float* force /*nullable*/, int64_t B, void* stream);
 
+/* Negative-time / Langevin descent on the force-field target (sde_integration.py:353-360 with the target of
+ * alp_energy.py:122-149): n_steps of x <- remove_mean(x + F dt + noise_scale sqrt_dt xi) in ONE launch, walkers LDS-resident,
+ * in place on x [B, 3 n_atoms]; bit-identical to n_steps x (pita_ff_logp_force + pita_em_step).  noise: [n_steps, B, 3 n]
+ * injected normals or NULL (Philox keyed by seed, walker_offset + walker, step0 + step, atom). */
+int pita_ff_descent(pita_ff_t* ff, float* x, const float* noise /*nullable*/, int64_t B, int n_steps, float dt,
+                    float noise_scale, float sqrt_dt, uint64_t seed, uint64_t walker_offset, int64_t step0,
+                    int remove_mean, void* stream);
+
 /* ---------------------------------------------------------------- EGNN backbone (K5, K7)
  * replaces EGNN_dynamics.forward (pita/src/models/components/egnn_temp_conditioned.py:56-93,
  * egnn.py:50-80), EGNN.forward (:172-194), E_GCL (:197-356) and the EDM wrappers

@@ -77,6 +77,8 @@ _PROTOS = {
     "pita_ff_create": (c_int, [POINTER(c_void_p), POINTER(FfConfig)]),
     "pita_ff_destroy": (c_int, [c_void_p]),
     "pita_ff_logp_force": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "pita_ff_descent": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_uint64,
+                                c_uint64, c_int64, c_int, c_void_p]),
     "pita_egnn_create": (c_int, [POINTER(c_void_p), POINTER(EgnnConfig), c_void_p, c_int64]),
     "pita_egnn_destroy": (c_int, [c_void_p]),
     "pita_egnn_num_weights": (c_int64, [POINTER(EgnnConfig)]),

@@ -168,6 +168,18 @@ class ForceFieldEnergy(BaseMoleculeEnergy):
         return (logp, force) if return_force else logp
 
 
+    def fused_descent(self, x, num_steps, dt, noise_scale, sqrt_dt, seed=0, walker_offset=0, step0=0, remove_mean=True,
+                      noise=None):
+        """``num_steps`` of x <- remove_mean(x + F dt + noise_scale*sqrt_dt*xi) in ONE launch, in place
+        (negative_time_descent, sde_integration.py:353-360; pita_ff_descent), bit-identical to the per-step path."""
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().pita_ff_descent(
+                self._native(), x.data_ptr(), _lib.ptr(noise), x.shape[0], int(num_steps), float(dt), float(noise_scale),
+                float(sqrt_dt), int(seed) & 0xFFFFFFFFFFFFFFFF, int(walker_offset), int(step0), int(bool(remove_mean)),
+                _lib.stream_ptr(x.device)), "pita_ff_descent")
+        return x
+
+
 class ALPEnergy(ForceFieldEnergy):
     """Drop-in for ``src.energies.alp_energy.ALPEnergy`` (pita/src/energies/alp_energy.py:41-149): the reference
     constructor's argument names and defaults, the same call contract (``energy(samples, return_force=False)``, samples

@@ -31,6 +31,14 @@ struct FfParams {
   int o_csr_off, o_csr_ent;  // per-atom interaction lists: csr_off[3][n+1] (bonds, angles, torsions), entries (term << 2) | role
   const float* x; float* logp; float* force;
   long long B;
+  // fused negative-time / Langevin descent (ff_kernel<true>): all steps of x <- remove_mean(x + F dt + noise_scale sqrt_dt xi)
+  // with the walkers LDS-resident; the arithmetic of pita_em_step (sampler_kernels.hip: elem_kernel<3, OP_EM>) op for op
+  float* xio;            // [B][3 n] walkers, updated in place
+  const float* noise;    // [steps][B][3 n] injected normals, or null: Philox keyed by (seed, global walker, step, atom)
+  int steps, remove_mean;
+  float dt, noise_scale, sqrt_dt;
+  unsigned long long seed, walker_offset;
+  long long step0;
 };
 
 // One thread = one (walker, atom): it evaluates every interaction its atom takes part in and keeps the atom's gradient
@@ -39,6 +47,7 @@ struct FfParams {
 // LDS executes ds_add_f32 at well under one lane per clock).  Per-atom interaction lists (CSR) are built on the host.
 constexpr int FF_THREADS = 256;
 
+template <bool DESCENT>
 __global__ void __launch_bounds__(FF_THREADS) ff_kernel(FfParams p) {
   extern __shared__ float sm[];
   const int n = p.n, D = 3 * n, WPB = FF_THREADS / n;
@@ -60,13 +69,20 @@ __global__ void __launch_bounds__(FF_THREADS) ff_kernel(FfParams p) {
   float* es = gs + WPB * D;        // [WPB][n] energy partials
   float* br = es + WPB * n;        // [WPB][n] Born radii
   float* bw = br + WPB * n;        // [WPB][n] dE/d(HCT sum)
+  float* xu = bw + WPB * n;        // DESCENT: [WPB][D] walkers in model units, resident over the steps
+  float* vv = xu + WPB * D;        // DESCENT: [WPB][D] updated walkers before the centring
   const int tid = threadIdx.x, wl = tid / n, a = tid - wl * n;
   const bool lane_on = wl < WPB;
   const long long nblk = (p.B + WPB - 1) / WPB;
   for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
     const long long w0 = blk * WPB;
     const int nw = (int)((p.B - w0) < WPB ? (p.B - w0) : WPB);
-    for (int q = tid; q < nw * D; q += FF_THREADS) xs[q] = p.x[w0 * D + q] * p.length_scale;
+    if (DESCENT) {
+      for (int q = tid; q < nw * D; q += FF_THREADS) xu[q] = p.xio[w0 * D + q];
+      __syncthreads();
+    }
+    for (int step = 0; step < (DESCENT ? p.steps : 1); ++step) {
+    for (int q = tid; q < nw * D; q += FF_THREADS) xs[q] = (DESCENT ? xu[q] : p.x[w0 * D + q]) * p.length_scale;
     __syncthreads();
     const bool act = lane_on && wl < nw;
     const float* xr = xs + (act ? wl : 0) * D;
@@ -248,14 +264,53 @@ __global__ void __launch_bounds__(FF_THREADS) ff_kernel(FfParams p) {
       es[wl * n + a] = E;
     }
     __syncthreads();
-    if (act && a == 0) {
-      float tot = 0.f;
-      for (int q = 0; q < n; ++q) tot += es[wl * n + q];
-      p.logp[w0 + wl] = -tot * p.inv_kT;
+    if (!DESCENT) {
+      if (act && a == 0) {
+        float tot = 0.f;
+        for (int q = 0; q < n; ++q) tot += es[wl * n + q];
+        p.logp[w0 + wl] = -tot * p.inv_kT;
+      }
+      if (p.force)
+        for (int q = tid; q < nw * D; q += FF_THREADS) p.force[w0 * D + q] = gs[q];
+    } else {
+      // Euler-Maruyama update + centring, exactly as pita_em_step does it from the force tensor: v = x + (F dt + (ns xi) sqrt_dt),
+      // mean over the atoms summed in atom order, v -= mean
+      float v[3] = {0.f, 0.f, 0.f};
+      if (act) {
+        float xi[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.noise) {
+          const long long base = (((long long)step * p.B + (w0 + wl)) * n + a) * 3;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) xi[k] = p.noise[base + k];
+        } else {
+          philox_normal4(p.seed, p.walker_offset + (unsigned long long)(w0 + wl), p.step0 + step, (uint32_t)a, xi);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float dr = gs[wl * D + 3 * a + k], dif = p.noise_scale * xi[k];
+          v[k] = xu[wl * D + 3 * a + k] + (dr * p.dt + (dif * p.sqrt_dt));
+          vv[wl * D + 3 * a + k] = v[k];
+        }
+      }
+      __syncthreads();
+      if (act) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          if (p.remove_mean) {
+            float sum = 0.f;
+            for (int q = 0; q < n; ++q) sum += vv[wl * D + 3 * q + k];
+            v[k] -= sum / (float)n;
+          }
+          xu[wl * D + 3 * a + k] = v[k];
+        }
+      }
     }
-    if (p.force)
-      for (int q = tid; q < nw * D; q += FF_THREADS) p.force[w0 * D + q] = gs[q];
     __syncthreads();
+    }  // steps
+    if (DESCENT) {
+      for (int q = tid; q < nw * D; q += FF_THREADS) p.xio[w0 * D + q] = xu[q];
+      __syncthreads();
+    }
   }
 }
 
@@ -414,7 +469,26 @@ extern "C" int pita_ff_logp_force(pita_ff_t* ff, const float* x, float* logp, fl
   PITA_REQUIRE(lds <= 64 * 1024, "pita_ff_logp_force: interaction tables do not fit in LDS");
   const long long nblk = (B + WPB - 1) / WPB;
   const long long cap = 256LL * 8;  // persistent blocks: the tables are staged once per block
-  hipLaunchKernelGGL(ff_kernel, dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(FF_THREADS), lds, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(ff_kernel<false>, dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(FF_THREADS), lds, (hipStream_t)stream, p);
+  PITA_LAUNCH_CHECK();
+  return PITA_OK;
+}
+
+extern "C" int pita_ff_descent(pita_ff_t* ff, float* x, const float* noise, int64_t B, int n_steps, float dt,
+                               float noise_scale, float sqrt_dt, uint64_t seed, uint64_t walker_offset, int64_t step0,
+                               int remove_mean, void* stream) {
+  PITA_REQUIRE(ff && B >= 0 && n_steps >= 0, "pita_ff_descent: bad argument");
+  if (B == 0 || n_steps == 0) return PITA_OK;
+  PITA_REQUIRE(x, "pita_ff_descent: null argument");
+  FfParams p = ff->p;
+  p.xio = x; p.noise = noise; p.B = B; p.steps = n_steps; p.dt = dt; p.noise_scale = noise_scale; p.sqrt_dt = sqrt_dt;
+  p.seed = seed; p.walker_offset = walker_offset; p.step0 = step0; p.remove_mean = remove_mean;
+  const int WPB = FF_THREADS / p.n;
+  const size_t lds = sizeof(float) * ((size_t)p.blob_words + (size_t)WPB * (4 * 3 * p.n + 3 * p.n));
+  PITA_REQUIRE(lds <= 64 * 1024, "pita_ff_descent: interaction tables do not fit in LDS");
+  const long long nblk = (B + WPB - 1) / WPB;
+  const long long cap = 256LL * 8;
+  hipLaunchKernelGGL(ff_kernel<true>, dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(FF_THREADS), lds, (hipStream_t)stream, p);
   PITA_LAUNCH_CHECK();
   return PITA_OK;
 }

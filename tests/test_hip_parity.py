@@ -1536,13 +1536,29 @@ def test_mala_sets_non_finite_walkers_aside(pa, golden):
     assert rel(out[:nv], xv) < 1e-5
 
 
-@pytest.mark.parametrize("target", ["lj13", "lj13_ragged", "lj55", "dw4"])
+@pytest.mark.parametrize("target", ["lj13", "lj13_ragged", "lj55", "dw4", "ff22", "ff22_gb"])
 @pytest.mark.parametrize("langevin", [False, True])
 def test_fused_descent_equals_per_step(pa, golden, target, langevin):
-    """pita_lj_descent / pita_dw_descent keep the walkers in LDS for all steps; they must reproduce the per-step
-    path (force kernel + pita_em_step) bit for bit, with injected and with Philox noise, and follow the oracle."""
+    """pita_lj_descent / pita_dw_descent / (round 6) pita_ff_descent keep the walkers in LDS for all steps; they must
+    reproduce the per-step path (force kernel + pita_em_step) bit for bit, with injected and with Philox noise, and follow
+    the oracle.  ff22: the table-driven force field on the synthetic 22-atom peptide (cutoff + reaction field; _gb: with the
+    GB-OBC1 solvent), 4 099 walkers = the C4 shard plus a ragged last block."""
     gen = torch.Generator().manual_seed(7)
-    if target.startswith("lj13"):
+    if target.startswith("ff22"):
+        from pita_amd.alp_energy import ForceFieldEnergy
+
+        tabs, pos = _synthetic_peptide()
+        if target.endswith("gb"):
+            rng = np.random.default_rng(3)
+            tabs["gb_radius"] = rng.choice([0.12, 0.13, 0.15, 0.155, 0.17], 22)
+            tabs["gb_scale"] = rng.choice([0.72, 0.79, 0.85], 22)
+        ff_t = {k: torch.as_tensor(v) for k, v in tabs.items()}
+        ff_t = {k: (v.long() if "idx" in k else v.double()) for k, v in ff_t.items()}
+        scale, n, d = 0.1640, 22, 3
+        e = ForceFieldEnergy(tabs, n_particles=22, temperature=300.0, data_normalization_factor=scale, cutoff=0.45)
+        x0 = ((torch.tensor(pos.reshape(-1), dtype=torch.float32)[None] + 0.004 * torch.randn(4099, 66, generator=gen)) / scale).cuda()
+        lf = lambda x: O.ff_logp_force(x.double(), ff_t, e.kT, scale, 0.45)
+    elif target.startswith("lj13"):
         e, n, d = pa.LennardJonesEnergy(39, 13, 3), 13, 3
         x0 = cu(golden("post_lj13.npz")["x0"])
         x0 = x0.repeat(9, 1)[: (577 if target.endswith("ragged") else 512)]
@@ -1558,6 +1574,8 @@ def test_fused_descent_equals_per_step(pa, golden, target, langevin):
         x0 = (torch.randn(1000, 8, generator=gen) * 1.5).cuda()
         lf = lambda x: O.dw4_logp_force(x, 4, 2)
     S, dt = 12, 1e-4
+    if target.startswith("ff22"):
+        S, dt = 6, 1e-7  # forces of a stiff molecule are ~1e4 in model units
     mk = lambda: pa.WeightedSDEIntegrator(sde=None, num_integration_steps=1, start_resampling_step=0,
                                           end_resampling_step=1, num_negative_time_steps=S, dt_negative_time=dt,
                                           do_langevin=langevin, seed=3)
@@ -1569,6 +1587,11 @@ def test_fused_descent_equals_per_step(pa, golden, target, langevin):
     xf = mk().negative_time_descent(x0, e, noise=nz.cuda())
     xs = mk().negative_time_descent(x0, e, noise=nz.cuda(), fused=False)
     assert torch.equal(xf, xs)
+    if target.startswith("ff22"):  # the fp64 oracle on a sample of the walkers
+        sel = torch.arange(0, x0.shape[0], 173)
+        xo = O.negative_time_descent(x0.cpu()[sel], lf, S, dt, n, d, do_langevin=langevin, noise_fn=lambda k, s: nz[k][sel])
+        assert rel(xf[sel.cuda()], xo) < 1e-5
+        return
     xo = O.negative_time_descent(x0.cpu(), lf, S, dt, n, d, do_langevin=langevin, noise_fn=lambda k, s: nz[k])
     assert rel(xf, xo) < 1e-5
 
