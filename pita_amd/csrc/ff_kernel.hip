@@ -28,6 +28,7 @@ struct FfParams {
   const unsigned* blob;  // all tables, contiguous (each padded to 16 B); staged into LDS once per block
   int blob_words;
   int o_bond_idx, o_bond_par, o_angle_idx, o_angle_par, o_tors_idx, o_tors_par, o_pair_idx, o_pair_par, o_gb_par;  // word offsets
+  int o_tors_cs;         // word offset of tors_cs[nt][2] = (cos phase, sin phase), computed on the host in double
   int o_csr_off, o_csr_ent;  // per-atom interaction lists: csr_off[3][n+1] (bonds, angles, torsions), entries (term << 2) | role
   const float* x; float* logp; float* force;
   long long B;
@@ -60,6 +61,7 @@ __global__ void __launch_bounds__(FF_THREADS) ff_kernel(FfParams p) {
   const float* angle_par = reinterpret_cast<const float*>(tb + p.o_angle_par);
   const int* tors_idx = reinterpret_cast<const int*>(tb + p.o_tors_idx);
   const float* tors_par = reinterpret_cast<const float*>(tb + p.o_tors_par);
+  const float* tors_cs = reinterpret_cast<const float*>(tb + p.o_tors_cs);  // [nt][2] cos, sin of the phase
   const float* pair_par = reinterpret_cast<const float*>(tb + p.o_pair_par);
   const float* gb_par = reinterpret_cast<const float*>(tb + p.o_gb_par);
   const int* csr_off = reinterpret_cast<const int*>(tb + p.o_csr_off);  // [3][n+1]: bonds, angles, torsions
@@ -69,7 +71,9 @@ __global__ void __launch_bounds__(FF_THREADS) ff_kernel(FfParams p) {
   float* es = gs + WPB * D;        // [WPB][n] energy partials
   float* br = es + WPB * n;        // [WPB][n] Born radii
   float* bw = br + WPB * n;        // [WPB][n] dE/d(HCT sum)
-  float* xu = bw + WPB * n;        // DESCENT: [WPB][D] walkers in model units, resident over the steps
+  const int n_slots = 2 * p.nb + 3 * p.na + 4 * p.nt;  // gradient slots of the bonded terms: one per (term, participating atom)
+  float* tg = bw + WPB * n;        // [WPB][n_slots][3] bonded-term gradients, phase 1 -> phase 2
+  float* xu = tg + WPB * 3 * n_slots;  // DESCENT: [WPB][D] walkers in model units, resident over the steps
   float* vv = xu + WPB * D;        // DESCENT: [WPB][D] updated walkers before the centring
   const int tid = threadIdx.x, wl = tid / n, a = tid - wl * n;
   const bool lane_on = wl < WPB;
@@ -88,74 +92,103 @@ __global__ void __launch_bounds__(FF_THREADS) ff_kernel(FfParams p) {
     const float* xr = xs + (act ? wl : 0) * D;
     const float xa0 = xr[3 * a % D], xa1 = xr[(3 * a + 1) % D], xa2 = xr[(3 * a + 2) % D];
     float E = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
-    if (act) {
-      // ---- HarmonicBondForce: 1/2 k (r - r0)^2
-      for (int e = csr_off[a]; e < csr_off[a + 1]; ++e) {
-        const int t = csr_ent[e] >> 2, role = csr_ent[e] & 3;
-        const int i = 3 * bond_idx[2 * t], j = 3 * bond_idx[2 * t + 1];
-        const float r0 = bond_par[2 * t], k = bond_par[2 * t + 1];
-        const float d0 = xr[i] - xr[j], d1 = xr[i + 1] - xr[j + 1], d2 = xr[i + 2] - xr[j + 2];
-        const float r = sqrtf(fmaf(d0, d0, fmaf(d1, d1, d2 * d2)));
-        const float dr = r - r0;
-        if (role == 0) E = fmaf(0.5f * k * dr, dr, E);
-        const float c = (role == 0 ? k : -k) * dr / r;
-        g0 = fmaf(c, d0, g0); g1 = fmaf(c, d1, g1); g2 = fmaf(c, d2, g2);
-      }
-      // ---- HarmonicAngleForce: 1/2 k (theta - theta0)^2
-      for (int e = csr_off[n + 1 + a]; e < csr_off[n + 1 + a + 1]; ++e) {
-        const int t = csr_ent[e] >> 2, role = csr_ent[e] & 3;
-        const int i = 3 * angle_idx[3 * t], j = 3 * angle_idx[3 * t + 1], k3 = 3 * angle_idx[3 * t + 2];
-        const float th0 = angle_par[2 * t], k = angle_par[2 * t + 1];
-        float av[3], bv[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { av[c] = xr[i + c] - xr[j + c]; bv[c] = xr[k3 + c] - xr[j + c]; }
-        const float aa = fmaf(av[0], av[0], fmaf(av[1], av[1], av[2] * av[2]));
-        const float bb = fmaf(bv[0], bv[0], fmaf(bv[1], bv[1], bv[2] * bv[2]));
-        const float ab = fmaf(av[0], bv[0], fmaf(av[1], bv[1], av[2] * bv[2]));
-        const float inv = 1.0f / sqrtf(aa * bb);
-        const float cosv = fminf(fmaxf(ab * inv, -1.0f), 1.0f);
-        const float dth = acosf(cosv) - th0;
-        if (role == 0) E = fmaf(0.5f * k * dth, dth, E);
-        const float sinv = fmaxf(sqrtf(fmaf(-cosv, cosv, 1.0f)), 1e-6f);
-        const float dEdc = -k * dth / sinv;  // dE/dcos
-        float gg[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float gi = dEdc * (bv[c] * inv - cosv * av[c] / aa);
-          const float gk = dEdc * (av[c] * inv - cosv * bv[c] / bb);
-          gg[c] = role == 0 ? gi : (role == 2 ? gk : -(gi + gk));
+    // ---- bonded terms, two phases (round 6).  Phase 1: one thread per TERM (the walker's threads deal the bonds, angles and
+    //      torsions out among themselves) evaluates it ONCE and parks the gradient of every participating atom in LDS;
+    //      phase 2: one thread per ATOM adds up its slots through the per-atom lists.  Before, every participating atom
+    //      re-evaluated the whole term (angles 3x, torsions 4x, with acosf / atan2f / sinf / cosf each time) and the atom
+    //      sitting in the most torsions set the pace of its wave.
+    {
+      float* tgw = tg + (act ? wl : 0) * (3 * n_slots);
+      if (act) {
+        // HarmonicBondForce: 1/2 k (r - r0)^2; slots [2 t + role]
+        for (int t = a; t < p.nb; t += n) {
+          const int i = 3 * bond_idx[2 * t], j = 3 * bond_idx[2 * t + 1];
+          const float r0 = bond_par[2 * t], k = bond_par[2 * t + 1];
+          const float d0 = xr[i] - xr[j], d1 = xr[i + 1] - xr[j + 1], d2 = xr[i + 2] - xr[j + 2];
+          const float r = sqrtf(fmaf(d0, d0, fmaf(d1, d1, d2 * d2)));
+          const float dr = r - r0;
+          E = fmaf(0.5f * k * dr, dr, E);
+          const float c = k * dr / r;
+          float* o = tgw + 3 * (2 * t);
+          o[0] = c * d0; o[1] = c * d1; o[2] = c * d2;
+          o[3] = -c * d0; o[4] = -c * d1; o[5] = -c * d2;
         }
-        g0 += gg[0]; g1 += gg[1]; g2 += gg[2];
-      }
-      // ---- PeriodicTorsionForce: k (1 + cos(n phi - phase))
-      for (int e = csr_off[2 * (n + 1) + a]; e < csr_off[2 * (n + 1) + a + 1]; ++e) {
-        const int t = csr_ent[e] >> 2, role = csr_ent[e] & 3;
-        const int i = 3 * tors_idx[4 * t], j = 3 * tors_idx[4 * t + 1], k3 = 3 * tors_idx[4 * t + 2], l = 3 * tors_idx[4 * t + 3];
-        const float per = tors_par[3 * t], ph = tors_par[3 * t + 1], k = tors_par[3 * t + 2];
-        float b1[3], b2[3], b3[3];
+        // HarmonicAngleForce: 1/2 k (theta - theta0)^2; slots [2 nb + 3 t + role]
+        for (int t = a; t < p.na; t += n) {
+          const int i = 3 * angle_idx[3 * t], j = 3 * angle_idx[3 * t + 1], k3 = 3 * angle_idx[3 * t + 2];
+          const float th0 = angle_par[2 * t], k = angle_par[2 * t + 1];
+          float av[3], bv[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { b1[c] = xr[j + c] - xr[i + c]; b2[c] = xr[k3 + c] - xr[j + c]; b3[c] = xr[l + c] - xr[k3 + c]; }
-        const float n1[3] = {b1[1] * b2[2] - b1[2] * b2[1], b1[2] * b2[0] - b1[0] * b2[2], b1[0] * b2[1] - b1[1] * b2[0]};
-        const float n2[3] = {b2[1] * b3[2] - b2[2] * b3[1], b2[2] * b3[0] - b2[0] * b3[2], b2[0] * b3[1] - b2[1] * b3[0]};
-        const float b22 = fmaf(b2[0], b2[0], fmaf(b2[1], b2[1], b2[2] * b2[2]));
-        const float nb2 = sqrtf(b22);
-        const float yv = (b1[0] * n2[0] + b1[1] * n2[1] + b1[2] * n2[2]) * nb2;
-        const float xv = n1[0] * n2[0] + n1[1] * n2[1] + n1[2] * n2[2];
-        const float ang = fmaf(per, atan2f(yv, xv), -ph);
-        if (role == 0) E += k * (1.0f + cosf(ang));
-        const float dEdphi = -k * per * sinf(ang);
-        const float n11 = fmaxf(n1[0] * n1[0] + n1[1] * n1[1] + n1[2] * n1[2], 1e-20f);
-        const float n22 = fmaxf(n2[0] * n2[0] + n2[1] * n2[1] + n2[2] * n2[2], 1e-20f);
-        const float pq = (b1[0] * b2[0] + b1[1] * b2[1] + b1[2] * b2[2]) / b22;
-        const float qq = (b3[0] * b2[0] + b3[1] * b2[1] + b3[2] * b2[2]) / b22;
-        const float ci = -nb2 / n11, cl = nb2 / n22;
-        // d phi / d r: role 0 -> i, 1 -> j, 2 -> k, 3 -> l
-        const float wi = role == 0 ? 1.0f : (role == 1 ? -(pq + 1.0f) : (role == 2 ? pq : 0.f));
-        const float wlc = role == 3 ? 1.0f : (role == 2 ? -(qq + 1.0f) : (role == 1 ? qq : 0.f));
-        g0 = fmaf(dEdphi, wi * ci * n1[0] + wlc * cl * n2[0], g0);
-        g1 = fmaf(dEdphi, wi * ci * n1[1] + wlc * cl * n2[1], g1);
-        g2 = fmaf(dEdphi, wi * ci * n1[2] + wlc * cl * n2[2], g2);
+          for (int c = 0; c < 3; ++c) { av[c] = xr[i + c] - xr[j + c]; bv[c] = xr[k3 + c] - xr[j + c]; }
+          const float aa = fmaf(av[0], av[0], fmaf(av[1], av[1], av[2] * av[2]));
+          const float bb = fmaf(bv[0], bv[0], fmaf(bv[1], bv[1], bv[2] * bv[2]));
+          const float ab = fmaf(av[0], bv[0], fmaf(av[1], bv[1], av[2] * bv[2]));
+          const float inv = 1.0f / sqrtf(aa * bb);
+          const float cosv = fminf(fmaxf(ab * inv, -1.0f), 1.0f);
+          const float dth = acosf(cosv) - th0;
+          E = fmaf(0.5f * k * dth, dth, E);
+          const float sinv = fmaxf(sqrtf(fmaf(-cosv, cosv, 1.0f)), 1e-6f);
+          const float dEdc = -k * dth / sinv;  // dE/dcos
+          float* o = tgw + 3 * (2 * p.nb + 3 * t);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float gi = dEdc * (bv[c] * inv - cosv * av[c] / aa);
+            const float gk = dEdc * (av[c] * inv - cosv * bv[c] / bb);
+            o[c] = gi; o[3 + c] = -(gi + gk); o[6 + c] = gk;
+          }
+        }
+        // PeriodicTorsionForce: k (1 + cos(n phi - phase)); slots [2 nb + 3 na + 4 t + role].  cos / sin of n phi by the
+        // angle-addition recurrence from (cos phi, sin phi) = (x, y) / |(x, y)| -- no atan2f / sinf / cosf per term; the
+        // periodicity is an integer in OpenMM; cos / sin of the phase come from the host (tors_cs)
+        for (int t = a; t < p.nt; t += n) {
+          const int i = 3 * tors_idx[4 * t], j = 3 * tors_idx[4 * t + 1], k3 = 3 * tors_idx[4 * t + 2], l = 3 * tors_idx[4 * t + 3];
+          const float per = tors_par[3 * t], k = tors_par[3 * t + 2];
+          const float cph = tors_cs[2 * t], sph = tors_cs[2 * t + 1];
+          float b1[3], b2[3], b3[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { b1[c] = xr[j + c] - xr[i + c]; b2[c] = xr[k3 + c] - xr[j + c]; b3[c] = xr[l + c] - xr[k3 + c]; }
+          const float n1[3] = {b1[1] * b2[2] - b1[2] * b2[1], b1[2] * b2[0] - b1[0] * b2[2], b1[0] * b2[1] - b1[1] * b2[0]};
+          const float n2[3] = {b2[1] * b3[2] - b2[2] * b3[1], b2[2] * b3[0] - b2[0] * b3[2], b2[0] * b3[1] - b2[1] * b3[0]};
+          const float b22 = fmaf(b2[0], b2[0], fmaf(b2[1], b2[1], b2[2] * b2[2]));
+          const float nb2 = sqrtf(b22);
+          const float yv = (b1[0] * n2[0] + b1[1] * n2[1] + b1[2] * n2[2]) * nb2;
+          const float xv = n1[0] * n2[0] + n1[1] * n2[1] + n1[2] * n2[2];
+          const float nrm = sqrtf(fmaf(xv, xv, yv * yv));
+          const float c1 = nrm > 0.f ? xv / nrm : 1.0f, s1 = nrm > 0.f ? yv / nrm : 0.0f;
+          float cn = 1.0f, sn = 0.0f;
+          const int nper = (int)per;
+          for (int q = 0; q < nper; ++q) {
+            const float cc = cn * c1 - sn * s1, ss = sn * c1 + cn * s1;
+            cn = cc; sn = ss;
+          }
+          E += k * (1.0f + (cn * cph + sn * sph));
+          const float dEdphi = -k * per * (sn * cph - cn * sph);
+          const float n11 = fmaxf(n1[0] * n1[0] + n1[1] * n1[1] + n1[2] * n1[2], 1e-20f);
+          const float n22 = fmaxf(n2[0] * n2[0] + n2[1] * n2[1] + n2[2] * n2[2], 1e-20f);
+          const float pq = (b1[0] * b2[0] + b1[1] * b2[1] + b1[2] * b2[2]) / b22;
+          const float qq = (b3[0] * b2[0] + b3[1] * b2[1] + b3[2] * b2[2]) / b22;
+          const float ci = -nb2 / n11, cl = nb2 / n22;
+          // d phi / d r of the four atoms: i: ci n1; j: -(pq + 1) ci n1 + qq cl n2; k: pq ci n1 - (qq + 1) cl n2; l: cl n2
+          const float wi[4] = {1.0f, -(pq + 1.0f), pq, 0.f}, wlc[4] = {0.f, qq, -(qq + 1.0f), 1.0f};
+          float* o = tgw + 3 * (2 * p.nb + 3 * p.na + 4 * t);
+#pragma unroll
+          for (int role = 0; role < 4; ++role)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[3 * role + c] = dEdphi * (wi[role] * ci * n1[c] + wlc[role] * cl * n2[c]);
+        }
       }
+      __syncthreads();
+      if (act) {
+        const int kind_base[3] = {0, 2 * p.nb, 2 * p.nb + 3 * p.na}, arity[3] = {2, 3, 4};
+        for (int kind = 0; kind < 3; ++kind)
+          for (int e = csr_off[kind * (n + 1) + a]; e < csr_off[kind * (n + 1) + a + 1]; ++e) {
+            const int t = csr_ent[e] >> 2, role = csr_ent[e] & 3;
+            const float* o = tgw + 3 * (kind_base[kind] + arity[kind] * t + role);
+            g0 += o[0]; g1 += o[1]; g2 += o[2];
+          }
+      }
+    }
+    if (act) {
       // ---- NonbondedForce: every partner j of atom a (exceptions carry their own parameters)
       for (int j = 0; j < n; ++j) {
         if (j == a) continue;
@@ -399,7 +432,13 @@ extern "C" int pita_ff_create(pita_ff_t** out, const pita_ff_config* c) {
     }
   }
   const size_t b_co = sizeof(int) * 3 * (n + 1), b_ce = sizeof(int) * (n_ent > 0 ? n_ent : 1);
-  const size_t total = b_bi + b_bp + b_ai + b_ap + b_ti + b_tp + b_pi + b_pp + b_gb + b_co + b_ce + 16 * 11;  // each table padded to 16 B
+  const size_t b_tc = sizeof(float) * 2 * c->n_torsions;
+  float* tcs = new float[2 * (c->n_torsions > 0 ? c->n_torsions : 1)];
+  for (int t = 0; t < c->n_torsions; ++t) {
+    tcs[2 * t] = (float)cos((double)c->tors_par[3 * t + 1]);
+    tcs[2 * t + 1] = (float)sin((double)c->tors_par[3 * t + 1]);
+  }
+  const size_t total = b_bi + b_bp + b_ai + b_ap + b_ti + b_tp + b_tc + b_pi + b_pp + b_gb + b_co + b_ce + 16 * 12;  // each table padded to 16 B
   pita_ff* ff = new pita_ff();
   hipError_t e = hipMalloc(&ff->d_all, total);
   char* base = static_cast<char*>(ff->d_all);
@@ -416,6 +455,7 @@ extern "C" int pita_ff_create(pita_ff_t** out, const pita_ff_config* c) {
     p.o_bond_idx = word_off(put(c->bond_idx, b_bi)); p.o_bond_par = word_off(put(c->bond_par, b_bp));
     p.o_angle_idx = word_off(put(c->angle_idx, b_ai)); p.o_angle_par = word_off(put(c->angle_par, b_ap));
     p.o_tors_idx = word_off(put(c->tors_idx, b_ti)); p.o_tors_par = word_off(put(c->tors_par, b_tp));
+    p.o_tors_cs = word_off(put(tcs, b_tc));
     p.o_pair_idx = word_off(put(pidx, b_pi)); p.o_pair_par = word_off(put(ppar, b_pp));
     p.o_gb_par = word_off(put(gpar, b_gb));
     p.o_csr_off = word_off(put(csr_off, b_co)); p.o_csr_ent = word_off(put(csr_ent, b_ce));
@@ -427,6 +467,7 @@ extern "C" int pita_ff_create(pita_ff_t** out, const pita_ff_config* c) {
   delete[] gpar;
   delete[] csr_off;
   delete[] csr_ent;
+  delete[] tcs;
   if (e != hipSuccess) {
     (void)hipFree(ff->d_all);
     delete ff;
@@ -465,7 +506,7 @@ extern "C" int pita_ff_logp_force(pita_ff_t* ff, const float* x, float* logp, fl
   FfParams p = ff->p;
   p.x = x; p.logp = logp; p.force = force; p.B = B;
   const int WPB = FF_THREADS / p.n;
-  const size_t lds = sizeof(float) * ((size_t)p.blob_words + (size_t)WPB * (2 * 3 * p.n + 3 * p.n));
+  const size_t lds = sizeof(float) * ((size_t)p.blob_words + (size_t)WPB * (2 * 3 * p.n + 3 * p.n + 3 * (2 * p.nb + 3 * p.na + 4 * p.nt)));
   PITA_REQUIRE(lds <= 64 * 1024, "pita_ff_logp_force: interaction tables do not fit in LDS");
   const long long nblk = (B + WPB - 1) / WPB;
   const long long cap = 256LL * 8;  // persistent blocks: the tables are staged once per block
@@ -484,7 +525,7 @@ extern "C" int pita_ff_descent(pita_ff_t* ff, float* x, const float* noise, int6
   p.xio = x; p.noise = noise; p.B = B; p.steps = n_steps; p.dt = dt; p.noise_scale = noise_scale; p.sqrt_dt = sqrt_dt;
   p.seed = seed; p.walker_offset = walker_offset; p.step0 = step0; p.remove_mean = remove_mean;
   const int WPB = FF_THREADS / p.n;
-  const size_t lds = sizeof(float) * ((size_t)p.blob_words + (size_t)WPB * (4 * 3 * p.n + 3 * p.n));
+  const size_t lds = sizeof(float) * ((size_t)p.blob_words + (size_t)WPB * (4 * 3 * p.n + 3 * p.n + 3 * (2 * p.nb + 3 * p.na + 4 * p.nt)));
   PITA_REQUIRE(lds <= 64 * 1024, "pita_ff_descent: interaction tables do not fit in LDS");
   const long long nblk = (B + WPB - 1) / WPB;
   const long long cap = 256LL * 8;
