@@ -364,6 +364,11 @@ extern "C" int pita_ff_create(pita_ff_t** out, const pita_ff_config* c) {
   PITA_REQUIRE((c->n_bonds == 0 || (c->bond_idx && c->bond_par)) && (c->n_angles == 0 || (c->angle_idx && c->angle_par)) &&
                    (c->n_torsions == 0 || (c->tors_idx && c->tors_par)) && (c->n_exceptions == 0 || (c->exc_idx && c->exc_par)),
                "pita_ff_create: table pointer missing");
+  for (int t = 0; t < c->n_torsions; ++t) {  // cos / sin(n phi - phase) come from an angle-addition recurrence over n
+    const float per = c->tors_par[3 * t];
+    PITA_REQUIRE(per >= 0.f && per <= 12.f && per == (float)(int)per,
+                 "pita_ff_create: torsion periodicity must be an integer in [0, 12] (OpenMM PeriodicTorsionForce)");
+  }
   const int n = c->n_atoms, np = n * (n - 1) / 2;
   auto check_idx = [&](const int* idx, int cnt) {
     for (int i = 0; i < cnt; ++i)

@@ -2846,6 +2846,11 @@ def test_forcefield_vs_oracle(pa, cutoff, gb):
     np.testing.assert_allclose(lp[idx.cuda()].cpu().numpy(), lpo.numpy(), rtol=2e-5, atol=2e-3)
     assert rel(f[idx.cuda()], fo) < 5e-5
     assert abs(f.reshape(B, 22, 3).sum(1)).max() < 1e-3 * f.abs().max().item()  # translation invariance
+    # the torsion angle enters through an angle-addition recurrence over its (integer) periodicity: anything else is refused
+    bad = {k: np.array(v, copy=True) for k, v in tabs.items()}
+    bad["tors_par"][0, 0] = 2.5
+    with pytest.raises(pa._lib.PitaHipError, match="periodicity"):
+        ForceFieldEnergy(bad, n_particles=22, temperature=300.0, data_normalization_factor=scale, cutoff=cutoff)(x[:4].cuda())
 
 
 def test_alp_energy_from_system_xml_vs_oracle(pa, golden):
