@@ -107,6 +107,18 @@ __global__ void __launch_bounds__(256, 1) dir_mid_kernel(Params p) {
     for (int q = 0; q < 4; ++q) { dpos[ks].hi[q] = 0x3c003c00u + ((lane * 7 + q) & 0xff); dpos[ks].lo[q] = 0x10001000u + (lane & 0xff); }
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   unsigned char* myzb = zb + wave * N * ZB_NODE_B;
+  // everything the node finish multiplies with stays in registers for the whole launch (a lone wave has 512): the four weight
+  // matrices as A fragments (64 registers) and the K = 64 coefficient rows (48); the first version of this micro-kernel
+  // fetched them from L2 inside every node finish and paid the latency each time (node finish 92 k cycles per walker)
+  WMat wa_r, wn1a_r, wn1b_r, wn2_r;
+  load_w(wa_r, p.wfrag, 0, lane);
+  load_w(wn1a_r, p.wfrag, 3, lane);
+  load_w(wn1b_r, p.wfrag, 4, lane);
+  load_w(wn2_r, p.wfrag, 5, lane);
+  float rrow[48];
+#pragma unroll
+  for (int q = 0; q < 48; ++q) rrow[q] = p.rtab[lane * 48 + q];
+  const f32x4 gn0 = *reinterpret_cast<const f32x4*>(p.init + 4 * g), gn1 = *reinterpret_cast<const f32x4*>(p.init + 16 + 4 * g);
   long long tN = 0, tB = 0, tM = 0, tW = 0, tF = 0;
 
   // partial sums of M over the edges THIS wave built for the current node (rows 0..31: 16 values, rows 32..: 8)
@@ -253,10 +265,8 @@ __global__ void __launch_bounds__(256, 1) dir_mid_kernel(Params p) {
         Frag xh;
         to_frag(dH[0], xh);   // the node being finished is always dH[0]: the array is rotated by one node below (104 moves per
                               // node -- a register-resident dH of all 13 nodes cannot be indexed by a run-time node)
-        WMat wa;
-        load_w(wa, p.wfrag, 0, lane);
         f32x4 za[2] = {zero4, zero4};
-        gemm(wa, xh, za);
+        gemm(wa_r, xh, za);
         Frag xa;
         to_frag(za, xa);
         Frag ab[3];
@@ -275,33 +285,27 @@ __global__ void __launch_bounds__(256, 1) dir_mid_kernel(Params p) {
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
           for (int rb = 0; rb < 3; ++rb) {
-            const float* rp = p.rtab + lane * 48 + (ks * 3 + rb) * 8;
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(rp), a1 = *reinterpret_cast<const f32x4*>(rp + 4);
-            const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const float* rp = rrow + (ks * 3 + rb) * 8;
+            const float v[8] = {rp[0], rp[1], rp[2], rp[3], rp[4], rp[5], rp[6], rp[7]};
             Frag rm;
             split8(v, rm.hi, rm.lo);
             acc[rb] = mma3(rm, dpos[ks], acc[rb]);
           }
         }
         // (3) node model: dH_i += W_n2 (g_n o (W_n1a dH_i + W_n1b Acc_i)); rows 32.. update the position tangent
-        WMat wn;
         f32x4 zn[2] = {zero4, zero4};
-        load_w(wn, p.wfrag, 3, lane);
-        gemm(wn, xh, zn);
+        gemm(wn1a_r, xh, zn);
         Frag xg;
         {
           const f32x4 a2[2] = {acc[0], acc[1]};
           to_frag(a2, xg);
         }
-        load_w(wn, p.wfrag, 4, lane);
-        gemm(wn, xg, zn);
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.init + ((i * 32 + 4 * g) & 4092)), g1 = *reinterpret_cast<const f32x4*>(p.init + ((i * 32 + 16 + 4 * g) & 4092));
-        zn[0] *= g0; zn[1] *= g1;
+        gemm(wn1b_r, xg, zn);
+        zn[0] *= gn0; zn[1] *= gn1;
         Frag xz;
         to_frag(zn, xz);
-        load_w(wn, p.wfrag, 5, lane);
         f32x4 nh[2] = {zero4, zero4};
-        gemm(wn, xz, nh);
+        gemm(wn2_r, xz, nh);
         {
           f32x4 upd[2];
 #pragma unroll
